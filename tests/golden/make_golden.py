@@ -1,0 +1,355 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REAL reference.
+
+Runs only in the build container (the reference tree is not on the GPU box):
+
+    python tests/golden/make_golden.py /root/reference
+
+It imports the reference's own ``snekmer.alphabet`` / ``snekmer.vectorize`` / ``snekmer.score``
+modules through an empty stub package (``import snekmer`` itself needs seaborn/hdbscan, which
+are absent) and scikit-learn's ``cosine_similarity`` (the reference's
+un-vendored dependency), feeds them the inputs below and stores inputs + outputs.  The
+Snakemake rule bodies cannot be imported (no snakemake), so the small loops that surround
+the imported calls in ``rules/kmerize.smk:89-129`` and ``rules/learn.smk:359-383`` are
+re-expressed here around the *imported* ``KmerVec.reduce_vectorize`` / ``reduce``.
+
+Fixtures are data only: inputs and expected outputs.
+"""
+import json
+import os
+import shutil
+import sys
+import types
+from collections import Counter
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+
+def import_reference(ref_root):
+    pkg = types.ModuleType("snekmer")
+    pkg.__path__ = [os.path.join(ref_root, "snekmer")]
+    sys.modules["snekmer"] = pkg
+    import snekmer.alphabet as alphabet  # noqa
+    import snekmer.vectorize as vectorize  # noqa
+    import snekmer.score as score  # noqa
+    import snekmer.utils as utils  # noqa
+
+    return alphabet, vectorize, score, utils
+
+
+RED6 = {"AGILMV": "A", "PH": "P", "FWY": "F", "NQSTC": "N", "DE": "D", "KR": "K", "_keys": "APFNDK"}
+
+EDGE_STRINGS = [
+    "",
+    "MKV",
+    "mkvlaagi",
+    "MKVL*AGIW**",
+    "MKVLXAGIWST",
+    "MKBBPG*",
+    "MKEEKNR",
+    "MKVLAAGIWSTXAAAA*",
+    "***",
+    "*MKVLAAGIW",
+    "MKVLAAGIWSTCDEFHNPQRY",
+    "AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA",
+    "MK-_!VLA^#$@.%&GIW",
+    "MKVL AAGIW\tSTC",
+    "MKUVLOAAGIWZSTJC",
+    "MKVLAAGIWSTCDEFHNPQRYMKVLAAGIWSTCDEFHNPQRYMKVLAAGIWSTCDEFHNPQRY*",
+    "MKÄVLAAGIWαSTC",
+]
+EDGE_KS = [1, 3, 8, 12, 14, 20]
+
+
+def read_fasta(path):
+    recs, name, chunks = [], None, []
+    for line in open(path):
+        line = line.rstrip("\r\n")
+        if line.startswith(">"):
+            if name is not None:
+                recs.append((name, "".join(chunks)))
+            name, chunks = line[1:].split()[0], []
+        else:
+            chunks.append(line.strip())
+    if name is not None:
+        recs.append((name, "".join(chunks)))
+    return recs
+
+
+def run_rule(V, A, records, alphabet, k, min_filter=0, basis=None):
+    """Drive the imported reference objects the way rules/kmerize.smk:67-139 does."""
+    kmer = V.KmerVec(alphabet=alphabet, k=k)
+    if basis is None:
+        tally = {}
+        for _, seq in records:
+            for key in kmer.reduce_vectorize(seq):
+                tally[key] = tally.get(key, 0) + 1
+        names = np.array(list(tally.keys()))
+        keep = np.array(list(tally.values())) > min_filter
+        kmerbasis = names[keep] if len(names) else names
+    else:
+        kmerbasis = list(basis)
+    kmer.set_kmer_set(kmerbasis)
+    vecs = np.zeros((len(records), len(kmerbasis)))
+    seqs, ids, lengths = [], [], []
+    for n, (rid, seq) in enumerate(records):
+        present = kmer.reduce_vectorize(seq)
+        vecs[n][np.isin(kmerbasis, present)] = 1
+        seqs.append(V.reduce(seq, alphabet=alphabet, mapping=A.FULL_ALPHABETS))
+        ids.append(rid)
+        lengths.append(len(seq))
+    return dict(
+        kmerlist=np.asarray(kmerbasis, dtype=str),
+        ids=np.asarray(ids, dtype=str),
+        seqs=np.asarray(seqs, dtype=str),
+        vecs=vecs,
+        lengths=np.asarray(lengths),
+    )
+
+
+def run_counts(seqs, kmerlist):
+    """Count projection as rules/learn.smk:359-383 / rules/apply.smk:188-206 define it:
+    all length-k substrings of the reduced string, looked up in kmerlist order."""
+    k = len(kmerlist[0])
+    rows = []
+    for v in seqs:
+        v = str(v)
+        tally = Counter(v[i : i + k] for i in range(0, len(v) - k + 1))
+        rows.append([tally.get(str(km), 0) for km in kmerlist])
+    return np.asarray(rows, dtype=np.int64).reshape(len(seqs), len(kmerlist))
+
+
+def to_csr(M):
+    rows, cols = np.nonzero(M)
+    rowptr = np.zeros(M.shape[0] + 1, dtype=np.int64)
+    np.add.at(rowptr, rows + 1, 1)
+    return np.cumsum(rowptr), cols.astype(np.int32), M[rows, cols].astype(np.int32)
+
+
+def main(ref_root):
+    A, V, S, U = import_reference(ref_root)
+    from sklearn.metrics.pairwise import cosine_similarity
+    import scipy.sparse as sp
+
+    A.ALPHABETS["red6"] = dict(RED6)
+    A.FULL_ALPHABETS["red6"] = {}
+    for grp, letter in RED6.items():
+        if grp != "_keys":
+            A.FULL_ALPHABETS["red6"].update({c: letter for c in grp})
+
+    alpha_names = ["hydro", "standard", "solvacc", "hydrocharge", "hydrostruct", "miqs", "ptm", "None", "red6"]
+
+    # ---- G1: alphabet tables -------------------------------------------------------
+    g1 = {}
+    for name in alpha_names:
+        g1[name] = {
+            "full": A.FULL_ALPHABETS[name],
+            "char_set": sorted(A.get_alphabet_keys(name)),
+            "short": A.get_alphabet(name),
+        }
+    g1["_meta"] = {
+        "ALPHABET_ORDER": {str(k): v for k, v in A.ALPHABET_ORDER.items()},
+        "ALPHABET2ID": A.ALPHABET2ID,
+        "ALPHABET_ID": A.ALPHABET_ID,
+        "StandardAlphabet": A.StandardAlphabet,
+        "check_valid_error": None,
+    }
+    try:
+        A.check_valid("no-such-alphabet")
+    except ValueError as e:
+        g1["_meta"]["check_valid_error"] = str(e)
+    json.dump(g1, open(os.path.join(HERE, "g1_alphabets.json"), "w"), indent=1, sort_keys=True)
+
+    # ---- G2: edge strings ----------------------------------------------------------
+    g2 = []
+    for name in alpha_names:
+        for s in EDGE_STRINGS:
+            red = V.reduce(s, alphabet=name, mapping=A.FULL_ALPHABETS)
+            for k in EDGE_KS:
+                out = V.KmerVec(name, k).reduce_vectorize(s)
+                g2.append(
+                    {
+                        "alphabet": name,
+                        "k": k,
+                        "seq": s,
+                        "reduced": red,
+                        "kmers": [str(x) for x in out],
+                        "dtype": str(out.dtype),
+                        "shape": list(out.shape),
+                    }
+                )
+    json.dump(g2, open(os.path.join(HERE, "g2_edge_cases.json"), "w"), ensure_ascii=True)
+
+    # ---- demo FASTA inputs (data files the reference ships) -------------------------
+    demo_dir = os.path.join(ref_root, "resources", "tutorial", "demo_example", "input")
+    os.makedirs(os.path.join(HERE, "data"), exist_ok=True)
+    demo_files = sorted(f for f in os.listdir(demo_dir) if f.endswith(".faa"))
+    records, file_of = [], []
+    for fi, f in enumerate(demo_files):
+        shutil.copyfile(os.path.join(demo_dir, f), os.path.join(HERE, "data", f))
+        os.chmod(os.path.join(HERE, "data", f), 0o644)
+        recs = read_fasta(os.path.join(demo_dir, f))
+        records += recs
+        file_of += [fi] * len(recs)
+    file_of = np.asarray(file_of)
+
+    # ---- G3/G4/G5: rule outputs, counts, cosine -------------------------------------
+    configs = [
+        ("hydro", 14, 0),
+        ("hydro", 14, 1),
+        ("hydro", 14, 2),
+        ("standard", 8, 0),
+        ("red6", 8, 0),
+        ("hydro", 20, 0),
+        ("solvacc", 8, 0),
+        ("miqs", 8, 0),
+        ("hydrocharge", 6, 0),
+        (None, 3, 0),
+    ]
+    summary = {}
+    for alphabet, k, mf in configs:
+        out = run_rule(V, A, records, alphabet, k, min_filter=mf)
+        counts = run_counts(out["seqs"], out["kmerlist"])
+        assert ((counts > 0) == (out["vecs"] > 0)).all()
+        cos = cosine_similarity(counts, counts)
+        totals = np.vstack([counts[file_of == fi].sum(axis=0) for fi in range(len(demo_files))])
+        cos_rect = cosine_similarity(totals, counts).T
+        rp, ci, cv = to_csr(counts)
+        tag = f"{alphabet}_k{k}_mf{mf}"
+        np.savez_compressed(
+            os.path.join(HERE, f"g3_demo_{tag}.npz"),
+            kmerlist=out["kmerlist"],
+            ids=out["ids"],
+            seqs=out["seqs"],
+            lengths=out["lengths"],
+            vecs_bits=np.packbits(out["vecs"].astype(bool), axis=1),
+            vecs_shape=np.asarray(out["vecs"].shape),
+            counts_rowptr=rp,
+            counts_col=ci,
+            counts_val=cv,
+            cosine=cos,
+            totals=totals,
+            cosine_rect=cos_rect,
+            file_of=file_of,
+        )
+        summary[tag] = dict(
+            basis=int(len(out["kmerlist"])),
+            nnz=int((counts > 0).sum()),
+            total=int(counts.sum()),
+            max=int(counts.max()) if counts.size else 0,
+            first=str(out["kmerlist"][0]) if len(out["kmerlist"]) else None,
+        )
+
+    # basis.txt branch (kmerize.smk:72-78): explicit basis, file order, no filter
+    ref0 = run_rule(V, A, records, "hydro", 14)
+    explicit = [str(x) for x in ref0["kmerlist"][::7][:200]] + ["SSSSSSSSSSSSSS", "VVVVVVVVVVVVVX"]
+    out = run_rule(V, A, records, "hydro", 14, basis=explicit)
+    counts = run_counts(out["seqs"], out["kmerlist"])
+    rp, ci, cv = to_csr(counts)
+    np.savez_compressed(
+        os.path.join(HERE, "g3_demo_hydro_k14_basisfile.npz"),
+        kmerlist=out["kmerlist"],
+        ids=out["ids"],
+        seqs=out["seqs"],
+        lengths=out["lengths"],
+        vecs_bits=np.packbits(out["vecs"].astype(bool), axis=1),
+        vecs_shape=np.asarray(out["vecs"].shape),
+        counts_rowptr=rp,
+        counts_col=ci,
+        counts_val=cv,
+    )
+    json.dump(summary, open(os.path.join(HERE, "g3_summary.json"), "w"), indent=1, sort_keys=True)
+
+    # ---- G6: KmerBasis.transform ----------------------------------------------------
+    rng = np.random.default_rng(7)
+    kb = V.KmerBasis()
+    basis = ["AAA", "AAC", "ACA", "CCC", "CAC", "ZZZ"]
+    kb.set_basis(basis)
+    vec_basis = ["CAC", "AAA", "QQQ", "ACA"]
+    mat = rng.integers(0, 5, size=(4, len(vec_basis))).astype(float)
+    g6 = {
+        "basis": basis,
+        "vector_basis": vec_basis,
+        "matrix": mat.tolist(),
+        "out": kb.transform(mat, vec_basis).tolist(),
+        "errors": {},
+    }
+    for label, fn in {
+        "set_basis_type": lambda: V.KmerBasis().set_basis(5),
+        "vector_basis_type": lambda: kb.transform(mat, 5),
+        "shape_mismatch": lambda: kb.transform(mat, vec_basis[:2]),
+        "one_dim": lambda: kb.transform(mat[0], vec_basis),
+    }.items():
+        try:
+            fn()
+            g6["errors"][label] = None
+        except Exception as e:  # noqa
+            g6["errors"][label] = [type(e).__name__, str(e)]
+    kv = V.KmerVec("hydro", 3)
+    kv.set_kmer_set(["SSS", "SSV", "VVV"])
+    g6["harmonize"] = kv.harmonize(np.array([[1.0, 2.0], [3.0, 4.0]]), ["VVV", "SVS"]).tolist()
+    g6["kmervec_attrs"] = sorted(kv.__dict__.keys())
+    g6["kmerset_attrs"] = sorted(kv.kmer_set.__dict__.keys())
+    g6["kmerset_kmers"] = list(kv.kmer_set.kmers)
+    g6["snekmer_version"] = kv.snekmer_version
+    json.dump(g6, open(os.path.join(HERE, "g6_basis.json"), "w"), indent=1)
+
+    # ---- G7: make_feature_matrix ----------------------------------------------------
+    g7 = []
+    kvs = V.KmerVec("standard", 3)
+    ragged = [kvs.reduce_vectorize(s) for s in EDGE_STRINGS[3:12]]
+    for mf in (0, 1, 2):
+        res, kl = V.make_feature_matrix(ragged, min_filter=mf)
+        g7.append(
+            {
+                "min_filter": mf,
+                "vecs": [[str(x) for x in r] for r in ragged],
+                "kmerlist": [str(x) for x in kl],
+                "rows": [r.tolist() for r in res],
+            }
+        )
+    json.dump(g7, open(os.path.join(HERE, "g7_feature_matrix.json"), "w"))
+
+    # ---- G8: seeded synthetic families ------------------------------------------------
+    from snekmer_amd.synth import synth_families, to_records
+
+    for alphabet, k, idx in (("red6", 12, 2), ("standard", 12, 2), ("hydro", 20, 5)):
+        res, off, fam = synth_families(256, 300, family=16, seed=20250523 + idx)
+        recs = to_records(res, off)
+        out = run_rule(V, A, recs, alphabet, k)
+        counts = run_counts(out["seqs"], out["kmerlist"])
+        cos = cosine_similarity(sp.csr_matrix(counts), sp.csr_matrix(counts))
+        rp, ci, cv = to_csr(counts)
+        np.savez_compressed(
+            os.path.join(HERE, f"g8_synth_{alphabet}_k{k}.npz"),
+            residues=res,
+            offsets=off,
+            family=fam,
+            kmerlist=out["kmerlist"],
+            counts_rowptr=rp,
+            counts_col=ci,
+            counts_val=cv,
+            cosine=np.asarray(cos),
+            lengths=out["lengths"],
+        )
+
+    # ---- G9: score.connection_matrix_from_features / utils.to_feature_matrix ---------
+    X = rng.integers(0, 4, size=(9, 23)).astype(float)
+    X[3] = 0
+    np.savez_compressed(
+        os.path.join(HERE, "g9_connection.npz"),
+        X=X,
+        cosine=S.connection_matrix_from_features(X, metric="cosine"),
+        jaccard=S.connection_matrix_from_features(X > 0, metric="jaccard"),
+        tfm=U.to_feature_matrix([list(r) for r in X], length_array=np.arange(1, 10)),
+        tfm_default=U.to_feature_matrix([list(r) for r in X]),
+    )
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")

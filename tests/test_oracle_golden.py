@@ -1,0 +1,161 @@
+"""Pins the oracle (oracle/ref_path.py + oracle/kmer_oracle.c) and the host alphabet tables
+against fixtures generated from the imported reference (tests/golden/make_golden.py)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ALL_ALPHABETS, GOLDEN, alpha_key, csr_to_dense, demo_records, ensure_red6, gjson, gnpz, parse_tag
+from oracle import c_oracle, ref_path
+from snekmer_amd import alphabet as A
+from snekmer_amd.utils import pack_sequences, unpack_sequences
+
+ensure_red6()
+
+
+def test_g1_alphabet_tables():
+    g1 = gjson("g1_alphabets.json")
+    meta = g1.pop("_meta")
+    for name, ref in g1.items():
+        key = alpha_key(name)
+        assert A.FULL_ALPHABETS[name] == ref["full"]
+        assert sorted(A.get_alphabet_keys(key)) == ref["char_set"]
+        assert A.get_alphabet(key) == ref["short"]
+        lut = A.build_lut(key)
+        assert lut.letters == "".join(ref["char_set"])
+        for b in range(256):
+            ch = chr(b)
+            t = ref["full"].get(ch, ch)
+            assert chr(lut.translate[b]) == t
+            assert lut.rank[b] == (ref["char_set"].index(t) if t in ref["char_set"] else 0xFF)
+    assert {str(k): v for k, v in A.ALPHABET_ORDER.items()} == meta["ALPHABET_ORDER"]
+    assert A.ALPHABET2ID == meta["ALPHABET2ID"]
+    assert A.ALPHABET_ID == meta["ALPHABET_ID"]
+    with pytest.raises(ValueError) as e:
+        A.check_valid("no-such-alphabet")
+    assert str(e.value) == meta["check_valid_error"]
+
+
+def test_g2_edge_cases_python_and_c_oracle():
+    g2 = gjson("g2_edge_cases.json")
+    assert len(g2) > 500
+    for case in g2:
+        key = alpha_key(case["alphabet"])
+        table = A.FULL_ALPHABETS[case["alphabet"]]
+        k = case["k"]
+        assert ref_path.reduce(case["seq"], table) == case["reduced"]
+        got = ref_path.reduce_vectorize(case["seq"], k, table)
+        assert list(got) == case["kmers"]
+        assert str(got.dtype) == case["dtype"] and list(got.shape) == case["shape"]
+        # C oracle on the packed form
+        lut = A.build_lut(key)
+        if lut.nsym**k >= 2**64:
+            continue
+        seq, off = pack_sequences([case["seq"]])
+        out, outlen = c_oracle.recode(lut.translate, seq, off)
+        red = unpack_sequences(out, off, outlen)[0]
+        if all(ord(c) < 256 for c in case["seq"]):
+            assert red == case["reduced"]
+        codes, nwin = c_oracle.kmer_codes(lut.rank, lut.nsym, k, seq, off)
+        w = int(nwin[0])
+        assert w == max(0, len(case["reduced"]) - k + 1)
+        valid = codes[:w][codes[:w] != np.iinfo(np.uint64).max]
+        assert list(lut.decode(valid, k)) == case["kmers"]
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g3_demo_*_mf*.npz"))))
+def test_g3_g4_g5_demo(path):
+    tag = os.path.basename(path)[len("g3_demo_") : -4]
+    alphabet, k, mf = parse_tag(tag)
+    name = "None" if alphabet is None else alphabet
+    g = np.load(path)
+    recs = demo_records()
+    table = A.FULL_ALPHABETS[name]
+    out = ref_path.kmerize_rule(recs, k, table, min_filter=mf)
+    vecs = np.unpackbits(g["vecs_bits"], axis=1)[:, : g["vecs_shape"][1]]
+    assert list(out["kmerlist"]) == list(g["kmerlist"])
+    assert list(out["ids"]) == list(g["ids"]) and list(out["seqs"]) == list(g["seqs"])
+    assert list(out["lengths"]) == list(g["lengths"])
+    assert (out["vecs"] == vecs).all()
+    counts, _ = ref_path.count_matrix(out["seqs"], out["kmerlist"])
+    gold_counts = csr_to_dense(g["counts_rowptr"], g["counts_col"], g["counts_val"], len(g["kmerlist"]))
+    assert (counts == gold_counts).all()
+    np.testing.assert_allclose(ref_path.cosine_similarity(counts), g["cosine"], atol=1e-13)
+    np.testing.assert_allclose(ref_path.cosine_similarity(g["totals"], counts).T, g["cosine_rect"], atol=1e-13)
+
+    # C oracle: CSR counts, basis in first-seen order with min_filter, cosine rows
+    lut = A.build_lut(alphabet)
+    seq, off = pack_sequences([s for _, s in recs])
+    rowptr, codes, cnt, first = c_oracle.count_csr(lut.rank, lut.nsym, k, seq, off)
+    basis, df, tot, fk, col = c_oracle.basis(rowptr, codes, cnt, first)
+    order = np.argsort(fk, kind="stable")
+    keep = order[tot[order] > mf]
+    assert list(lut.decode(basis[keep], k)) == list(g["kmerlist"])
+    newcol = np.full(len(basis), -1, dtype=np.int64)
+    newcol[keep] = np.arange(len(keep))
+    dense = np.zeros((len(recs), len(keep)), dtype=np.int64)
+    for i in range(len(recs)):
+        s, e = rowptr[i], rowptr[i + 1]
+        c = newcol[col[s:e]]
+        dense[i, c[c >= 0]] = cnt[s:e][c >= 0]
+    assert (dense == gold_counts).all()
+    if mf == 0:
+        S = c_oracle.cosine_rows(rowptr, col, cnt, len(basis), np.arange(len(recs)))
+        np.testing.assert_allclose(S, g["cosine"], atol=1e-12)
+
+
+def test_g3_basis_file_branch():
+    g = gnpz("g3_demo_hydro_k14_basisfile.npz")
+    recs = demo_records()
+    out = ref_path.kmerize_rule(recs, 14, A.FULL_ALPHABETS["hydro"], basis=list(g["kmerlist"]))
+    vecs = np.unpackbits(g["vecs_bits"], axis=1)[:, : g["vecs_shape"][1]]
+    assert (out["vecs"] == vecs).all()
+    counts, _ = ref_path.count_matrix(out["seqs"], out["kmerlist"])
+    gold = csr_to_dense(g["counts_rowptr"], g["counts_col"], g["counts_val"], len(g["kmerlist"]))
+    assert (counts == gold).all()
+
+
+def test_g6_basis_transform():
+    g6 = gjson("g6_basis.json")
+    got = ref_path.basis_transform(g6["basis"], np.asarray(g6["matrix"]), g6["vector_basis"])
+    assert got.tolist() == g6["out"]
+
+
+def test_g7_make_feature_matrix():
+    for case in gjson("g7_feature_matrix.json"):
+        rows, kl = ref_path.make_feature_matrix([np.asarray(v, dtype=str) for v in case["vecs"]], case["min_filter"])
+        assert [str(x) for x in kl] == case["kmerlist"]
+        assert [r.tolist() for r in rows] == case["rows"]
+
+
+@pytest.mark.parametrize("name,k", [("red6", 12), ("standard", 12), ("hydro", 20)])
+def test_g8_synthetic(name, k):
+    from snekmer_amd.synth import synth_families
+
+    g = gnpz(f"g8_synth_{name}_k{k}.npz")
+    idx = 5 if name == "hydro" else 2
+    res, off, fam = synth_families(256, 300, family=16, seed=20250523 + idx)
+    assert (res == g["residues"]).all() and (off == g["offsets"]).all() and (fam == g["family"]).all()
+    lut = A.build_lut(name)
+    rowptr, codes, cnt, first = c_oracle.count_csr(lut.rank, lut.nsym, k, res, off)
+    basis, df, tot, fk, col = c_oracle.basis(rowptr, codes, cnt, first)
+    order = np.argsort(fk, kind="stable")
+    assert list(lut.decode(basis[order], k)) == list(g["kmerlist"])
+    rank_of = np.empty(len(basis), dtype=np.int64)
+    rank_of[order] = np.arange(len(basis))
+    n = len(off) - 1
+    for i in range(0, n, 17):
+        s, e = rowptr[i], rowptr[i + 1]
+        gs, ge = g["counts_rowptr"][i], g["counts_rowptr"][i + 1]
+        mine = dict(zip(rank_of[col[s:e]].tolist(), cnt[s:e].tolist()))
+        gold = dict(zip(g["counts_col"][gs:ge].tolist(), g["counts_val"][gs:ge].tolist()))
+        assert mine == gold
+    S = c_oracle.cosine_rows(rowptr, col, cnt, len(basis), np.arange(n))
+    np.testing.assert_allclose(S, g["cosine"], atol=1e-12)
+
+
+def test_g9_connection_matrix():
+    g = gnpz("g9_connection.npz")
+    np.testing.assert_allclose(ref_path.cosine_distances(g["X"]), g["cosine"], atol=1e-13)
+    np.testing.assert_allclose(ref_path.hamming_similarity(g["X"] > 0), g["jaccard"], atol=1e-13)
