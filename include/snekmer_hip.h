@@ -1,0 +1,200 @@
+/*
+ * snekmer_hip.h — C ABI of libsnekmer_hip.so, the MI355X (gfx950) implementation of Snekmer's
+ * AAR-kmer vectorize + cosine hot path.
+ *
+ * The reference (PNNL-CompBio/Snekmer v1.3.0) is pure Python and has no FFI of its own; its
+ * boundary for this path is the Python module surface.  Each entry point below therefore cites
+ * the reference *Python* code whose per-sequence loop it replaces with one batched device call.
+ * snekmer_amd/_hip.py is the ctypes binding; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - Every function returns an int status: SKM_OK or a negative SKM_E_* code;
+ *     skm_last_error() returns a thread-local message for the last failure.
+ *   - A context is bound to one device and one HIP stream.  Calls on one context are issued in
+ *     order on that stream and are asynchronous unless stated ("host-synchronous"); use
+ *     skm_sync() before reading results through anything but skm_memcpy_d2h.  A context is not
+ *     re-entrant; distinct contexts may be used from distinct host threads.
+ *   - Pointers named d_* are device pointers (from skm_malloc or any hipMalloc), h_* are host
+ *     pointers.  The caller owns every buffer; the library keeps only grow-only scratch inside
+ *     the context.
+ *   - Sequences are passed packed: d_seq holds all residues back to back, d_off[i]..d_off[i+1]
+ *     delimits sequence i (int64, n+1 entries).
+ *   - h_translate / h_rank are the 256-byte tables of snekmer_amd.alphabet.build_lut():
+ *     translate[b] = recoded byte, rank[b] = class rank (ASCII order of class letters) or 0xFF
+ *     when the recoded byte is not a class letter.
+ *   - k-mer code = sum_i rank(c_i) * nsym^(k-1-i); code_bits is 32 or 64 and the all-ones word of
+ *     that width is the "invalid window" sentinel.  nsym^k must be < 2^code_bits.
+ */
+#ifndef SNEKMER_HIP_H
+#define SNEKMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKM_ABI_VERSION 1
+
+#define SKM_OK 0
+#define SKM_E_BADARG (-1)
+#define SKM_E_NOMEM (-2)
+#define SKM_E_HIP (-3)
+#define SKM_E_OVERFLOW (-4)
+#define SKM_E_UNSUPPORTED (-5)
+#define SKM_E_COMM (-6)
+
+typedef struct skm_ctx skm_ctx;
+
+/* ---- library / context ------------------------------------------------------------------- */
+int skm_abi_version(void);
+const char *skm_last_error(void);
+int skm_device_count(int *h_count);
+int skm_create(int device_id, skm_ctx **out_ctx);
+int skm_destroy(skm_ctx *ctx);
+int skm_sync(skm_ctx *ctx); /* host-synchronous */
+int skm_device_info(skm_ctx *ctx, char *h_name, int name_cap, int *h_cus, int64_t *h_mem_bytes);
+
+/* ---- device memory ----------------------------------------------------------------------- */
+int skm_malloc(skm_ctx *ctx, size_t bytes, void **out_dptr);
+int skm_free(skm_ctx *ctx, void *dptr);
+int skm_memcpy_h2d(skm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* host-sync */
+int skm_memcpy_d2h(skm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* host-sync */
+int skm_memcpy_d2d(skm_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+int skm_memset(skm_ctx *ctx, void *d_dst, int byte_value, size_t bytes);
+
+/* ---- per-kernel timing (HIP events on the context's stream) ------------------------------- */
+/* While enabled, every kernel launch made by the library is bracketed by hipEvents on the
+ * context's stream.  skm_profile_read synchronises, then returns for the kernel whose name
+ * starts with `h_prefix` the number of launches and the summed device time since the last
+ * skm_profile_reset. */
+int skm_profile_enable(skm_ctx *ctx, int on);
+int skm_profile_reset(skm_ctx *ctx);
+int skm_profile_read(skm_ctx *ctx, const char *h_prefix, int64_t *h_launches, double *h_total_ms);
+/* Writes "name\tlaunches\ttotal_ms\n" lines for every kernel seen; returns bytes needed. */
+int skm_profile_dump(skm_ctx *ctx, char *h_buf, int cap, int *h_needed);
+
+/* ---- a3: recode -------------------------------------------------------------------------- */
+/* Replaces the per-sequence `reduce()` of snekmer/vectorize.py:173-195
+ * (str.rstrip("*") + str.translate) as called from rules/kmerize.smk:122-126.
+ * d_out has the layout of d_seq; d_outlen[i] = length after stripping trailing '*'.  Bytes of
+ * d_out past d_outlen[i] within a record are unspecified. */
+int skm_recode(skm_ctx *ctx, const uint8_t *h_translate, const uint8_t *d_seq, const int64_t *d_off,
+               int64_t n, uint8_t *d_out, int32_t *d_outlen);
+
+/* ---- a5/a6: k-mer windows in window order ------------------------------------------------- */
+/* Replaces KmerVec._kmer_gen + KmerVec.reduce_vectorize (snekmer/vectorize.py:239-249, :292-328)
+ * as called per record from rules/kmerize.smk:95,118.  For sequence i with stripped length L_i,
+ * d_nwin[i] = max(L_i-k+1, 0) and d_codes[d_off[i] + p] (p < d_nwin[i]) is the code of window p
+ * or the sentinel when the window holds a non-class character.  d_codes needs one word of
+ * code_bits per residue. */
+int skm_kmer_codes(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits,
+                   const uint8_t *d_seq, const int64_t *d_off, int64_t n, void *d_codes,
+                   int32_t *d_nwin);
+
+/* ---- a12: per-sequence k-mer counts (CSR) -------------------------------------------------- */
+/* Replaces the count loops of rules/learn.smk:359-383 and rules/apply.smk:188-206 (dict count of
+ * every window of the reduced string, then projection on the basis) with one pass that yields,
+ * per sequence, its distinct valid codes in ascending order with multiplicities.
+ * Outputs: d_rowptr[n+1]; d_codes / d_counts (/ d_firstpos, optional: index of the first window
+ * carrying that code, needed for the reference's first-seen basis order) with capacity
+ * cap_entries >= total residues.  *h_nnz receives the number of entries (host-synchronous). */
+int skm_count_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits,
+                  const uint8_t *d_seq, const int64_t *d_off, int64_t n, int64_t total_residues,
+                  int64_t cap_entries, int64_t *d_rowptr, void *d_codes, uint32_t *d_counts,
+                  uint32_t *d_firstpos, int64_t *h_nnz);
+
+/* ---- a11: observed basis ------------------------------------------------------------------ */
+/* Replaces the dict-of-observed-k-mers pass of rules/kmerize.smk:89-104 and the np.unique of
+ * scripts/cluster_cluster.py:67.  Input: the CSR of skm_count_csr over n sequences; key_bits =
+ * number of significant low bits in a code (ceil(log2(nsym^k)); 0 means code_bits).
+ * Outputs (each optional unless noted, capacity nnz unless noted):
+ *   *h_ncols          number of distinct codes B (required; host-synchronous)
+ *   d_basis[B]        distinct codes ascending (== lexicographic k-mer order), code_bits wide
+ *   d_colidx[nnz]     basis column of every CSR entry (required)
+ *   d_df[B]           sequences containing the k-mer
+ *   d_total[B]        total occurrences (what `min_filter` tests, kmerize.smk:96-104)
+ *   d_firstkey[B]     (row << 32 | first window); ascending order == the reference's first-seen order
+ *   d_fs_order[B]     basis columns listed in first-seen order (needs d_firstpos)
+ *   d_colptr[nnz+1], d_prow[nnz], d_pval[nnz]   the same matrix column-major (postings: for each
+ *                     basis column the rows holding it, ascending, and their counts);
+ *                     only d_colptr[0..B] is meaningful. */
+int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int64_t n, int64_t nnz, const int64_t *d_rowptr,
+                    const void *d_codes, const uint32_t *d_counts, const uint32_t *d_firstpos,
+                    int64_t *h_ncols, void *d_basis, uint32_t *d_colidx, uint32_t *d_df,
+                    uint64_t *d_total, uint64_t *d_firstkey, uint32_t *d_fs_order,
+                    uint32_t *d_colptr, uint32_t *d_prow, uint32_t *d_pval);
+
+/* Column-major copy (postings) of any CSR with column ids < ncols; rows ascending per column. */
+int skm_csr_transpose(skm_ctx *ctx, int64_t n, int64_t nnz, int64_t ncols, const int64_t *d_rowptr,
+                      const uint32_t *d_colidx, const uint32_t *d_counts, uint32_t *d_colptr,
+                      uint32_t *d_prow, uint32_t *d_pval);
+
+/* Row pointers of `nparts` CSR pieces laid end to end: d_local holds the pieces' own rowptr arrays
+ * back to back (piece p has h_nrows[p]+1 entries starting at 0); d_rowptr receives the
+ * sum(h_nrows)+1 entries of the concatenated matrix.  Used after the all-gather of CSR shards. */
+int skm_csr_concat_rowptr(skm_ctx *ctx, int nparts, const int64_t *h_nrows, const int64_t *h_nnz,
+                          const int64_t *d_local, int64_t *d_rowptr);
+
+/* Dense rows from CSR (the `vecs` array of rules/kmerize.smk:112-119 and the count matrix of
+ * rules/learn.smk:376-383).  d_colmap (optional, [ncols_in]) renumbers columns; 0xFFFFFFFF drops
+ * one.  mode 0 = counts, 1 = presence (0/1).  dtype: 0 = float64, 1 = float32, 2 = int8
+ * (saturation reported as SKM_E_OVERFLOW is NOT checked here; see skm_csr_max_count).
+ * d_out is [n x ld] row-major and is fully overwritten. */
+int skm_csr_to_dense(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const uint32_t *d_colidx,
+                     const uint32_t *d_counts, const uint32_t *d_colmap, int64_t ncols_out,
+                     int mode, int dtype, void *d_out, int64_t ld);
+
+/* ---- a13/a14: cosine ----------------------------------------------------------------------- */
+/* 1/||row|| (float32; 1.0 for an all-zero row, as sklearn's normalize does) and optionally the
+ * exact squared norms. */
+int skm_row_norms_csr(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const uint32_t *d_counts,
+                      float *d_rnorm, uint64_t *d_normsq);
+
+/* Replaces sklearn.metrics.pairwise.cosine_similarity(X, Y) at rules/apply.smk:282-284,
+ * rules/learn.smk:821-823, rules/evaluate.smk:434-436 and the metric="cosine" branch of
+ * snekmer/score.py:149-172, for count rows held sparse over a shared column space.
+ * X: CSR rows [row0,row1) of an n-row matrix; Y: postings (column-major) of an m-row matrix
+ * (pass X's own postings for the square N x N case).  Writes
+ *   out[(i-row0)*ld + j] = <x_i, y_j> * x_rnorm[i] * y_rnorm[j]   for i in [row0,row1), j in [0,m)
+ * with the integer dot product exact (int32) and the scaling in float32.
+ * mode 0 = similarity; mode 1 = cosine distance as sklearn's pairwise_distances gives it
+ * (1 - s clipped to [0,2]; exact 0 where i == j, square case only). */
+int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
+                   const uint32_t *d_xcounts, const float *d_xrnorm, int64_t m, int64_t ncols,
+                   const uint32_t *d_ycolptr, const uint32_t *d_yprow, const uint32_t *d_ypval,
+                   const float *d_yrnorm, int64_t row0, int64_t row1, int mode, float *d_out,
+                   int64_t ld);
+
+/* Exact sum over columns of df*(df) pairs the sparse kernel will visit (cost model input). */
+int skm_pair_work(skm_ctx *ctx, int64_t ncols, const uint32_t *d_colptr, uint64_t *h_pairs);
+
+/* ---- dense small-basis path (north-star "N x |S|^k count matrix" + MFMA cosine) ------------ */
+/* Atomic scatter of window counts into a dense [n x ld] matrix of uint16 (dtype 0) or
+ * uint32 (dtype 1); ld >= nsym^k, nsym^k <= 2^26.  The matrix is zero-filled first. */
+int skm_count_dense(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, const uint8_t *d_seq,
+                    const int64_t *d_off, int64_t n, int dtype, void *d_out, int64_t ld);
+
+/* out[i*ld + j] = (sum_c X[i,c]*Y[j,c]) * xr[i] * yr[j]; X [n x kdim], Y [m x kdim] int8 row-major
+ * with kdim a multiple of 64 and rows padded with zeros; i8 MFMA with int32 accumulation.
+ * Y may equal X.  mode as in skm_cosine_csr. */
+int skm_cosine_dense_i8(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim, const int8_t *d_x,
+                        const int8_t *d_y, const float *d_xrnorm, const float *d_yrnorm, int mode,
+                        float *d_out, int64_t ld);
+
+/* ---- multi-GPU (RCCL over xGMI; one context per rank) --------------------------------------- */
+#define SKM_COMM_ID_BYTES 128
+int skm_comm_unique_id(uint8_t *h_id /* SKM_COMM_ID_BYTES */);
+int skm_comm_init(skm_ctx *ctx, int nranks, int rank, const uint8_t *h_id);
+int skm_comm_destroy(skm_ctx *ctx);
+/* Variable-size all-gather: rank r contributes h_bytes[r] bytes from d_send; every rank receives
+ * all contributions back to back (rank order) in d_recv.  h_bytes has nranks entries and must be
+ * identical on all ranks. */
+int skm_allgatherv(skm_ctx *ctx, const void *d_send, const int64_t *h_bytes, void *d_recv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNEKMER_HIP_H */

@@ -1,0 +1,267 @@
+"""_hip: ctypes binding of libsnekmer_hip.so (include/snekmer_hip.h).
+
+There is deliberately no CPU fallback: importing this module never fails, but the first use
+of the device path raises :class:`HipUnavailable` when the shared library or a GPU is
+missing.  Host-side formatting (strings, numpy containers) lives in the callers; every
+numeric result comes from the HIP kernels.
+"""
+import ctypes as C
+import os
+import threading
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsnekmer_hip.so")
+
+SKM_OK = 0
+ERRORS = {-1: "BADARG", -2: "NOMEM", -3: "HIP", -4: "OVERFLOW", -5: "UNSUPPORTED", -6: "COMM"}
+COMM_ID_BYTES = 128
+
+
+class HipUnavailable(RuntimeError):
+    """The HIP extension (or a GPU) is not available; there is no CPU fallback."""
+
+
+class HipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libsnekmer_hip: SKM_E_{ERRORS.get(code, code)}: {message}")
+        self.code = code
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_SIGNATURES = {
+    "skm_abi_version": (C.c_int, []),
+    "skm_last_error": (C.c_char_p, []),
+    "skm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "skm_create": (C.c_int, [C.c_int, C.POINTER(_p)]),
+    "skm_destroy": (C.c_int, [_p]),
+    "skm_sync": (C.c_int, [_p]),
+    "skm_device_info": (C.c_int, [_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_i64)]),
+    "skm_malloc": (C.c_int, [_p, C.c_size_t, C.POINTER(_p)]),
+    "skm_free": (C.c_int, [_p, _p]),
+    "skm_memcpy_h2d": (C.c_int, [_p, _p, _p, C.c_size_t]),
+    "skm_memcpy_d2h": (C.c_int, [_p, _p, _p, C.c_size_t]),
+    "skm_memcpy_d2d": (C.c_int, [_p, _p, _p, C.c_size_t]),
+    "skm_memset": (C.c_int, [_p, _p, C.c_int, C.c_size_t]),
+    "skm_profile_enable": (C.c_int, [_p, C.c_int]),
+    "skm_profile_reset": (C.c_int, [_p]),
+    "skm_profile_read": (C.c_int, [_p, C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "skm_profile_dump": (C.c_int, [_p, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
+    "skm_recode": (C.c_int, [_p, _p, _p, _p, _i64, _p, _p]),
+    "skm_kmer_codes": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _i64, _p, _p]),
+    "skm_count_csr": (
+        C.c_int,
+        [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, C.POINTER(_i64)],
+    ),
+    "skm_basis_build": (
+        C.c_int,
+        [_p, C.c_int, C.c_int, _i64, _i64, _p, _p, _p, _p, C.POINTER(_i64), _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    ),
+    "skm_csr_transpose": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p]),
+    "skm_csr_concat_rowptr": (C.c_int, [_p, C.c_int, _p, _p, _p, _p]),
+    "skm_csr_to_dense": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, C.c_int, C.c_int, _p, _i64]),
+    "skm_row_norms_csr": (C.c_int, [_p, _i64, _p, _p, _p, _p]),
+    "skm_cosine_csr": (
+        C.c_int,
+        [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i64, C.c_int, _p, _i64],
+    ),
+    "skm_pair_work": (C.c_int, [_p, _i64, _p, C.POINTER(C.c_uint64)]),
+    "skm_count_dense": (C.c_int, [_p, _p, C.c_int, C.c_int, _p, _p, _i64, C.c_int, _p, _i64]),
+    "skm_cosine_dense_i8": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, C.c_int, _p, _i64]),
+    "skm_comm_unique_id": (C.c_int, [_p]),
+    "skm_comm_init": (C.c_int, [_p, C.c_int, C.c_int, _p]),
+    "skm_comm_destroy": (C.c_int, [_p]),
+    "skm_allgatherv": (C.c_int, [_p, _p, _p, _p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load_library():
+    """dlopen the in-tree shared library and set argtypes; raises HipUnavailable if absent."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipUnavailable(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C snekmer_amd/csrc`. snekmer_amd has no CPU fallback."
+            )
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as exc:  # e.g. libamdhip64 not found
+            raise HipUnavailable(f"cannot load {LIB_PATH}: {exc}") from exc
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def _check(lib, status: int):
+    if status != SKM_OK:
+        raise HipError(status, lib.skm_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = C.c_int(0)
+    status = lib.skm_device_count(C.byref(n))
+    if status != SKM_OK:
+        return 0
+    return n.value
+
+
+class DeviceArray:
+    """A typed 1-D/2-D view of device memory owned by a Context."""
+
+    def __init__(self, ctx: "Context", shape, dtype):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        self.ptr = ctx._malloc(max(self.nbytes, 1))
+
+    def free(self):
+        if self.ptr is not None and self.ctx is not None and self.ctx.handle is not None:
+            self.ctx._free(self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def upload(self, host: np.ndarray) -> "DeviceArray":
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.size != self.size:
+            raise ValueError(f"upload size mismatch: {host.size} vs {self.size}")
+        self.ctx._h2d(self.ptr, host)
+        return self
+
+    def download(self, count: Optional[int] = None, offset: int = 0) -> np.ndarray:
+        """Copy `count` elements starting at element `offset` (flat) to a new host array."""
+        if count is None:
+            count = self.size - offset
+            shape = self.shape if offset == 0 else (count,)
+        else:
+            shape = (count,)
+        out = np.empty(count, dtype=self.dtype)
+        if count:
+            self.ctx._d2h(out, self.ptr + offset * self.dtype.itemsize)
+        return out.reshape(shape)
+
+    def at(self, offset_elems: int) -> int:
+        return self.ptr + int(offset_elems) * self.dtype.itemsize
+
+
+class Context:
+    """One device + one HIP stream (skm_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        if device_count() <= device:
+            raise HipUnavailable(
+                f"no HIP device {device} visible ({device_count()} found); snekmer_amd has no CPU fallback"
+            )
+        handle = _p()
+        _check(self.lib, self.lib.skm_create(device, C.byref(handle)))
+        self.handle = handle
+        self.device = device
+
+    def close(self):
+        if getattr(self, "handle", None) is not None:
+            self.lib.skm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- memory
+    def _malloc(self, nbytes: int) -> int:
+        out = _p()
+        _check(self.lib, self.lib.skm_malloc(self.handle, nbytes, C.byref(out)))
+        return out.value
+
+    def _free(self, ptr: int):
+        self.lib.skm_free(self.handle, _p(ptr))
+
+    def _h2d(self, dptr: int, host: np.ndarray):
+        _check(self.lib, self.lib.skm_memcpy_h2d(self.handle, _p(dptr), host.ctypes.data_as(_p), host.nbytes))
+
+    def _d2h(self, host: np.ndarray, dptr: int):
+        _check(self.lib, self.lib.skm_memcpy_d2h(self.handle, host.ctypes.data_as(_p), _p(dptr), host.nbytes))
+
+    def empty(self, shape, dtype) -> DeviceArray:
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype) -> DeviceArray:
+        arr = DeviceArray(self, shape, dtype)
+        _check(self.lib, self.lib.skm_memset(self.handle, _p(arr.ptr), 0, arr.nbytes))
+        return arr
+
+    def to_device(self, host: np.ndarray, dtype=None) -> DeviceArray:
+        host = np.ascontiguousarray(host, dtype=dtype)
+        return DeviceArray(self, host.shape, host.dtype).upload(host)
+
+    def sync(self):
+        _check(self.lib, self.lib.skm_sync(self.handle))
+
+    def device_info(self) -> Tuple[str, int, int]:
+        name = C.create_string_buffer(256)
+        cus = C.c_int(0)
+        mem = _i64(0)
+        _check(self.lib, self.lib.skm_device_info(self.handle, name, 256, C.byref(cus), C.byref(mem)))
+        return name.value.decode(), cus.value, mem.value
+
+    # -- profiling
+    def profile_enable(self, on: bool = True):
+        _check(self.lib, self.lib.skm_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        _check(self.lib, self.lib.skm_profile_reset(self.handle))
+
+    def profile_read(self, prefix: str) -> Tuple[int, float]:
+        n = _i64(0)
+        ms = C.c_double(0.0)
+        _check(self.lib, self.lib.skm_profile_read(self.handle, prefix.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def profile_dump(self) -> dict:
+        need = C.c_int(0)
+        _check(self.lib, self.lib.skm_profile_dump(self.handle, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(max(need.value, 1))
+        _check(self.lib, self.lib.skm_profile_dump(self.handle, buf, need.value, C.byref(need)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split("\t")
+            out[name] = (int(cnt), float(ms))
+        return out
+
+    # -- raw entry points (thin; shapes are the callers' business)
+    def call(self, name: str, *args):
+        _check(self.lib, getattr(self.lib, name)(self.handle, *args))
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    """Process-wide context on the device named by SNEKMER_DEVICE / LOCAL_RANK (default 0)."""
+    global _default_ctx
+    if _default_ctx is None:
+        dev = int(os.environ.get("SNEKMER_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _default_ctx = Context(dev)
+    return _default_ctx

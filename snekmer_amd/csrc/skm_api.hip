@@ -1,0 +1,286 @@
+// Context, memory, error and per-kernel timing plumbing of libsnekmer_hip.so.
+#include <cstring>
+#include <map>
+
+#include "skm_common.h"
+
+static thread_local char g_err[1024] = "";
+
+void skm_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int skm_abi_version(void) { return SKM_ABI_VERSION; }
+extern "C" const char *skm_last_error(void) { return g_err; }
+
+extern "C" int skm_device_count(int *h_count)
+{
+    SKM_REQUIRE(h_count, SKM_E_BADARG, "skm_device_count: null output");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *h_count = 0;
+        skm_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return SKM_E_HIP;
+    }
+    *h_count = n;
+    return SKM_OK;
+}
+
+extern "C" int skm_create(int device_id, skm_ctx **out_ctx)
+{
+    SKM_REQUIRE(out_ctx, SKM_E_BADARG, "skm_create: null output");
+    *out_ctx = nullptr;
+    int n = 0;
+    SKM_HIP(hipGetDeviceCount(&n));
+    SKM_REQUIRE(device_id >= 0 && device_id < n, SKM_E_BADARG,
+                "skm_create: device %d out of range (%d visible)", device_id, n);
+    SKM_HIP(hipSetDevice(device_id));
+    skm_ctx *ctx = new skm_ctx();
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    SKM_HIP(hipGetDeviceProperties(&prop, device_id));
+    ctx->num_cus = prop.multiProcessorCount;
+    SKM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    SKM_HIP(hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocDefault));
+    *out_ctx = ctx;
+    return SKM_OK;
+}
+
+extern "C" int skm_destroy(skm_ctx *ctx)
+{
+    if (!ctx)
+        return SKM_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    skm_comm_destroy(ctx);
+    for (auto &p : ctx->prof) {
+        hipEventDestroy(p.start);
+        hipEventDestroy(p.stop);
+    }
+    for (auto e : ctx->event_pool)
+        hipEventDestroy(e);
+    for (int i = 0; i < WS_COUNT; ++i)
+        if (ctx->ws[i])
+            hipFree(ctx->ws[i]);
+    if (ctx->h_pinned)
+        hipHostFree(ctx->h_pinned);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SKM_OK;
+}
+
+extern "C" int skm_sync(skm_ctx *ctx)
+{
+    SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    SKM_HIP(hipStreamSynchronize(ctx->stream));
+    return SKM_OK;
+}
+
+extern "C" int skm_device_info(skm_ctx *ctx, char *h_name, int name_cap, int *h_cus, int64_t *h_mem_bytes)
+{
+    SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    hipDeviceProp_t prop;
+    SKM_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    if (h_name && name_cap > 0) {
+        snprintf(h_name, (size_t)name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (h_cus)
+        *h_cus = prop.multiProcessorCount;
+    if (h_mem_bytes)
+        *h_mem_bytes = (int64_t)prop.totalGlobalMem;
+    return SKM_OK;
+}
+
+// ---------------------------------------------------------------------------- memory
+extern "C" int skm_malloc(skm_ctx *ctx, size_t bytes, void **out_dptr)
+{
+    SKM_REQUIRE(ctx && out_dptr, SKM_E_BADARG, "skm_malloc: null argument");
+    *out_dptr = nullptr;
+    SKM_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(out_dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        skm_set_error("hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+        return SKM_E_NOMEM;
+    }
+    return SKM_OK;
+}
+
+extern "C" int skm_free(skm_ctx *ctx, void *dptr)
+{
+    SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    if (dptr) {
+        SKM_HIP(hipSetDevice(ctx->device));
+        SKM_HIP(hipFree(dptr));
+    }
+    return SKM_OK;
+}
+
+extern "C" int skm_memcpy_h2d(skm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    if (!bytes)
+        return SKM_OK;
+    SKM_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SKM_HIP(hipStreamSynchronize(ctx->stream));
+    return SKM_OK;
+}
+
+extern "C" int skm_memcpy_d2h(skm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    if (!bytes)
+        return SKM_OK;
+    SKM_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SKM_HIP(hipStreamSynchronize(ctx->stream));
+    return SKM_OK;
+}
+
+extern "C" int skm_memcpy_d2d(skm_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)
+{
+    SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    if (!bytes)
+        return SKM_OK;
+    SKM_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return SKM_OK;
+}
+
+extern "C" int skm_memset(skm_ctx *ctx, void *d_dst, int byte_value, size_t bytes)
+{
+    SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    if (!bytes)
+        return SKM_OK;
+    SKM_HIP(hipMemsetAsync(d_dst, byte_value, bytes, ctx->stream));
+    return SKM_OK;
+}
+
+int skm_ws(skm_ctx *ctx, int slot, size_t bytes, void **out)
+{
+    if (bytes < 256)
+        bytes = 256;
+    if (ctx->ws_bytes[slot] < bytes) {
+        if (ctx->ws[slot]) {
+            SKM_HIP(hipStreamSynchronize(ctx->stream));
+            SKM_HIP(hipFree(ctx->ws[slot]));
+            ctx->ws[slot] = nullptr;
+            ctx->ws_bytes[slot] = 0;
+        }
+        size_t want = bytes + bytes / 8;  // headroom so slightly larger batches do not realloc
+        hipError_t e = hipMalloc(&ctx->ws[slot], want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            skm_set_error("scratch slot %d: hipMalloc(%zu bytes): %s", slot, want, hipGetErrorString(e));
+            return SKM_E_NOMEM;
+        }
+        ctx->ws_bytes[slot] = want;
+    }
+    *out = ctx->ws[slot];
+    return SKM_OK;
+}
+
+// ---------------------------------------------------------------------------- profiling
+skm_prof_scope::skm_prof_scope(skm_ctx *c, const char *name) : ctx(c)
+{
+    if (!ctx->profiling)
+        return;
+    skm_prof_entry ent;
+    ent.name = name;
+    auto take = [&](hipEvent_t *ev) {
+        if (!ctx->event_pool.empty()) {
+            *ev = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else {
+            hipEventCreate(ev);
+        }
+    };
+    take(&ent.start);
+    take(&ent.stop);
+    hipEventRecord(ent.start, ctx->stream);
+    stop = ent.stop;
+    ctx->prof.push_back(ent);
+}
+
+skm_prof_scope::~skm_prof_scope()
+{
+    if (stop)
+        hipEventRecord(stop, ctx->stream);
+}
+
+extern "C" int skm_profile_enable(skm_ctx *ctx, int on)
+{
+    SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    ctx->profiling = on != 0;
+    return SKM_OK;
+}
+
+extern "C" int skm_profile_reset(skm_ctx *ctx)
+{
+    SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    SKM_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &p : ctx->prof) {
+        ctx->event_pool.push_back(p.start);
+        ctx->event_pool.push_back(p.stop);
+    }
+    ctx->prof.clear();
+    return SKM_OK;
+}
+
+extern "C" int skm_profile_read(skm_ctx *ctx, const char *h_prefix, int64_t *h_launches, double *h_total_ms)
+{
+    SKM_REQUIRE(ctx && h_prefix, SKM_E_BADARG, "null argument");
+    SKM_HIP(hipStreamSynchronize(ctx->stream));
+    int64_t cnt = 0;
+    double tot = 0;
+    size_t plen = strlen(h_prefix);
+    for (auto &p : ctx->prof) {
+        if (strncmp(p.name, h_prefix, plen) != 0)
+            continue;
+        float ms = 0;
+        SKM_HIP(hipEventElapsedTime(&ms, p.start, p.stop));
+        tot += ms;
+        ++cnt;
+    }
+    if (h_launches)
+        *h_launches = cnt;
+    if (h_total_ms)
+        *h_total_ms = tot;
+    return SKM_OK;
+}
+
+extern "C" int skm_profile_dump(skm_ctx *ctx, char *h_buf, int cap, int *h_needed)
+{
+    SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    SKM_HIP(hipStreamSynchronize(ctx->stream));
+    std::map<std::string, std::pair<int64_t, double>> agg;
+    std::vector<std::string> order;
+    for (auto &p : ctx->prof) {
+        float ms = 0;
+        SKM_HIP(hipEventElapsedTime(&ms, p.start, p.stop));
+        auto it = agg.find(p.name);
+        if (it == agg.end()) {
+            order.push_back(p.name);
+            agg[p.name] = {1, ms};
+        } else {
+            it->second.first++;
+            it->second.second += ms;
+        }
+    }
+    std::string out;
+    char line[256];
+    for (auto &nm : order) {
+        snprintf(line, sizeof(line), "%s\t%lld\t%.6f\n", nm.c_str(), (long long)agg[nm].first, agg[nm].second);
+        out += line;
+    }
+    if (h_needed)
+        *h_needed = (int)out.size() + 1;
+    if (h_buf && cap > 0) {
+        strncpy(h_buf, out.c_str(), (size_t)cap - 1);
+        h_buf[cap - 1] = 0;
+    }
+    return SKM_OK;
+}

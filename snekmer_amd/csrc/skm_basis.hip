@@ -1,0 +1,472 @@
+// Stage 2 of the hot path: observed basis, column ids, postings (column-major copy), dense views.
+//
+// Reference behaviour being replaced:
+//   dict of observed k-mers, first-seen order, min_filter    snekmer/rules/kmerize.smk:89-104
+//   np.unique over all k-mer lists                           snekmer/scripts/cluster_cluster.py:67
+//   vecs[n][np.isin(kmerbasis, addvec)] = 1                  snekmer/rules/kmerize.smk:112-119
+//   store = [k_counts.get(item, 0) for item in kmerlist]     snekmer/rules/learn.smk:376-383
+//
+// Device design: because a code is a pure function of (alphabet, k, window), columns are found by
+// one stable LSD radix sort of the CSR's codes (rocPRIM building block, key bits = log2 |S|^k) with
+// the entry index as payload.  The sorted order *is* the column-major copy of the matrix: one
+// scatter pass then emits column ids, postings, document frequencies and first-seen keys.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "skm_common.h"
+
+namespace {
+
+constexpr int BLK = 256;
+
+__global__ void k_iota_u32(uint32_t *out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        out[i] = (uint32_t)i;
+}
+
+__global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
+
+// rowid[e] = row owning CSR entry e; one wave per row.
+__global__ __launch_bounds__(BLK) void k_expand_rowid(const int64_t *__restrict__ rowptr, int64_t n,
+                                                      uint32_t *__restrict__ rowid)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const int64_t b = rowptr[i], e = rowptr[i + 1];
+        for (int64_t t = b + lane; t < e; t += 64)
+            rowid[t] = (uint32_t)i;
+    }
+}
+
+template <typename K>
+struct head_flag {
+    const K *keys;
+    __device__ uint32_t operator()(uint32_t t) const { return (t == 0 || keys[t] != keys[t - 1]) ? 1u : 0u; }
+};
+
+// One pass over the sorted order: column ids back to CSR order, postings, basis codes,
+// column starts and first-seen keys.
+template <typename K>
+__global__ __launch_bounds__(BLK) void k_basis_scatter(int64_t nnz, const K *__restrict__ skeys,
+                                                       const uint32_t *__restrict__ sidx,
+                                                       const uint32_t *__restrict__ colid1,
+                                                       const uint32_t *__restrict__ rowid,
+                                                       const uint32_t *__restrict__ counts,
+                                                       const uint32_t *__restrict__ firstpos,
+                                                       K *__restrict__ basis, uint32_t *__restrict__ colidx,
+                                                       uint32_t *__restrict__ colptr, uint32_t *__restrict__ prow,
+                                                       uint32_t *__restrict__ pval, uint64_t *__restrict__ firstkey)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nnz; t += stride) {
+        const uint32_t c = colid1[t] - 1u;
+        const uint32_t e = sidx[t];
+        const K key = skeys[t];
+        const bool head = t == 0 || skeys[t - 1] != key;
+        colidx[e] = c;
+        uint32_t row = 0;
+        if (prow || (head && firstkey))
+            row = rowid[e];
+        if (prow) {
+            prow[t] = row;
+            pval[t] = counts[e];
+        }
+        if (head) {
+            if (basis)
+                basis[c] = key;
+            if (colptr)
+                colptr[c] = (uint32_t)t;
+            if (firstkey)
+                firstkey[c] = ((uint64_t)row << 32) | (firstpos ? firstpos[e] : 0u);
+        }
+    }
+}
+
+__global__ void k_col_stats(int64_t ncols, const uint32_t *__restrict__ colptr, const uint32_t *__restrict__ pval,
+                            uint32_t *__restrict__ df, uint64_t *__restrict__ total)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols)
+        return;
+    uint32_t b = colptr[c], e = colptr[c + 1];
+    if (df)
+        df[c] = e - b;
+    if (total) {
+        uint64_t s = 0;
+        for (uint32_t t = b; t < e; ++t)
+            s += pval[t];
+        total[c] = s;
+    }
+}
+
+__global__ void k_pair_work(int64_t ncols, const uint32_t *__restrict__ colptr, unsigned long long *out)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (c < ncols) {
+        unsigned long long d = colptr[c + 1] - colptr[c];
+        v = d * d;
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0 && v)
+        atomicAdd(out, v);
+}
+
+// colptr[c] = first sorted position whose column id is >= c (c in [0, ncols]).
+__global__ void k_colptr_search(int64_t ncols, int64_t nnz, const uint32_t *__restrict__ skeys,
+                                uint32_t *__restrict__ colptr)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > ncols)
+        return;
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (skeys[mid] < (uint32_t)c)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    colptr[c] = (uint32_t)lo;
+}
+
+__global__ void k_gather_postings(int64_t nnz, const uint32_t *__restrict__ sidx,
+                                  const uint32_t *__restrict__ rowid, const uint32_t *__restrict__ counts,
+                                  uint32_t *__restrict__ prow, uint32_t *__restrict__ pval)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < nnz; t += stride) {
+        uint32_t e = sidx[t];
+        prow[t] = rowid[e];
+        pval[t] = counts[e];
+    }
+}
+
+__global__ void k_rebase_rowptr(const int64_t *__restrict__ local, int64_t nrows, int64_t src0, int64_t dst0,
+                                int64_t base, int last, int64_t *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrows + (last ? 1 : 0))
+        out[dst0 + i] = local[src0 + i] + base;
+}
+
+template <typename T>
+__device__ __forceinline__ T dense_value(uint32_t v);
+template <>
+__device__ __forceinline__ double dense_value<double>(uint32_t v) { return (double)v; }
+template <>
+__device__ __forceinline__ float dense_value<float>(uint32_t v) { return (float)v; }
+template <>
+__device__ __forceinline__ int8_t dense_value<int8_t>(uint32_t v) { return (int8_t)(v > 127u ? 127u : v); }
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void k_csr_to_dense(int64_t n, const int64_t *__restrict__ rowptr,
+                                                      const uint32_t *__restrict__ colidx,
+                                                      const uint32_t *__restrict__ counts,
+                                                      const uint32_t *__restrict__ colmap, int64_t ncols_out,
+                                                      int mode, T *__restrict__ out, int64_t ld)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const int64_t b = rowptr[i], e = rowptr[i + 1];
+        for (int64_t t = b + lane; t < e; t += 64) {
+            uint32_t c = colidx[t];
+            if (colmap)
+                c = colmap[c];
+            if (c == 0xFFFFFFFFu || (int64_t)c >= ncols_out)
+                continue;
+            out[i * ld + c] = dense_value<T>(mode ? 1u : counts[t]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLK) void k_row_norms(int64_t n, const int64_t *__restrict__ rowptr,
+                                                   const uint32_t *__restrict__ counts, float *__restrict__ rnorm,
+                                                   uint64_t *__restrict__ normsq)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const int64_t b = rowptr[i], e = rowptr[i + 1];
+        unsigned long long s = 0;
+        for (int64_t t = b + lane; t < e; t += 64) {
+            unsigned long long v = counts[t];
+            s += v * v;
+        }
+        for (int o = 32; o > 0; o >>= 1)
+            s += __shfl_down(s, o);
+        if (lane == 0) {
+            if (normsq)
+                normsq[i] = s;
+            if (rnorm)
+                rnorm[i] = s ? (float)(1.0 / sqrt((double)s)) : 1.0f;
+        }
+    }
+}
+
+template <typename K>
+int sort_pairs(skm_ctx *ctx, const K *kin, K *kout, const uint32_t *vin, uint32_t *vout, int64_t nnz, int bits,
+               const char *label)
+{
+    size_t tmp = 0;
+    SKM_HIP(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, (size_t)nnz, 0u, (unsigned)bits, ctx->stream));
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_ROCPRIM, tmp, &p));
+    SKM_PROF(ctx, label);
+    SKM_HIP(rocprim::radix_sort_pairs(p, tmp, kin, kout, vin, vout, (size_t)nnz, 0u, (unsigned)bits, ctx->stream));
+    return SKM_OK;
+}
+
+template <typename K>
+int basis_impl(skm_ctx *ctx, int key_bits, int64_t n, int64_t nnz, const int64_t *d_rowptr, const K *d_codes,
+               const uint32_t *d_counts, const uint32_t *d_firstpos, int64_t *h_ncols, K *d_basis, uint32_t *d_colidx,
+               uint32_t *d_df, uint64_t *d_total, uint64_t *d_firstkey, uint32_t *d_fs_order, uint32_t *d_colptr,
+               uint32_t *d_prow, uint32_t *d_pval)
+{
+    hipStream_t st = ctx->stream;
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_A, sizeof(K) * (size_t)nnz, &p));
+    K *skeys = (K *)p;
+    SKM_TRY(skm_ws(ctx, WS_B, sizeof(uint32_t) * (size_t)nnz, &p));
+    uint32_t *iota = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_C, sizeof(uint32_t) * (size_t)nnz, &p));
+    uint32_t *sidx = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)nnz, &p));
+    uint32_t *colid1 = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint32_t) * (size_t)nnz, &p));
+    uint32_t *rowid = (uint32_t *)p;
+
+    const bool need_stats = d_df || d_total;
+    const bool need_fs = d_fs_order != nullptr;
+    uint32_t *colptr = d_colptr, *prow = d_prow, *pval = d_pval;
+    if (need_stats && !colptr) {
+        SKM_TRY(skm_ws(ctx, WS_F, sizeof(uint32_t) * (size_t)(nnz + 1), &p));
+        colptr = (uint32_t *)p;
+    }
+    if ((need_stats && d_total && !pval) || (prow && !pval) || (pval && !prow)) {
+        if (!prow) {
+            SKM_TRY(skm_ws(ctx, WS_G, sizeof(uint32_t) * (size_t)nnz, &p));
+            prow = (uint32_t *)p;
+        }
+        if (!pval) {
+            SKM_TRY(skm_ws(ctx, WS_H, sizeof(uint32_t) * (size_t)nnz, &p));
+            pval = (uint32_t *)p;
+        }
+    }
+    uint64_t *firstkey = d_firstkey;
+    if (need_fs && !firstkey) {
+        SKM_TRY(skm_ws(ctx, WS_I, sizeof(uint64_t) * (size_t)nnz, &p));
+        firstkey = (uint64_t *)p;
+    }
+
+    const int g_ent = skm_grid_cap(ctx, skm_ceil_div(nnz, BLK), 16);
+    {
+        SKM_PROF(ctx, "k_iota_u32");
+        k_iota_u32<<<g_ent, BLK, 0, st>>>(iota, nnz);
+    }
+    {
+        SKM_PROF(ctx, "k_expand_rowid");
+        k_expand_rowid<<<skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16), BLK, 0, st>>>(d_rowptr, n, rowid);
+    }
+    SKM_TRY(skm_check_launch("k_expand_rowid"));
+    SKM_TRY(sort_pairs<K>(ctx, d_codes, skeys, iota, sidx, nnz, key_bits, "rocprim_radix_sort_codes"));
+    {
+        size_t tmp = 0;
+        auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), head_flag<K>{skeys});
+        SKM_HIP(rocprim::inclusive_scan(nullptr, tmp, in, colid1, (size_t)nnz, rocprim::plus<uint32_t>(), st));
+        SKM_TRY(skm_ws(ctx, WS_ROCPRIM, tmp, &p));
+        SKM_PROF(ctx, "rocprim_scan_heads");
+        SKM_HIP(rocprim::inclusive_scan(p, tmp, in, colid1, (size_t)nnz, rocprim::plus<uint32_t>(), st));
+    }
+    {
+        SKM_PROF(ctx, "k_basis_scatter");
+        k_basis_scatter<K><<<g_ent, BLK, 0, st>>>(nnz, skeys, sidx, colid1, rowid, d_counts, d_firstpos, d_basis,
+                                                   d_colidx, colptr, prow, pval, firstkey);
+    }
+    SKM_TRY(skm_check_launch("k_basis_scatter"));
+    uint32_t *h_b = (uint32_t *)ctx->h_pinned;
+    SKM_HIP(hipMemcpyAsync(h_b, colid1 + (nnz - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SKM_HIP(hipStreamSynchronize(st));
+    const int64_t B = (int64_t)*h_b;
+    *h_ncols = B;
+    if (colptr) {
+        k_set_u32<<<1, 1, 0, st>>>(colptr + B, (uint32_t)nnz);
+    }
+    if (need_stats) {
+        SKM_PROF(ctx, "k_col_stats");
+        k_col_stats<<<(unsigned)skm_ceil_div(B, BLK), BLK, 0, st>>>(B, colptr, pval, d_df, d_total);
+        SKM_TRY(skm_check_launch("k_col_stats"));
+    }
+    if (need_fs) {
+        // first-seen order = ascending (row, first window) key
+        SKM_TRY(skm_ws(ctx, WS_A, sizeof(uint64_t) * (size_t)B, &p));  // skeys no longer needed
+        uint64_t *fk_sorted = (uint64_t *)p;
+        k_iota_u32<<<skm_grid_cap(ctx, skm_ceil_div(B, BLK), 16), BLK, 0, st>>>(iota, B);
+        SKM_TRY(sort_pairs<uint64_t>(ctx, firstkey, fk_sorted, iota, d_fs_order, B, 64, "rocprim_radix_sort_firstseen"));
+    }
+    return SKM_OK;
+}
+
+}  // namespace
+
+extern "C" int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int64_t n, int64_t nnz,
+                               const int64_t *d_rowptr, const void *d_codes, const uint32_t *d_counts,
+                               const uint32_t *d_firstpos, int64_t *h_ncols, void *d_basis, uint32_t *d_colidx,
+                               uint32_t *d_df, uint64_t *d_total, uint64_t *d_firstkey, uint32_t *d_fs_order,
+                               uint32_t *d_colptr, uint32_t *d_prow, uint32_t *d_pval)
+{
+    SKM_REQUIRE(ctx && h_ncols && n >= 0 && nnz >= 0, SKM_E_BADARG, "skm_basis_build: bad argument");
+    SKM_REQUIRE(code_bits == 32 || code_bits == 64, SKM_E_BADARG, "skm_basis_build: code_bits must be 32 or 64");
+    SKM_REQUIRE(nnz < ((int64_t)1 << 32) - 1, SKM_E_OVERFLOW, "skm_basis_build: nnz >= 2^32; split the batch");
+    SKM_REQUIRE(!d_fs_order || d_firstpos, SKM_E_BADARG, "skm_basis_build: d_fs_order needs d_firstpos");
+    *h_ncols = 0;
+    if (nnz == 0) {
+        if (d_colptr)
+            SKM_HIP(hipMemsetAsync(d_colptr, 0, sizeof(uint32_t), ctx->stream));
+        return SKM_OK;
+    }
+    SKM_REQUIRE(d_rowptr && d_codes && d_counts && d_colidx, SKM_E_BADARG, "skm_basis_build: null CSR array");
+    if (key_bits <= 0 || key_bits > code_bits)
+        key_bits = code_bits;
+    SKM_HIP(hipSetDevice(ctx->device));
+    if (code_bits == 32)
+        return basis_impl<uint32_t>(ctx, key_bits, n, nnz, d_rowptr, (const uint32_t *)d_codes, d_counts, d_firstpos,
+                                    h_ncols, (uint32_t *)d_basis, d_colidx, d_df, d_total, d_firstkey, d_fs_order,
+                                    d_colptr, d_prow, d_pval);
+    return basis_impl<uint64_t>(ctx, key_bits, n, nnz, d_rowptr, (const uint64_t *)d_codes, d_counts, d_firstpos,
+                                h_ncols, (uint64_t *)d_basis, d_colidx, d_df, d_total, d_firstkey, d_fs_order, d_colptr,
+                                d_prow, d_pval);
+}
+
+extern "C" int skm_csr_transpose(skm_ctx *ctx, int64_t n, int64_t nnz, int64_t ncols, const int64_t *d_rowptr,
+                                 const uint32_t *d_colidx, const uint32_t *d_counts, uint32_t *d_colptr,
+                                 uint32_t *d_prow, uint32_t *d_pval)
+{
+    SKM_REQUIRE(ctx && d_colptr && n >= 0 && nnz >= 0 && ncols >= 0, SKM_E_BADARG, "skm_csr_transpose: bad argument");
+    SKM_REQUIRE(nnz < ((int64_t)1 << 32) - 1 && ncols < ((int64_t)1 << 32) - 1, SKM_E_OVERFLOW,
+                "skm_csr_transpose: nnz or ncols >= 2^32");
+    SKM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (nnz == 0) {
+        SKM_HIP(hipMemsetAsync(d_colptr, 0, sizeof(uint32_t) * (size_t)(ncols + 1), st));
+        return SKM_OK;
+    }
+    SKM_REQUIRE(d_rowptr && d_colidx && d_counts && d_prow && d_pval, SKM_E_BADARG, "skm_csr_transpose: null array");
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_A, sizeof(uint32_t) * (size_t)nnz, &p));
+    uint32_t *skeys = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_B, sizeof(uint32_t) * (size_t)nnz, &p));
+    uint32_t *iota = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_C, sizeof(uint32_t) * (size_t)nnz, &p));
+    uint32_t *sidx = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint32_t) * (size_t)nnz, &p));
+    uint32_t *rowid = (uint32_t *)p;
+    const int g_ent = skm_grid_cap(ctx, skm_ceil_div(nnz, BLK), 16);
+    k_iota_u32<<<g_ent, BLK, 0, st>>>(iota, nnz);
+    k_expand_rowid<<<skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16), BLK, 0, st>>>(d_rowptr, n, rowid);
+    int bits = 1;
+    while (bits < 32 && ((int64_t)1 << bits) < ncols)
+        ++bits;
+    SKM_TRY(sort_pairs<uint32_t>(ctx, d_colidx, skeys, iota, sidx, nnz, bits, "rocprim_radix_sort_cols"));
+    {
+        SKM_PROF(ctx, "k_colptr_search");
+        k_colptr_search<<<(unsigned)skm_ceil_div(ncols + 1, BLK), BLK, 0, st>>>(ncols, nnz, skeys, d_colptr);
+    }
+    {
+        SKM_PROF(ctx, "k_gather_postings");
+        k_gather_postings<<<g_ent, BLK, 0, st>>>(nnz, sidx, rowid, d_counts, d_prow, d_pval);
+    }
+    return skm_check_launch("k_gather_postings");
+}
+
+extern "C" int skm_csr_concat_rowptr(skm_ctx *ctx, int nparts, const int64_t *h_nrows, const int64_t *h_nnz,
+                                     const int64_t *d_local, int64_t *d_rowptr)
+{
+    SKM_REQUIRE(ctx && nparts >= 1 && h_nrows && h_nnz && d_local && d_rowptr, SKM_E_BADARG,
+                "skm_csr_concat_rowptr: bad argument");
+    SKM_HIP(hipSetDevice(ctx->device));
+    int64_t src = 0, dst = 0, base = 0;
+    SKM_PROF(ctx, "k_rebase_rowptr");
+    for (int p = 0; p < nparts; ++p) {
+        const int last = p == nparts - 1;
+        const int64_t cnt = h_nrows[p] + (last ? 1 : 0);
+        if (cnt > 0)
+            k_rebase_rowptr<<<(unsigned)skm_ceil_div(cnt, BLK), BLK, 0, ctx->stream>>>(d_local, h_nrows[p], src, dst, base,
+                                                                                    last, d_rowptr);
+        src += h_nrows[p] + 1;
+        dst += h_nrows[p];
+        base += h_nnz[p];
+    }
+    return skm_check_launch("k_rebase_rowptr");
+}
+
+extern "C" int skm_csr_to_dense(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const uint32_t *d_colidx,
+                                const uint32_t *d_counts, const uint32_t *d_colmap, int64_t ncols_out, int mode,
+                                int dtype, void *d_out, int64_t ld)
+{
+    SKM_REQUIRE(ctx && n >= 0 && ncols_out >= 0 && ld >= ncols_out, SKM_E_BADARG, "skm_csr_to_dense: bad argument");
+    SKM_REQUIRE(dtype >= 0 && dtype <= 2, SKM_E_BADARG, "skm_csr_to_dense: dtype must be 0 (f64), 1 (f32) or 2 (i8)");
+    if (n == 0 || ld == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_rowptr && d_out, SKM_E_BADARG, "skm_csr_to_dense: null array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    const size_t esz = dtype == 0 ? 8 : (dtype == 1 ? 4 : 1);
+    SKM_HIP(hipMemsetAsync(d_out, 0, esz * (size_t)n * (size_t)ld, ctx->stream));
+    const int grid = skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16);
+    SKM_PROF(ctx, "k_csr_to_dense");
+    if (dtype == 0)
+        k_csr_to_dense<double><<<grid, BLK, 0, ctx->stream>>>(n, d_rowptr, d_colidx, d_counts, d_colmap, ncols_out, mode,
+                                                               (double *)d_out, ld);
+    else if (dtype == 1)
+        k_csr_to_dense<float><<<grid, BLK, 0, ctx->stream>>>(n, d_rowptr, d_colidx, d_counts, d_colmap, ncols_out, mode,
+                                                              (float *)d_out, ld);
+    else
+        k_csr_to_dense<int8_t><<<grid, BLK, 0, ctx->stream>>>(n, d_rowptr, d_colidx, d_counts, d_colmap, ncols_out, mode,
+                                                               (int8_t *)d_out, ld);
+    return skm_check_launch("k_csr_to_dense");
+}
+
+extern "C" int skm_row_norms_csr(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const uint32_t *d_counts,
+                                 float *d_rnorm, uint64_t *d_normsq)
+{
+    SKM_REQUIRE(ctx && n >= 0, SKM_E_BADARG, "skm_row_norms_csr: bad argument");
+    if (n == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_rowptr, SKM_E_BADARG, "skm_row_norms_csr: null rowptr");
+    SKM_HIP(hipSetDevice(ctx->device));
+    SKM_PROF(ctx, "k_row_norms");
+    k_row_norms<<<skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16), BLK, 0, ctx->stream>>>(n, d_rowptr, d_counts, d_rnorm,
+                                                                                          d_normsq);
+    return skm_check_launch("k_row_norms");
+}
+
+extern "C" int skm_pair_work(skm_ctx *ctx, int64_t ncols, const uint32_t *d_colptr, uint64_t *h_pairs)
+{
+    SKM_REQUIRE(ctx && h_pairs && ncols >= 0, SKM_E_BADARG, "skm_pair_work: bad argument");
+    *h_pairs = 0;
+    if (ncols == 0)
+        return SKM_OK;
+    SKM_HIP(hipSetDevice(ctx->device));
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
+    unsigned long long *acc = (unsigned long long *)((uint8_t *)p + 1024);
+    SKM_HIP(hipMemsetAsync(acc, 0, 8, ctx->stream));
+    k_pair_work<<<(unsigned)skm_ceil_div(ncols, BLK), BLK, 0, ctx->stream>>>(ncols, d_colptr, acc);
+    SKM_TRY(skm_check_launch("k_pair_work"));
+    SKM_HIP(hipMemcpyAsync(ctx->h_pinned, acc, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SKM_HIP(hipStreamSynchronize(ctx->stream));
+    *h_pairs = *(uint64_t *)ctx->h_pinned;
+    return SKM_OK;
+}

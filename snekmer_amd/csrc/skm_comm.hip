@@ -1,0 +1,145 @@
+// Multi-GPU exchange: one context per rank, RCCL over xGMI.
+//
+// The reference has no communication layer; the only exchange this path
+// needs is one all-gather of the per-shard CSR rows before the pairwise step.
+// librccl is opened lazily with dlopen so that single-GPU users never pay its load time.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "skm_common.h"
+
+namespace {
+
+// Minimal mirror of the RCCL C API we call (rccl.h: ncclUniqueId is 128 opaque bytes).
+struct nccl_uid {
+    char internal[128];
+};
+typedef int (*fn_get_uid)(nccl_uid *);
+typedef int (*fn_init_rank)(void **, int, nccl_uid, int);
+typedef int (*fn_destroy)(void *);
+typedef int (*fn_bcast)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_group)(void);
+typedef const char *(*fn_errstr)(int);
+
+struct rccl_api {
+    void *lib = nullptr;
+    fn_get_uid get_uid = nullptr;
+    fn_init_rank init_rank = nullptr;
+    fn_destroy destroy = nullptr;
+    fn_bcast bcast = nullptr;
+    fn_group group_start = nullptr, group_end = nullptr;
+    fn_errstr errstr = nullptr;
+};
+rccl_api g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.lib)
+        return SKM_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *nm : names) {
+        lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (lib)
+            break;
+    }
+    if (!lib) {
+        skm_set_error("cannot load librccl: %s", dlerror());
+        return SKM_E_COMM;
+    }
+    g_rccl.get_uid = (fn_get_uid)dlsym(lib, "ncclGetUniqueId");
+    g_rccl.init_rank = (fn_init_rank)dlsym(lib, "ncclCommInitRank");
+    g_rccl.destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy");
+    g_rccl.bcast = (fn_bcast)dlsym(lib, "ncclBroadcast");
+    g_rccl.group_start = (fn_group)dlsym(lib, "ncclGroupStart");
+    g_rccl.group_end = (fn_group)dlsym(lib, "ncclGroupEnd");
+    g_rccl.errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.bcast || !g_rccl.group_start ||
+        !g_rccl.group_end) {
+        skm_set_error("librccl lacks a required symbol");
+        dlclose(lib);
+        return SKM_E_COMM;
+    }
+    g_rccl.lib = lib;
+    return SKM_OK;
+}
+
+#define SKM_NCCL(expr)                                                                              \
+    do {                                                                                            \
+        int _r = (expr);                                                                            \
+        if (_r != 0) {                                                                              \
+            skm_set_error("%s -> RCCL error %d (%s)", #expr, _r, g_rccl.errstr ? g_rccl.errstr(_r) : "?"); \
+            return SKM_E_COMM;                                                                      \
+        }                                                                                           \
+    } while (0)
+
+constexpr int NCCL_INT8 = 0;  // ncclInt8 / ncclChar
+
+}  // namespace
+
+extern "C" int skm_comm_unique_id(uint8_t *h_id)
+{
+    SKM_REQUIRE(h_id, SKM_E_BADARG, "skm_comm_unique_id: null output");
+    SKM_TRY(load_rccl());
+    nccl_uid uid;
+    SKM_NCCL(g_rccl.get_uid(&uid));
+    static_assert(sizeof(uid) == SKM_COMM_ID_BYTES, "unique id size");
+    memcpy(h_id, &uid, sizeof(uid));
+    return SKM_OK;
+}
+
+extern "C" int skm_comm_init(skm_ctx *ctx, int nranks, int rank, const uint8_t *h_id)
+{
+    SKM_REQUIRE(ctx && h_id && nranks >= 1 && rank >= 0 && rank < nranks, SKM_E_BADARG, "skm_comm_init: bad argument");
+    SKM_REQUIRE(!ctx->comm, SKM_E_BADARG, "skm_comm_init: communicator already initialised");
+    SKM_TRY(load_rccl());
+    SKM_HIP(hipSetDevice(ctx->device));
+    nccl_uid uid;
+    memcpy(&uid, h_id, sizeof(uid));
+    SKM_NCCL(g_rccl.init_rank(&ctx->comm, nranks, uid, rank));
+    ctx->nranks = nranks;
+    ctx->rank = rank;
+    return SKM_OK;
+}
+
+extern "C" int skm_comm_destroy(skm_ctx *ctx)
+{
+    if (ctx && ctx->comm && g_rccl.destroy) {
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->stream);
+        g_rccl.destroy(ctx->comm);
+        ctx->comm = nullptr;
+        ctx->nranks = 1;
+        ctx->rank = 0;
+    }
+    return SKM_OK;
+}
+
+// Variable-size all-gather as one group of per-rank broadcasts: xGMI is point-to-point, each
+// broadcast is a ring/tree over the same links, and grouping lets RCCL overlap them.
+extern "C" int skm_allgatherv(skm_ctx *ctx, const void *d_send, const int64_t *h_bytes, void *d_recv)
+{
+    SKM_REQUIRE(ctx && h_bytes && d_recv, SKM_E_BADARG, "skm_allgatherv: bad argument");
+    SKM_HIP(hipSetDevice(ctx->device));
+    if (!ctx->comm) {
+        SKM_REQUIRE(ctx->nranks == 1, SKM_E_COMM, "skm_allgatherv: communicator not initialised");
+        if (h_bytes[0] > 0 && d_send != d_recv)
+            SKM_HIP(hipMemcpyAsync(d_recv, d_send, (size_t)h_bytes[0], hipMemcpyDeviceToDevice, ctx->stream));
+        return SKM_OK;
+    }
+    SKM_PROF(ctx, "rccl_allgatherv");
+    SKM_NCCL(g_rccl.group_start());
+    int64_t offset = 0;
+    for (int r = 0; r < ctx->nranks; ++r) {
+        SKM_REQUIRE(h_bytes[r] >= 0, SKM_E_BADARG, "skm_allgatherv: negative size for rank %d", r);
+        if (h_bytes[r] > 0) {
+            uint8_t *dst = (uint8_t *)d_recv + offset;
+            const void *src = r == ctx->rank ? d_send : (const void *)dst;
+            SKM_NCCL(g_rccl.bcast(src, dst, (size_t)h_bytes[r], NCCL_INT8, r, ctx->comm, ctx->stream));
+        }
+        offset += h_bytes[r];
+    }
+    SKM_NCCL(g_rccl.group_end());
+    return SKM_OK;
+}

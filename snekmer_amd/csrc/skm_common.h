@@ -1,0 +1,103 @@
+// Internal declarations shared by the HIP translation units of libsnekmer_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "snekmer_hip.h"
+
+void skm_set_error(const char *fmt, ...);
+
+#define SKM_HIP(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            skm_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return SKM_E_HIP;                                                                \
+        }                                                                                    \
+    } while (0)
+
+#define SKM_REQUIRE(cond, code, ...)   \
+    do {                               \
+        if (!(cond)) {                 \
+            skm_set_error(__VA_ARGS__); \
+            return (code);             \
+        }                              \
+    } while (0)
+
+#define SKM_TRY(expr)          \
+    do {                       \
+        int _s = (expr);       \
+        if (_s != SKM_OK)      \
+            return _s;         \
+    } while (0)
+
+// Grow-only scratch slots.  Every entry point draws its temporaries from fixed slots so that,
+// after a warm-up call, the timed path performs no hipMalloc/hipFree.
+enum skm_ws_slot {
+    WS_A = 0, WS_B, WS_C, WS_D, WS_E, WS_F, WS_G, WS_H, WS_I, WS_J, WS_ROCPRIM, WS_SMALL, WS_LUT,
+    WS_COUNT
+};
+
+struct skm_prof_entry {
+    const char *name;
+    hipEvent_t start, stop;
+};
+
+struct skm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    void *ws[WS_COUNT] = {};
+    size_t ws_bytes[WS_COUNT] = {};
+    void *h_pinned = nullptr;  // small pinned buffer for count read-backs
+    bool profiling = false;
+    std::vector<skm_prof_entry> prof;
+    std::vector<hipEvent_t> event_pool;
+    // RCCL (loaded lazily with dlopen; see skm_comm.hip)
+    void *rccl_lib = nullptr;
+    void *comm = nullptr;
+    int nranks = 1, rank = 0;
+};
+
+int skm_ws(skm_ctx *ctx, int slot, size_t bytes, void **out);
+
+// RAII bracket that records start/stop events around a launch when profiling is on.
+struct skm_prof_scope {
+    skm_ctx *ctx;
+    hipEvent_t stop = nullptr;
+    skm_prof_scope(skm_ctx *c, const char *name);
+    ~skm_prof_scope();
+};
+#define SKM_CAT2(a, b) a##b
+#define SKM_CAT(a, b) SKM_CAT2(a, b)
+#define SKM_PROF(ctx, name) skm_prof_scope SKM_CAT(_prof_scope_, __LINE__)(ctx, name)
+
+static inline int skm_check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        skm_set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return SKM_E_HIP;
+    }
+    return SKM_OK;
+}
+
+struct skm_lut256 {
+    uint8_t b[256];
+};
+
+static inline int64_t skm_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grid cap for grid-stride kernels: enough workgroups to fill 256 CUs several times over.
+static inline int skm_grid_cap(const skm_ctx *ctx, int64_t want, int per_cu = 8)
+{
+    int64_t cap = (int64_t)(ctx->num_cus > 0 ? ctx->num_cus : 256) * per_cu;
+    if (want < 1)
+        want = 1;
+    return (int)(want < cap ? want : cap);
+}

@@ -1,0 +1,757 @@
+// Stage 1 of the hot path: recode, k-mer window codes and per-sequence k-mer counts (CSR).
+//
+// Reference behaviour being replaced (per record, in Python):
+//   reduce()                 snekmer/vectorize.py:173-195
+//   KmerVec._kmer_gen        snekmer/vectorize.py:239-249
+//   KmerVec.reduce_vectorize snekmer/vectorize.py:292-328
+//   count loops              snekmer/rules/learn.smk:359-383, snekmer/rules/apply.smk:188-206
+//
+// Device design (gfx950): one 64-lane wavefront owns one sequence.  The wave stages the
+// sequence's class ranks in LDS once (1 B/residue read from HBM), every lane then forms the codes
+// of windows lane, lane+64, ... straight from LDS, the wave sorts its <= 512 codes with a bitonic
+// network held in registers (cross-lane steps are wave shuffles), run-length encodes them with
+// ballots and writes (code, count) pairs.  Sequences with more than 512 windows take a
+// workgroup-per-sequence variant with the keys in LDS (<= 8192 windows) or in global scratch.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "skm_common.h"
+
+namespace {
+
+constexpr int SHORT_MAX = 512;    // windows handled by the register sort (8 per lane)
+constexpr int BLOCK_LDS_MAX = 8192;  // windows handled with keys in LDS
+constexpr int NBUCKET = 7;        // 0: no windows, 1: short, 2..5: LDS cap 1024..8192, 6: global
+constexpr int BLK = 256;
+
+template <typename K>
+__device__ __forceinline__ K sentinel()
+{
+    return ~K(0);
+}
+
+// ------------------------------------------------------------------------------- recode
+__global__ void k_recode_bytes(skm_lut256 lut, const uint8_t *__restrict__ seq, uint8_t *__restrict__ out,
+                               int64_t total)
+{
+    __shared__ uint8_t s_lut[256];
+    if (threadIdx.x < 64)
+        reinterpret_cast<uint32_t *>(s_lut)[threadIdx.x] = reinterpret_cast<const uint32_t *>(lut.b)[threadIdx.x];
+    __syncthreads();
+    const int64_t nvec = total >> 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint4 *in4 = reinterpret_cast<const uint4 *>(seq);
+    uint4 *out4 = reinterpret_cast<uint4 *>(out);
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        uint4 w = in4[v];
+        uint32_t *p = reinterpret_cast<uint32_t *>(&w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t x = p[q];
+            p[q] = (uint32_t)s_lut[x & 255] | ((uint32_t)s_lut[(x >> 8) & 255] << 8) |
+                   ((uint32_t)s_lut[(x >> 16) & 255] << 16) | ((uint32_t)s_lut[x >> 24] << 24);
+        }
+        out4[v] = w;
+    }
+    for (int64_t b = (nvec << 4) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total; b += stride)
+        out[b] = s_lut[seq[b]];
+}
+
+// Stripped length (trailing '*' removed, snekmer/vectorize.py:193), window count and size class.
+__global__ void k_classify(const uint8_t *__restrict__ seq, const int64_t *__restrict__ off, int64_t n, int k,
+                           int32_t *__restrict__ slen, int32_t *__restrict__ nwin, uint32_t *__restrict__ lists,
+                           uint32_t *__restrict__ bucket_fill, int32_t *__restrict__ row_nnz)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    int64_t b = off[i], e = off[i + 1];
+    while (e > b && seq[e - 1] == '*')
+        --e;
+    int64_t len = e - b;
+    int64_t w = len - k + 1;
+    if (w < 0)
+        w = 0;
+    if (slen)
+        slen[i] = (int32_t)len;
+    if (nwin)
+        nwin[i] = (int32_t)w;
+    if (lists) {
+        int bucket;
+        if (w == 0) {
+            bucket = 0;
+            row_nnz[i] = 0;
+        } else if (w <= SHORT_MAX)
+            bucket = 1;
+        else if (w <= 1024)
+            bucket = 2;
+        else if (w <= 2048)
+            bucket = 3;
+        else if (w <= 4096)
+            bucket = 4;
+        else if (w <= BLOCK_LDS_MAX)
+            bucket = 5;
+        else
+            bucket = 6;
+        uint32_t slot = atomicAdd(&bucket_fill[bucket], 1u);
+        lists[(int64_t)bucket * n + slot] = (uint32_t)i;
+    }
+}
+
+// ------------------------------------------------------------------------------- window codes
+template <typename K>
+__device__ __forceinline__ K window_code(const uint8_t *ranks, int p, int k, int nsym)
+{
+    K c = 0;
+    uint32_t bad = 0;
+    for (int j = 0; j < k; ++j) {
+        uint32_t r = ranks[p + j];
+        bad |= (r == 0xFFu);
+        c = c * (K)nsym + (K)r;
+    }
+    return bad ? sentinel<K>() : c;
+}
+
+// Wave per sequence, windows in window order (a5/a6).  Tiles of 1024 windows with a k-1 halo.
+template <typename K>
+__global__ __launch_bounds__(64) void k_kmer_codes(skm_lut256 lut, int nsym, int k,
+                                                   const uint8_t *__restrict__ seq,
+                                                   const int64_t *__restrict__ off, int64_t n,
+                                                   const int32_t *__restrict__ slen, K *__restrict__ codes)
+{
+    constexpr int TILE = 1024;
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t s_rank[TILE + 64];
+    const int lane = threadIdx.x;
+    reinterpret_cast<uint32_t *>(s_lut)[lane] = reinterpret_cast<const uint32_t *>(lut.b)[lane];
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const int64_t b = off[i];
+        const int len = slen[i];
+        const int w = len - k + 1;
+        for (int t0 = 0; t0 < w; t0 += TILE) {
+            __syncthreads();
+            int span = min(TILE + k - 1, len - t0);
+            for (int p = lane; p < span; p += 64)
+                s_rank[p] = s_lut[seq[b + t0 + p]];
+            __syncthreads();
+            int wt = min(TILE, w - t0);
+            for (int p = lane; p < wt; p += 64)
+                codes[b + t0 + p] = window_code<K>(s_rank, p, k, nsym);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- register bitonic
+template <typename K>
+__device__ __forceinline__ K shfl_xor_k(K v, int m)
+{
+    if constexpr (sizeof(K) == 8) {
+        uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+        lo = __shfl_xor(lo, m);
+        hi = __shfl_xor(hi, m);
+        return ((K)hi << 32) | lo;
+    } else {
+        return (K)__shfl_xor((uint32_t)v, m);
+    }
+}
+
+template <typename K>
+__device__ __forceinline__ K shfl_idx_k(K v, int src)
+{
+    if constexpr (sizeof(K) == 8) {
+        uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+        lo = __shfl(lo, src);
+        hi = __shfl(hi, src);
+        return ((K)hi << 32) | lo;
+    } else {
+        return (K)__shfl((uint32_t)v, src);
+    }
+}
+
+// Sort 512 keys laid out as element e = r*64 + lane, ascending in e.
+template <typename K>
+__device__ __forceinline__ void wave_bitonic_512(K (&v)[8], int lane)
+{
+#pragma unroll
+    for (int size = 2; size <= 512; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= 64) {
+                const int rs = stride >> 6;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if ((r & rs) == 0) {
+                        const bool asc = ((r << 6) & size) == 0;  // size >= 128 here: depends on r only
+                        K a = v[r], b = v[r | rs];
+                        bool sw = asc ? (a > b) : (a < b);
+                        v[r] = sw ? b : a;
+                        v[r | rs] = sw ? a : b;
+                    }
+                }
+            } else {
+                const bool lower = (lane & stride) == 0;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const bool asc = size >= 64 ? (((r << 6) & size) == 0) : ((lane & size) == 0);
+                    K other = shfl_xor_k<K>(v[r], stride);
+                    K mn = v[r] < other ? v[r] : other;
+                    K mx = v[r] < other ? other : v[r];
+                    v[r] = (lower == asc) ? mn : mx;
+                }
+            }
+        }
+    }
+}
+
+// Wave-per-sequence count kernel for sequences with 1..512 windows.
+template <typename K, bool WITH_POS>
+__global__ __launch_bounds__(64) void k_count_short(skm_lut256 lut, int nsym, int k,
+                                                    const uint8_t *__restrict__ seq,
+                                                    const int64_t *__restrict__ off,
+                                                    const int32_t *__restrict__ slen,
+                                                    const uint32_t *__restrict__ list, uint32_t nlist,
+                                                    K *__restrict__ tmp_codes, uint32_t *__restrict__ tmp_counts,
+                                                    uint32_t *__restrict__ tmp_first, int32_t *__restrict__ row_nnz)
+{
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t s_rank[SHORT_MAX + 64];
+    __shared__ K s_uniq[WITH_POS ? SHORT_MAX : 1];
+    __shared__ uint32_t s_pos[WITH_POS ? SHORT_MAX : 1];
+    const int lane = threadIdx.x;
+    const K SENT = sentinel<K>();
+    reinterpret_cast<uint32_t *>(s_lut)[lane] = reinterpret_cast<const uint32_t *>(lut.b)[lane];
+
+    for (uint32_t it = blockIdx.x; it < nlist; it += gridDim.x) {
+        const uint32_t i = list[it];
+        const int64_t b = off[i];
+        const int len = slen[i];
+        const int w = len - k + 1;
+        __syncthreads();
+        for (int p = lane; p < len; p += 64)
+            s_rank[p] = s_lut[seq[b + p]];
+        __syncthreads();
+
+        K v[8];
+        K orig[WITH_POS ? 8 : 1];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            int p = r * 64 + lane;
+            v[r] = p < w ? window_code<K>(s_rank, p, k, nsym) : SENT;
+            if constexpr (WITH_POS)
+                orig[r] = v[r];
+        }
+        wave_bitonic_512<K>(v, lane);
+
+        // run-length encode the sorted keys
+        unsigned long long hmask[8];
+        int nvalid = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            K prev = shfl_idx_k<K>(v[r], (lane + 63) & 63);  // lane-1 (lane 0 reads lane 63: replaced below)
+            if (r > 0) {
+                K tail = shfl_idx_k<K>(v[r - 1], 63);
+                if (lane == 0)
+                    prev = tail;
+            }
+            bool valid = v[r] != SENT;
+            bool first = (r == 0 && lane == 0);
+            bool head = valid && (first || v[r] != prev);
+            hmask[r] = __ballot(head);
+            nvalid += __popcll(__ballot(valid));
+        }
+        int pre[9];
+        pre[0] = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            pre[r + 1] = pre[r] + __popcll(hmask[r]);
+        const int nruns = pre[8];
+        if constexpr (WITH_POS) {
+            for (int t = lane; t < nruns; t += 64)
+                s_pos[t] = 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if ((hmask[r] >> lane) & 1ull) {
+                int e = r * 64 + lane;
+                int idx = pre[r] + __popcll(hmask[r] & ((1ull << lane) - 1ull));
+                int next = nvalid;
+                unsigned long long m = lane == 63 ? 0ull : (hmask[r] >> (lane + 1));
+                if (m) {
+                    next = e + 1 + __ffsll((long long)m) - 1;
+                } else {
+                    bool found = false;
+#pragma unroll
+                    for (int r2 = 0; r2 < 8; ++r2) {
+                        if (r2 > r && !found && hmask[r2]) {
+                            next = r2 * 64 + __ffsll((long long)hmask[r2]) - 1;
+                            found = true;
+                        }
+                    }
+                }
+                tmp_codes[b + idx] = v[r];
+                tmp_counts[b + idx] = (uint32_t)(next - e);
+                if constexpr (WITH_POS)
+                    s_uniq[idx] = v[r];
+            }
+        }
+        if (lane == 0)
+            row_nnz[i] = nruns;
+        if constexpr (WITH_POS) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                K c = orig[r];
+                if (c != SENT) {
+                    int lo = 0, hi = nruns - 1;
+                    while (lo < hi) {
+                        int mid = (lo + hi) >> 1;
+                        if (s_uniq[mid] < c)
+                            lo = mid + 1;
+                        else
+                            hi = mid;
+                    }
+                    atomicMin(&s_pos[lo], (uint32_t)(r * 64 + lane));
+                }
+            }
+            __syncthreads();
+            for (int t = lane; t < nruns; t += 64)
+                tmp_first[b + t] = s_pos[t];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- block variant
+// Workgroup per sequence; keys / run heads / first positions live in LDS (GLOBAL=false, cap <=
+// 8192) or in a per-workgroup slice of global scratch (GLOBAL=true, any length).
+template <typename K, bool WITH_POS, bool GLOBAL>
+__global__ __launch_bounds__(BLK) void k_count_block(skm_lut256 lut, int nsym, int k,
+                                                     const uint8_t *__restrict__ seq,
+                                                     const int64_t *__restrict__ off,
+                                                     const int32_t *__restrict__ slen,
+                                                     const uint32_t *__restrict__ list, uint32_t nlist,
+                                                     uint32_t cap_lds, const int64_t *__restrict__ g_base,
+                                                     uint8_t *__restrict__ g_scratch,
+                                                     K *__restrict__ tmp_codes, uint32_t *__restrict__ tmp_counts,
+                                                     uint32_t *__restrict__ tmp_first, int32_t *__restrict__ row_nnz)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint32_t s_wsum[BLK / 64];
+    __shared__ uint32_t s_nvalid;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const K SENT = sentinel<K>();
+    if (tid < 64)
+        reinterpret_cast<uint32_t *>(s_lut)[tid] = reinterpret_cast<const uint32_t *>(lut.b)[tid];
+
+    for (uint32_t it = blockIdx.x; it < nlist; it += gridDim.x) {
+        const uint32_t i = list[it];
+        const int64_t b = off[i];
+        const int len = slen[i];
+        const uint32_t w = (uint32_t)(len - k + 1);
+        uint32_t cap;
+        K *keys;
+        uint32_t *heads, *pos;
+        uint8_t *ranks = nullptr;
+        if constexpr (GLOBAL) {
+            cap = 1;
+            while (cap < w)
+                cap <<= 1;
+            uint8_t *base = g_scratch + g_base[it];
+            keys = reinterpret_cast<K *>(base);
+            heads = reinterpret_cast<uint32_t *>(base + (size_t)cap * sizeof(K));
+            pos = heads + cap + 1;
+        } else {
+            cap = cap_lds;
+            keys = reinterpret_cast<K *>(s_dyn);
+            heads = reinterpret_cast<uint32_t *>(s_dyn + (size_t)cap * sizeof(K));
+            pos = heads + cap + 1;
+            ranks = reinterpret_cast<uint8_t *>(pos + (WITH_POS ? cap : 0));
+        }
+        __syncthreads();
+        if (tid == 0)
+            s_nvalid = 0;
+        if constexpr (!GLOBAL) {
+            for (int p = tid; p < len; p += BLK)
+                ranks[p] = s_lut[seq[b + p]];
+        }
+        __syncthreads();
+        uint32_t myvalid = 0;
+        for (uint32_t p = tid; p < cap; p += BLK) {
+            K c = SENT;
+            if (p < w) {
+                if constexpr (GLOBAL) {
+                    K acc = 0;
+                    uint32_t bad = 0;
+                    for (int j = 0; j < k; ++j) {
+                        uint32_t r = s_lut[seq[b + p + j]];
+                        bad |= (r == 0xFFu);
+                        acc = acc * (K)nsym + (K)r;
+                    }
+                    c = bad ? SENT : acc;
+                } else {
+                    c = window_code<K>(ranks, (int)p, k, nsym);
+                }
+            }
+            myvalid += (c != SENT);
+            keys[p] = c;
+        }
+        atomicAdd(&s_nvalid, myvalid);
+        __syncthreads();
+        // bitonic sort of `cap` keys
+        for (uint32_t size = 2; size <= cap; size <<= 1) {
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (uint32_t t = tid; t < (cap >> 1); t += BLK) {
+                    uint32_t lo = 2 * t - (t & (stride - 1));
+                    uint32_t hi = lo + stride;
+                    bool asc = (lo & size) == 0;
+                    K a = keys[lo], c2 = keys[hi];
+                    if ((a > c2) == asc) {
+                        keys[lo] = c2;
+                        keys[hi] = a;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        const uint32_t nvalid = s_nvalid;
+        // heads[idx] = position of the idx-th distinct key
+        uint32_t running = 0;
+        for (uint32_t base = 0; base < nvalid; base += BLK) {
+            uint32_t e = base + tid;
+            bool head = e < nvalid && (e == 0 || keys[e] != keys[e - 1]);
+            unsigned long long bal = __ballot(head);
+            if (lane == 0)
+                s_wsum[wid] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int q = 0; q < BLK / 64; ++q) {
+                uint32_t s = s_wsum[q];
+                before += q < wid ? s : 0;
+                total += s;
+            }
+            if (head) {
+                uint32_t idx = running + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                heads[idx] = e;
+                tmp_codes[b + idx] = keys[e];
+            }
+            running += total;
+            __syncthreads();
+        }
+        const uint32_t nruns = running;
+        if (tid == 0) {
+            heads[nruns] = nvalid;
+            row_nnz[i] = (int32_t)nruns;
+        }
+        if constexpr (WITH_POS) {
+            for (uint32_t t = tid; t < nruns; t += BLK)
+                pos[t] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        for (uint32_t t = tid; t < nruns; t += BLK)
+            tmp_counts[b + t] = heads[t + 1] - heads[t];
+        if constexpr (WITH_POS) {
+            for (uint32_t p = tid; p < w; p += BLK) {
+                K c;
+                if constexpr (GLOBAL) {
+                    K acc = 0;
+                    uint32_t bad = 0;
+                    for (int j = 0; j < k; ++j) {
+                        uint32_t r = s_lut[seq[b + p + j]];
+                        bad |= (r == 0xFFu);
+                        acc = acc * (K)nsym + (K)r;
+                    }
+                    c = bad ? SENT : acc;
+                } else {
+                    c = window_code<K>(ranks, (int)p, k, nsym);
+                }
+                if (c != SENT) {
+                    uint32_t lo = 0, hi = nruns - 1;
+                    while (lo < hi) {
+                        uint32_t mid = (lo + hi) >> 1;
+                        if (keys[heads[mid]] < c)
+                            lo = mid + 1;
+                        else
+                            hi = mid;
+                    }
+                    atomicMin(&pos[lo], p);
+                }
+            }
+            __syncthreads();
+            for (uint32_t t = tid; t < nruns; t += BLK)
+                tmp_first[b + t] = pos[t];
+        }
+    }
+}
+
+// Copy each row's entries from its padded slot (at off[i]) to the tight CSR position.
+template <typename K>
+__global__ __launch_bounds__(BLK) void k_compact_rows(const int64_t *__restrict__ off,
+                                                      const int64_t *__restrict__ rowptr, int64_t n,
+                                                      const K *__restrict__ tmp_codes,
+                                                      const uint32_t *__restrict__ tmp_counts,
+                                                      const uint32_t *__restrict__ tmp_first,
+                                                      K *__restrict__ codes, uint32_t *__restrict__ counts,
+                                                      uint32_t *__restrict__ first)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const int64_t src = off[i], dst = rowptr[i];
+        const int64_t cnt = rowptr[i + 1] - dst;
+        for (int64_t t = lane; t < cnt; t += 64) {
+            codes[dst + t] = tmp_codes[src + t];
+            counts[dst + t] = tmp_counts[src + t];
+            if (first)
+                first[dst + t] = tmp_first[src + t];
+        }
+    }
+}
+
+struct to_i64 {
+    __device__ int64_t operator()(int32_t x) const { return (int64_t)x; }
+};
+
+int make_lut(const uint8_t *h, skm_lut256 *out)
+{
+    if (!h) {
+        skm_set_error("null lookup table");
+        return SKM_E_BADARG;
+    }
+    memcpy(out->b, h, 256);
+    return SKM_OK;
+}
+
+int check_code_space(int nsym, int k, int code_bits)
+{
+    if (nsym < 1 || nsym > 254 || k < 1 || k > 64 || (code_bits != 32 && code_bits != 64)) {
+        skm_set_error("bad alphabet size / k / code width (nsym=%d k=%d bits=%d)", nsym, k, code_bits);
+        return SKM_E_BADARG;
+    }
+    // nsym^k must be < 2^code_bits so that the all-ones word stays free as the sentinel
+    unsigned __int128 space = 1, lim = (unsigned __int128)1 << code_bits;
+    for (int j = 0; j < k; ++j) {
+        space *= (unsigned)nsym;
+        if (space >= lim) {
+            skm_set_error("k-mer space %d^%d does not fit %d-bit codes", nsym, k, code_bits);
+            return SKM_E_UNSUPPORTED;
+        }
+    }
+    return SKM_OK;
+}
+
+template <typename K, bool WITH_POS>
+int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const uint8_t *d_seq,
+                   const int64_t *d_off, int64_t n, int64_t total_residues, int64_t *d_rowptr, K *d_codes,
+                   uint32_t *d_counts, uint32_t *d_firstpos, int64_t *h_nnz)
+{
+    hipStream_t st = ctx->stream;
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_A, sizeof(int32_t) * (size_t)(n + 1), &p));
+    int32_t *slen = (int32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_B, sizeof(int32_t) * (size_t)(n + 1), &p));
+    int32_t *row_nnz = (int32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_C, sizeof(uint32_t) * (size_t)n * NBUCKET + 64, &p));
+    uint32_t *lists = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
+    uint32_t *fill = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_D, sizeof(K) * (size_t)(total_residues + 1), &p));
+    K *tmp_codes = (K *)p;
+    SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint32_t) * (size_t)(total_residues + 1), &p));
+    uint32_t *tmp_counts = (uint32_t *)p;
+    uint32_t *tmp_first = nullptr;
+    if (WITH_POS) {
+        SKM_TRY(skm_ws(ctx, WS_F, sizeof(uint32_t) * (size_t)(total_residues + 1), &p));
+        tmp_first = (uint32_t *)p;
+    }
+
+    SKM_HIP(hipMemsetAsync(fill, 0, sizeof(uint32_t) * NBUCKET, st));
+    SKM_HIP(hipMemsetAsync(row_nnz + n, 0, sizeof(int32_t), st));
+    {
+        SKM_PROF(ctx, "k_classify");
+        k_classify<<<(unsigned)skm_ceil_div(n, 256), 256, 0, st>>>(d_seq, d_off, n, k, slen, nullptr, lists, fill,
+                                                                     row_nnz);
+    }
+    SKM_TRY(skm_check_launch("k_classify"));
+    uint32_t *h_fill = (uint32_t *)ctx->h_pinned;
+    SKM_HIP(hipMemcpyAsync(h_fill, fill, sizeof(uint32_t) * NBUCKET, hipMemcpyDeviceToHost, st));
+    SKM_HIP(hipStreamSynchronize(st));
+
+    if (h_fill[1]) {
+        SKM_PROF(ctx, "k_count_short");
+        int grid = skm_grid_cap(ctx, h_fill[1], 64);
+        k_count_short<K, WITH_POS><<<grid, 64, 0, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + 1 * n, h_fill[1],
+                                                         tmp_codes, tmp_counts, tmp_first, row_nnz);
+        SKM_TRY(skm_check_launch("k_count_short"));
+    }
+    for (int bk = 2; bk <= 5; ++bk) {
+        if (!h_fill[bk])
+            continue;
+        uint32_t cap = 512u << (bk - 1);
+        size_t lds = (size_t)cap * sizeof(K) + sizeof(uint32_t) * (cap + 1) + (WITH_POS ? sizeof(uint32_t) * cap : 0) +
+                     (size_t)cap + 64 + 16;
+        SKM_PROF(ctx, "k_count_block_lds");
+        auto kern = k_count_block<K, WITH_POS, false>;
+        SKM_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int grid = skm_grid_cap(ctx, h_fill[bk], 4);
+        kern<<<grid, BLK, lds, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + (int64_t)bk * n, h_fill[bk], cap, nullptr,
+                                     nullptr, tmp_codes, tmp_counts, tmp_first, row_nnz);
+        SKM_TRY(skm_check_launch("k_count_block_lds"));
+    }
+    if (h_fill[6]) {
+        // Rare path (sequences with > 8192 windows): keys in global scratch, one workgroup each.
+        uint32_t nl = h_fill[6];
+        std::vector<uint32_t> ids(nl);
+        SKM_HIP(hipMemcpyAsync(ids.data(), lists + 6 * n, sizeof(uint32_t) * nl, hipMemcpyDeviceToHost, st));
+        SKM_HIP(hipStreamSynchronize(st));
+        std::vector<int32_t> lens(nl);
+        for (uint32_t q = 0; q < nl; ++q)
+            SKM_HIP(hipMemcpyAsync(&lens[q], slen + ids[q], sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        SKM_HIP(hipStreamSynchronize(st));
+        std::vector<int64_t> base(nl);
+        size_t tot = 0;
+        for (uint32_t q = 0; q < nl; ++q) {
+            uint64_t w = (uint64_t)(lens[q] - k + 1), cap = 1;
+            while (cap < w)
+                cap <<= 1;
+            base[q] = (int64_t)tot;
+            tot += cap * sizeof(K) + sizeof(uint32_t) * (2 * cap + 2);
+            tot = (tot + 255) & ~(size_t)255;
+        }
+        SKM_TRY(skm_ws(ctx, WS_G, tot, &p));
+        uint8_t *scratch = (uint8_t *)p;
+        SKM_TRY(skm_ws(ctx, WS_H, sizeof(int64_t) * nl, &p));
+        int64_t *d_base = (int64_t *)p;
+        SKM_HIP(hipMemcpyAsync(d_base, base.data(), sizeof(int64_t) * nl, hipMemcpyHostToDevice, st));
+        SKM_HIP(hipStreamSynchronize(st));
+        SKM_PROF(ctx, "k_count_block_global");
+        k_count_block<K, WITH_POS, true><<<nl, BLK, 16, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + 6 * n, nl, 0,
+                                                               d_base, scratch, tmp_codes, tmp_counts, tmp_first,
+                                                               row_nnz);
+        SKM_TRY(skm_check_launch("k_count_block_global"));
+    }
+
+    // rowptr = exclusive scan of row_nnz (n+1 entries, the last one zero)
+    {
+        size_t tmp_bytes = 0;
+        auto in = rocprim::make_transform_iterator(row_nnz, to_i64());
+        SKM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, in, d_rowptr, (int64_t)0, (size_t)(n + 1),
+                                        rocprim::plus<int64_t>(), st));
+        SKM_TRY(skm_ws(ctx, WS_ROCPRIM, tmp_bytes, &p));
+        SKM_PROF(ctx, "rocprim_scan_rowptr");
+        SKM_HIP(rocprim::exclusive_scan(p, tmp_bytes, in, d_rowptr, (int64_t)0, (size_t)(n + 1),
+                                        rocprim::plus<int64_t>(), st));
+    }
+    {
+        SKM_PROF(ctx, "k_compact_rows");
+        int grid = skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16);
+        k_compact_rows<K><<<grid, BLK, 0, st>>>(d_off, d_rowptr, n, tmp_codes, tmp_counts, tmp_first, d_codes, d_counts,
+                                                 WITH_POS ? d_firstpos : nullptr);
+    }
+    SKM_TRY(skm_check_launch("k_compact_rows"));
+    int64_t *h_n = (int64_t *)ctx->h_pinned;
+    SKM_HIP(hipMemcpyAsync(h_n, d_rowptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    SKM_HIP(hipStreamSynchronize(st));
+    *h_nnz = *h_n;
+    return SKM_OK;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" int skm_recode(skm_ctx *ctx, const uint8_t *h_translate, const uint8_t *d_seq, const int64_t *d_off,
+                          int64_t n, uint8_t *d_out, int32_t *d_outlen)
+{
+    SKM_REQUIRE(ctx && d_off && d_outlen && n >= 0, SKM_E_BADARG, "skm_recode: bad argument");
+    skm_lut256 lut;
+    SKM_TRY(make_lut(h_translate, &lut));
+    if (n == 0)
+        return SKM_OK;
+    SKM_HIP(hipSetDevice(ctx->device));
+    int64_t *h_tot = (int64_t *)ctx->h_pinned;
+    SKM_HIP(hipMemcpyAsync(h_tot, d_off + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SKM_HIP(hipStreamSynchronize(ctx->stream));
+    int64_t total = *h_tot;
+    SKM_REQUIRE(total == 0 || (d_seq && d_out), SKM_E_BADARG, "skm_recode: null sequence buffer");
+    SKM_REQUIRE(((uintptr_t)d_seq & 15) == 0 && ((uintptr_t)d_out & 15) == 0, SKM_E_BADARG,
+                "skm_recode: buffers must be 16-byte aligned");
+    if (total) {
+        SKM_PROF(ctx, "k_recode_bytes");
+        int grid = skm_grid_cap(ctx, skm_ceil_div(total, 256 * 16), 8);
+        k_recode_bytes<<<grid, 256, 0, ctx->stream>>>(lut, d_seq, d_out, total);
+        SKM_TRY(skm_check_launch("k_recode_bytes"));
+    }
+    {
+        SKM_PROF(ctx, "k_classify");
+        k_classify<<<(unsigned)skm_ceil_div(n, 256), 256, 0, ctx->stream>>>(d_seq, d_off, n, 1, d_outlen, nullptr,
+                                                                             nullptr, nullptr, nullptr);
+    }
+    return skm_check_launch("k_classify");
+}
+
+extern "C" int skm_kmer_codes(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits,
+                              const uint8_t *d_seq, const int64_t *d_off, int64_t n, void *d_codes,
+                              int32_t *d_nwin)
+{
+    SKM_REQUIRE(ctx && d_off && d_nwin && d_codes && n >= 0, SKM_E_BADARG, "skm_kmer_codes: bad argument");
+    skm_lut256 lut;
+    SKM_TRY(make_lut(h_rank, &lut));
+    SKM_TRY(check_code_space(nsym, k, code_bits));
+    if (n == 0)
+        return SKM_OK;
+    SKM_HIP(hipSetDevice(ctx->device));
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_A, sizeof(int32_t) * (size_t)(n + 1), &p));
+    int32_t *slen = (int32_t *)p;
+    {
+        SKM_PROF(ctx, "k_classify");
+        k_classify<<<(unsigned)skm_ceil_div(n, 256), 256, 0, ctx->stream>>>(d_seq, d_off, n, k, slen, d_nwin, nullptr,
+                                                                             nullptr, nullptr);
+    }
+    SKM_TRY(skm_check_launch("k_classify"));
+    int grid = skm_grid_cap(ctx, n, 64);
+    SKM_PROF(ctx, "k_kmer_codes");
+    if (code_bits == 32)
+        k_kmer_codes<uint32_t><<<grid, 64, 0, ctx->stream>>>(lut, nsym, k, d_seq, d_off, n, slen, (uint32_t *)d_codes);
+    else
+        k_kmer_codes<uint64_t><<<grid, 64, 0, ctx->stream>>>(lut, nsym, k, d_seq, d_off, n, slen, (uint64_t *)d_codes);
+    return skm_check_launch("k_kmer_codes");
+}
+
+extern "C" int skm_count_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits,
+                             const uint8_t *d_seq, const int64_t *d_off, int64_t n, int64_t total_residues,
+                             int64_t cap_entries, int64_t *d_rowptr, void *d_codes, uint32_t *d_counts,
+                             uint32_t *d_firstpos, int64_t *h_nnz)
+{
+    SKM_REQUIRE(ctx && d_off && d_rowptr && d_codes && d_counts && h_nnz && n >= 0, SKM_E_BADARG,
+                "skm_count_csr: bad argument");
+    SKM_REQUIRE(cap_entries >= total_residues, SKM_E_BADARG,
+                "skm_count_csr: cap_entries (%lld) must be >= total residues (%lld)", (long long)cap_entries,
+                (long long)total_residues);
+    SKM_REQUIRE(total_residues < ((int64_t)1 << 32), SKM_E_OVERFLOW,
+                "skm_count_csr: more than 2^32 residues in one batch; split the batch");
+    skm_lut256 lut;
+    SKM_TRY(make_lut(h_rank, &lut));
+    SKM_TRY(check_code_space(nsym, k, code_bits));
+    SKM_HIP(hipSetDevice(ctx->device));
+    *h_nnz = 0;
+    if (n == 0) {
+        SKM_HIP(hipMemsetAsync(d_rowptr, 0, sizeof(int64_t), ctx->stream));
+        return SKM_OK;
+    }
+    if (code_bits == 32) {
+        if (d_firstpos)
+            return count_csr_impl<uint32_t, true>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, d_rowptr,
+                                                  (uint32_t *)d_codes, d_counts, d_firstpos, h_nnz);
+        return count_csr_impl<uint32_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, d_rowptr,
+                                               (uint32_t *)d_codes, d_counts, nullptr, h_nnz);
+    }
+    if (d_firstpos)
+        return count_csr_impl<uint64_t, true>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, d_rowptr,
+                                              (uint64_t *)d_codes, d_counts, d_firstpos, h_nnz);
+    return count_csr_impl<uint64_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, d_rowptr,
+                                           (uint64_t *)d_codes, d_counts, nullptr, h_nnz);
+}

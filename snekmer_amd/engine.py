@@ -1,0 +1,259 @@
+"""engine: batched device operations of the hot path, composed from the C-ABI entry points.
+
+Data stays in HBM between stages:
+
+    SeqBatch --count_csr--> CountsCSR --build_basis--> Basis (+ column ids, postings)
+                                         |                         |
+                                         +------ cosine_matrix ----+--> float32 [rows x M] in HBM
+
+The reference does each of these per sequence in Python (snekmer/rules/kmerize.smk:89-129,
+snekmer/rules/learn.smk:359-383, snekmer/rules/apply.smk:188-206,278-289); here each stage is
+one call per batch.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _hip
+from .alphabet import AlphabetLUT
+
+_p = C.c_void_p
+_i64 = C.c_int64
+
+
+def _ptr(arr) -> _p:
+    if arr is None:
+        return _p(None)
+    if isinstance(arr, _hip.DeviceArray):
+        return _p(arr.ptr)
+    if isinstance(arr, np.ndarray):
+        return arr.ctypes.data_as(_p)
+    return _p(int(arr))
+
+
+def key_bits(nsym: int, k: int) -> int:
+    return max(1, int(nsym**k - 1).bit_length())
+
+
+class SeqBatch:
+    """Packed sequences resident on the device (bytes + int64 offsets[n+1])."""
+
+    def __init__(self, ctx: _hip.Context, residues: np.ndarray, offsets: np.ndarray):
+        residues = np.ascontiguousarray(residues, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if offsets.ndim != 1 or offsets.size < 1 or offsets[0] != 0 or np.any(np.diff(offsets) < 0):
+            raise ValueError("offsets must start at 0 and be non-decreasing")
+        if int(offsets[-1]) != residues.size:
+            raise ValueError("offsets[-1] must equal the number of residues")
+        self.ctx = ctx
+        self.n = int(offsets.size - 1)
+        self.total = int(residues.size)
+        self.h_offsets = offsets
+        # 64 spare bytes keep 16-byte vector loads of the tail in bounds
+        self.d_seq = ctx.zeros(self.total + 64, np.uint8)
+        if self.total:
+            ctx._h2d(self.d_seq.ptr, residues)
+        self.d_off = ctx.to_device(offsets)
+
+    @classmethod
+    def from_strings(cls, ctx, seqs: Sequence[str]) -> "SeqBatch":
+        from .utils import pack_sequences
+
+        data, off = pack_sequences(seqs)
+        return cls(ctx, data, off)
+
+
+class CountsCSR:
+    """Per-sequence (code, count) lists on the device; codes ascending within a row."""
+
+    def __init__(self, ctx, n, nnz, code_bits, rowptr, codes, counts, firstpos):
+        self.ctx, self.n, self.nnz, self.code_bits = ctx, n, nnz, code_bits
+        self.rowptr, self.codes, self.counts, self.firstpos = rowptr, codes, counts, firstpos
+        self.colidx: Optional[_hip.DeviceArray] = None
+
+    @property
+    def code_dtype(self):
+        return np.uint32 if self.code_bits == 32 else np.uint64
+
+    def host(self):
+        """(rowptr, codes, counts, firstpos|None) as numpy arrays."""
+        fp = self.firstpos.download(self.nnz) if self.firstpos is not None else None
+        return (
+            self.rowptr.download(self.n + 1),
+            self.codes.download(self.nnz),
+            self.counts.download(self.nnz),
+            fp,
+        )
+
+
+class Basis:
+    """Observed k-mer basis of one CountsCSR plus its column-major copy (postings)."""
+
+    def __init__(self):
+        self.ncols = 0
+        self.codes = self.df = self.total = self.firstkey = self.fs_order = None
+        self.colptr = self.prow = self.pval = None
+
+
+def recode(ctx: _hip.Context, batch: SeqBatch, lut: AlphabetLUT) -> Tuple[np.ndarray, np.ndarray]:
+    """a3: translated bytes (same layout as the input) and stripped lengths, on the host."""
+    d_out = ctx.empty(batch.total + 64, np.uint8)
+    d_len = ctx.empty(max(batch.n, 1), np.int32)
+    ctx.call("skm_recode", _ptr(lut.translate), _ptr(batch.d_seq), _ptr(batch.d_off), _i64(batch.n), _ptr(d_out), _ptr(d_len))
+    return d_out.download(batch.total), d_len.download(batch.n)
+
+
+def kmer_codes(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int) -> Tuple[np.ndarray, np.ndarray, int]:
+    """a5/a6: (codes per window slot, windows per sequence, code_bits) on the host."""
+    bits = lut.code_bits(k)
+    dt = np.uint32 if bits == 32 else np.uint64
+    d_codes = ctx.empty(batch.total + 1, dt)
+    d_nwin = ctx.zeros(max(batch.n, 1), np.int32)
+    ctx.call(
+        "skm_kmer_codes", _ptr(lut.rank), lut.nsym, k, bits, _ptr(batch.d_seq), _ptr(batch.d_off), _i64(batch.n),
+        _ptr(d_codes), _ptr(d_nwin),
+    )
+    return d_codes.download(batch.total), d_nwin.download(batch.n), bits
+
+
+def count_csr(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int, with_firstpos: bool = False,
+              out: Optional[CountsCSR] = None) -> CountsCSR:
+    """a12: per-sequence k-mer counts.  Pass `out` (from a previous call on an equally sized
+    batch) to reuse its device buffers."""
+    bits = lut.code_bits(k)
+    dt = np.uint32 if bits == 32 else np.uint64
+    cap = batch.total + 1
+    if out is None or out.codes.size < cap or out.code_bits != bits or out.rowptr.size < batch.n + 1:
+        rowptr = ctx.empty(batch.n + 1, np.int64)
+        codes = ctx.empty(cap, dt)
+        counts = ctx.empty(cap, np.uint32)
+        firstpos = ctx.empty(cap, np.uint32) if with_firstpos else None
+        out = CountsCSR(ctx, batch.n, 0, bits, rowptr, codes, counts, firstpos)
+    elif with_firstpos and out.firstpos is None:
+        out.firstpos = ctx.empty(cap, np.uint32)
+    nnz = _i64(0)
+    ctx.call(
+        "skm_count_csr", _ptr(lut.rank), lut.nsym, k, bits, _ptr(batch.d_seq), _ptr(batch.d_off), _i64(batch.n),
+        _i64(batch.total), _i64(cap), _ptr(out.rowptr), _ptr(out.codes), _ptr(out.counts),
+        _ptr(out.firstpos if with_firstpos else None), C.byref(nnz),
+    )
+    out.n, out.nnz = batch.n, int(nnz.value)
+    return out
+
+
+def build_basis(ctx, csr: CountsCSR, nsym: int, k: int, stats: bool = False, first_seen: bool = False,
+                postings: bool = True, out: Optional[Basis] = None) -> Basis:
+    """a11: observed basis (ascending codes), column ids for `csr`, optional stats / first-seen
+    order / postings."""
+    nnz = csr.nnz
+    b = out or Basis()
+    cap = max(nnz, 1)
+    dt = csr.code_dtype
+
+    def need(cur, size, dtype):
+        if cur is None or cur.size < size or cur.dtype != np.dtype(dtype):
+            return ctx.empty(size, dtype)
+        return cur
+
+    b.codes = need(b.codes, cap, dt)
+    csr.colidx = need(csr.colidx, cap, np.uint32)
+    if stats:
+        b.df = need(b.df, cap, np.uint32)
+        b.total = need(b.total, cap, np.uint64)
+    if first_seen:
+        if csr.firstpos is None:
+            raise ValueError("first_seen=True needs count_csr(..., with_firstpos=True)")
+        b.firstkey = need(b.firstkey, cap, np.uint64)
+        b.fs_order = need(b.fs_order, cap, np.uint32)
+    if postings:
+        b.colptr = need(b.colptr, cap + 1, np.uint32)
+        b.prow = need(b.prow, cap, np.uint32)
+        b.pval = need(b.pval, cap, np.uint32)
+    ncols = _i64(0)
+    ctx.call(
+        "skm_basis_build", csr.code_bits, key_bits(nsym, k), _i64(csr.n), _i64(nnz), _ptr(csr.rowptr), _ptr(csr.codes),
+        _ptr(csr.counts), _ptr(csr.firstpos if first_seen else None), C.byref(ncols), _ptr(b.codes), _ptr(csr.colidx),
+        _ptr(b.df if stats else None), _ptr(b.total if stats else None), _ptr(b.firstkey if first_seen else None),
+        _ptr(b.fs_order if first_seen else None), _ptr(b.colptr if postings else None),
+        _ptr(b.prow if postings else None), _ptr(b.pval if postings else None),
+    )
+    b.ncols = int(ncols.value)
+    return b
+
+
+def row_norms(ctx, n: int, rowptr, counts, out=None) -> _hip.DeviceArray:
+    rn = out if out is not None and out.size >= max(n, 1) else ctx.empty(max(n, 1) + 4, np.float32)
+    ctx.call("skm_row_norms_csr", _i64(n), _ptr(rowptr), _ptr(counts), _ptr(rn), _ptr(None))
+    return rn
+
+
+def transpose(ctx, n: int, nnz: int, ncols: int, rowptr, colidx, counts):
+    colptr = ctx.empty(ncols + 1, np.uint32)
+    prow = ctx.empty(max(nnz, 1), np.uint32)
+    pval = ctx.empty(max(nnz, 1), np.uint32)
+    ctx.call("skm_csr_transpose", _i64(n), _i64(nnz), _i64(ncols), _ptr(rowptr), _ptr(colidx), _ptr(counts),
+             _ptr(colptr), _ptr(prow), _ptr(pval))
+    return colptr, prow, pval
+
+
+def cosine_matrix(ctx, x: CountsCSR, x_rnorm, m: int, ncols: int, colptr, prow, pval, y_rnorm,
+                  row0: int = 0, row1: Optional[int] = None, mode: int = 0, out=None, ld: Optional[int] = None):
+    """a13/a14: float32 block [row1-row0, m] of cosine similarities (mode 0) or distances (mode 1)."""
+    row1 = x.n if row1 is None else row1
+    ld = m if ld is None else ld
+    rows = row1 - row0
+    if out is None:
+        out = ctx.empty((max(rows, 1), max(ld, 1)), np.float32)
+    ctx.call(
+        "skm_cosine_csr", _i64(x.n), _ptr(x.rowptr), _ptr(x.colidx), _ptr(x.counts), _ptr(x_rnorm), _i64(m), _i64(ncols),
+        _ptr(colptr), _ptr(prow), _ptr(pval), _ptr(y_rnorm), _i64(row0), _i64(row1), mode, _ptr(out), _i64(ld),
+    )
+    return out
+
+
+def csr_to_dense(ctx, n: int, rowptr, colidx, counts, ncols_out: int, colmap=None, presence: bool = False,
+                 dtype=np.float64) -> _hip.DeviceArray:
+    code = {np.dtype(np.float64): 0, np.dtype(np.float32): 1, np.dtype(np.int8): 2}[np.dtype(dtype)]
+    out = ctx.empty((max(n, 1), max(ncols_out, 1)), dtype)
+    ctx.call("skm_csr_to_dense", _i64(n), _ptr(rowptr), _ptr(colidx), _ptr(counts), _ptr(colmap), _i64(ncols_out),
+             1 if presence else 0, code, _ptr(out), _i64(max(ncols_out, 1)))
+    return out
+
+
+class Pipeline:
+    """vectorize + all-pairs cosine for one batch, reusing every device buffer between steps.
+
+    This is the unit `bench.py` times: inputs resident in HBM, outputs (CSR counts, basis,
+    N x N float32 cosine) resident in HBM.
+    """
+
+    def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int):
+        self.ctx, self.lut, self.k = ctx, lut, k
+        self.csr: Optional[CountsCSR] = None
+        self.basis: Optional[Basis] = None
+        self.rnorm = None
+        self.out = None
+
+    def vectorize(self, batch: SeqBatch) -> CountsCSR:
+        self.csr = count_csr(self.ctx, batch, self.lut, self.k, out=self.csr)
+        self.basis = build_basis(self.ctx, self.csr, self.lut.nsym, self.k, out=self.basis)
+        self.rnorm = row_norms(self.ctx, self.csr.n, self.csr.rowptr, self.csr.counts, out=self.rnorm)
+        return self.csr
+
+    def cosine(self, row0: int = 0, row1: Optional[int] = None):
+        n = self.csr.n
+        row1 = n if row1 is None else row1
+        rows = row1 - row0
+        ld = (n + 3) // 4 * 4
+        if self.out is None or self.out.shape[0] < rows or self.out.shape[1] != ld:
+            self.out = None
+            self.out = self.ctx.empty((max(rows, 1), max(ld, 1)), np.float32)
+        b = self.basis
+        cosine_matrix(self.ctx, self.csr, self.rnorm, n, b.ncols, b.colptr, b.prow, b.pval, self.rnorm,
+                      row0=row0, row1=row1, out=self.out, ld=ld)
+        return self.out
+
+    def step(self, batch: SeqBatch):
+        self.vectorize(batch)
+        return self.cosine()

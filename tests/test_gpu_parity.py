@@ -1,0 +1,316 @@
+"""GPU parity: HIP path (through the C-ABI) vs the oracle and the committed golden fixtures.
+
+Bars: bit-exact for codes, counts, column ids, basis order; |delta| <= 1e-5 for cosine
+(BASELINE.json north_star).  Nothing here reads /root/reference.
+"""
+import glob
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, alpha_key, csr_to_dense, demo_records, ensure_red6, gjson, gnpz, parse_tag
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 1e-5
+
+ensure_red6()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from snekmer_amd import _hip
+
+    return _hip.default_context()
+
+
+def _oracle():
+    from oracle import c_oracle
+
+    return c_oracle
+
+
+def _mixed_batch(seed, n=600, long_lengths=(600, 1030, 2100, 4200, 8100, 9000, 20000)):
+    """Short family sequences plus a few long ones (LDS-block and global-scratch size classes),
+    empties, shorter-than-k, all-invalid and low-complexity records."""
+    from snekmer_amd.synth import synth_families
+    from snekmer_amd.utils import pack_sequences
+
+    res, off, _ = synth_families(n, 300, family=20, seed=seed)
+    raw = res.tobytes()
+    seqs = [raw[off[i] : off[i + 1]].decode() for i in range(n)]
+    rng = np.random.default_rng(seed)
+    aa = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+    for L in long_lengths:
+        s = aa[rng.integers(0, 20, size=L)].tobytes().decode()
+        seqs.insert(int(rng.integers(0, len(seqs))), s)
+    seqs += ["", "MKV", "XXXXXXXXXXXXXXXXXXXXXXXXXXXXXX", "A" * 700, "AG" * 300 + "**", "*", "MKVLAAGIWSTC" * 90 + "X" + "MKVLAAGIWSTC" * 20]
+    return seqs, pack_sequences(seqs)
+
+
+# ------------------------------------------------------------------ a3 / a5 / a6 edge cases
+def test_reduce_and_reduce_vectorize_edge_cases():
+    import snekmer_amd as skm
+
+    g2 = gjson("g2_edge_cases.json")
+    by_cfg = {}
+    for case in g2:
+        by_cfg.setdefault((case["alphabet"], case["k"]), []).append(case)
+    checked = 0
+    for (name, k), cases in by_cfg.items():
+        key = alpha_key(name)
+        lut = skm.alphabet.build_lut(key)
+        if lut.nsym**k >= 2**64:
+            with pytest.raises(ValueError):
+                skm.vectorize.KmerVec(key, k).reduce_vectorize("MKVLAAGIW" * 4)
+            continue
+        seqs = [c["seq"] for c in cases]
+        reduced = skm.vectorize.reduce_batch(seqs, key)
+        kmers = skm.vectorize.KmerVec(key, k).reduce_vectorize_batch(seqs)
+        for c, red, km in zip(cases, reduced, kmers):
+            assert red == c["reduced"], (name, k, c["seq"])
+            assert list(km) == c["kmers"], (name, k, c["seq"])
+            assert str(km.dtype) == c["dtype"] and list(km.shape) == c["shape"]
+            checked += 1
+    assert checked > 500
+    # single-record API
+    kv = skm.vectorize.KmerVec("hydro", 4)
+    assert list(kv.reduce_vectorize("MKVLXAGIWST")) == ["VSVV", "VVVS", "VVSS", "VSSS"]
+    assert skm.vectorize.reduce("MKVLAAGIWSTCX*", 1) == "AKAAAAAAFNNCX"
+    assert list(kv._kmer_gen("VSVV*VVVS")) == ["VSVV", "VVVS"]
+    assert list(kv._kmer_gen("VSVVV*")) == ["VSVV", "SVVV"]
+
+
+# ------------------------------------------------------------------ a12 counts, all size classes
+@pytest.mark.parametrize(
+    "name,k", [("red6", 12), ("standard", 12), ("hydro", 20), ("hydro", 14), ("solvacc", 8), (None, 3), ("miqs", 8), ("hydro", 33), ("ptm", 5)]
+)
+def test_count_csr_and_basis_vs_oracle(ctx, name, k):
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+
+    orc = _oracle()
+    lut = A.build_lut(name)
+    seqs, (res, off) = _mixed_batch(seed=11 + k)
+    batch = engine.SeqBatch(ctx, res, off)
+    csr = engine.count_csr(ctx, batch, lut, k, with_firstpos=True)
+    rowptr, codes, counts, first = csr.host()
+    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+    assert csr.nnz == len(o_codes)
+    assert (rowptr == o_rowptr).all()
+    assert (codes.astype(np.uint64) == o_codes).all()
+    assert (counts == o_counts).all()
+    assert (first == o_first).all()
+
+    # window-order codes (a5/a6)
+    wcodes, nwin, bits = engine.kmer_codes(ctx, batch, lut, k)
+    o_w, o_nwin = orc.kmer_codes(lut.rank, lut.nsym, k, res, off)
+    assert (nwin == o_nwin).all()
+    sent = np.iinfo(wcodes.dtype).max
+    for i in range(batch.n):
+        a = wcodes[off[i] : off[i] + nwin[i]].astype(np.uint64)
+        b = o_w[off[i] : off[i] + nwin[i]]
+        a = np.where(a == np.uint64(sent), np.iinfo(np.uint64).max, a)
+        assert (a == b).all()
+
+    # observed basis (a11)
+    b = engine.build_basis(ctx, csr, lut.nsym, k, stats=True, first_seen=True, postings=True)
+    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
+    B = b.ncols
+    assert B == len(ob)
+    assert (b.codes.download(B).astype(np.uint64) == ob).all()
+    assert (b.df.download(B) == odf).all()
+    assert (b.total.download(B) == otot).all()
+    assert (b.firstkey.download(B) == ofk).all()
+    assert (csr.colidx.download(csr.nnz) == ocol).all()
+    assert (b.fs_order.download(B) == np.argsort(ofk, kind="stable")).all()
+    # postings = column-major copy, rows ascending inside a column
+    colptr = b.colptr.download(B + 1)
+    prow, pval = b.prow.download(csr.nnz), b.pval.download(csr.nnz)
+    assert colptr[0] == 0 and colptr[B] == csr.nnz and (np.diff(colptr.astype(np.int64)) == odf).all()
+    row_of = np.repeat(np.arange(batch.n), np.diff(o_rowptr))
+    order = np.lexsort((row_of, ocol))
+    assert (prow == row_of[order]).all() and (pval == o_counts[order]).all()
+
+    # without first positions the same counts come out
+    csr2 = engine.count_csr(ctx, batch, lut, k, with_firstpos=False)
+    r2, c2, n2, _ = csr2.host()
+    assert (r2 == o_rowptr).all() and (c2.astype(np.uint64) == o_codes).all() and (n2 == o_counts).all()
+
+
+def test_unsupported_code_space_is_loud(ctx):
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+
+    lut = A.build_lut(None)  # 20 letters
+    batch = engine.SeqBatch.from_strings(ctx, ["MKVLAAGIWSTCDEFHNPQRY" * 3])
+    with pytest.raises(ValueError):
+        engine.count_csr(ctx, batch, lut, 15)  # 20^15 > 2^64
+
+
+# ------------------------------------------------------------------ a11 rule outputs vs goldens
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g3_demo_*_mf*.npz"))))
+def test_vectorize_records_matches_rule_goldens(ctx, path):
+    from snekmer_amd.kmerize import vectorize_records
+
+    tag = os.path.basename(path)[len("g3_demo_") : -4]
+    alphabet, k, mf = parse_tag(tag)
+    g = np.load(path)
+    out = vectorize_records(demo_records(), alphabet, k, min_filter=mf, ctx=ctx)
+    vecs = np.unpackbits(g["vecs_bits"], axis=1)[:, : g["vecs_shape"][1]]
+    assert list(out["kmerlist"]) == list(g["kmerlist"])
+    assert out["kmerlist"].dtype == g["kmerlist"].dtype
+    assert list(out["ids"]) == list(g["ids"])
+    assert list(out["seqs"]) == list(g["seqs"])
+    assert list(out["lengths"]) == list(g["lengths"])
+    assert out["vecs"].dtype == np.float64 and out["vecs"].shape == tuple(g["vecs_shape"])
+    assert (out["vecs"] == vecs).all()
+    mine = csr_to_dense(out["counts_rowptr"], out["counts_col"], out["counts_val"], len(g["kmerlist"]))
+    gold = csr_to_dense(g["counts_rowptr"], g["counts_col"], g["counts_val"], len(g["kmerlist"]))
+    assert (mine == gold).all()
+
+
+def test_vectorize_records_basis_file_branch(ctx):
+    from snekmer_amd.kmerize import vectorize_records
+
+    g = gnpz("g3_demo_hydro_k14_basisfile.npz")
+    out = vectorize_records(demo_records(), "hydro", 14, basis=list(g["kmerlist"]), ctx=ctx)
+    vecs = np.unpackbits(g["vecs_bits"], axis=1)[:, : g["vecs_shape"][1]]
+    assert (out["vecs"] == vecs).all()
+    assert list(out["kmerlist"]) == list(g["kmerlist"])
+
+
+def test_vectorize_fasta_writes_reference_formats(ctx, tmp_path):
+    import snekmer_amd as skm
+    from snekmer_amd.kmerize import vectorize_fasta
+
+    g = gnpz("g3_demo_hydro_k14_mf0.npz")
+    npz, kmers = str(tmp_path / "TIGR03149.npz"), str(tmp_path / "TIGR03149.kmers")
+    vectorize_fasta(os.path.join(GOLDEN, "data", "TIGR03149.faa"), "hydro", 14, npz_out=npz, kmers_out=kmers)
+    (kmerlist,), df = skm.io.load_npz(npz)
+    assert list(df.columns) == ["filename", "sequence_id", "sequence", "sequence_length", "sequence_vector"]
+    n = len(df)
+    assert list(df["sequence_id"]) == list(g["ids"][:n]) and list(df["sequence"]) == list(g["seqs"][:n])
+    with open(kmers, "rb") as f:
+        kv = pickle.load(f)
+    assert sorted(kv.__dict__) == sorted(gjson("g6_basis.json")["kmervec_attrs"])
+    assert list(kv.kmer_set.kmers) == list(kmerlist)
+
+
+# ------------------------------------------------------------------ a13 / a14 cosine
+@pytest.mark.parametrize("tag", ["hydro_k14_mf0", "standard_k8_mf0", "red6_k8_mf0", "hydro_k20_mf0", "solvacc_k8_mf0", "None_k3_mf0"])
+def test_cosine_matches_sklearn_goldens(ctx, tag):
+    import scipy.sparse as sp
+
+    from snekmer_amd.score import cosine_similarity
+
+    g = gnpz(f"g3_demo_{tag}.npz")
+    ncols = len(g["kmerlist"])
+    counts = csr_to_dense(g["counts_rowptr"], g["counts_col"], g["counts_val"], ncols)
+    S = cosine_similarity(counts, ctx=ctx)
+    assert S.dtype == np.float32 and S.shape == g["cosine"].shape
+    assert np.abs(S - g["cosine"]).max() <= COS_TOL
+    # sparse input, rectangular family-totals x sequences, transposed as the rule does
+    R = cosine_similarity(g["totals"], sp.csr_matrix(counts), ctx=ctx).T
+    assert np.abs(R - g["cosine_rect"]).max() <= COS_TOL
+
+
+@pytest.mark.parametrize("name,k", [("red6", 12), ("standard", 12), ("hydro", 20)])
+def test_pipeline_matches_synthetic_goldens(ctx, name, k):
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+
+    g = gnpz(f"g8_synth_{name}_k{k}.npz")
+    lut = A.build_lut(name)
+    pipe = engine.Pipeline(ctx, lut, k)
+    batch = engine.SeqBatch(ctx, g["residues"], g["offsets"])
+    out = pipe.step(batch)
+    n = batch.n
+    S = out.download().reshape(out.shape)[:n, :n]
+    assert np.abs(S - g["cosine"]).max() <= COS_TOL
+    # second step on the same buffers gives identical bits (no stale scratch)
+    S2 = pipe.step(batch).download().reshape(out.shape)[:n, :n]
+    assert (S == S2).all()
+
+
+def test_cosine_medium_vs_oracle_all_modes(ctx):
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+
+    orc = _oracle()
+    lut = A.build_lut("red6")
+    k = 12
+    seqs, (res, off) = _mixed_batch(seed=5, n=1500)
+    batch = engine.SeqBatch(ctx, res, off)
+    pipe = engine.Pipeline(ctx, lut, k)
+    out = pipe.step(batch)
+    n = batch.n
+    S = out.download().reshape(out.shape)[:n, :n]
+    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
+    ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), np.arange(n))
+    assert np.abs(S - ref).max() <= COS_TOL
+    # rows with no valid k-mer are all-zero, including their diagonal (sklearn: zero norm -> 1)
+    empty = np.nonzero(np.diff(o_rowptr) == 0)[0]
+    assert len(empty) >= 3 and (S[empty] == 0).all() and (S[:, empty] == 0).all()
+    # row-block call (what one rank computes) equals the corresponding rows
+    blk = pipe.cosine(row0=501, row1=1203).download().reshape(pipe.out.shape)[: 1203 - 501, :n]
+    assert (blk == S[501:1203]).all()
+    # distance mode
+    b = pipe.basis
+    D = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, b.ncols, b.colptr, b.prow, b.pval, pipe.rnorm, mode=1,
+                             ld=pipe.out.shape[1]).download().reshape(-1, pipe.out.shape[1])[:n, :n]
+    refD = np.clip(1.0 - ref, 0, 2)
+    np.fill_diagonal(refD, 0.0)
+    assert np.abs(D - refD).max() <= COS_TOL and (np.diag(D) == 0).all()
+
+
+def test_connection_matrix_and_feature_matrix_goldens(ctx):
+    import snekmer_amd as skm
+
+    g = gnpz("g9_connection.npz")
+    D = skm.score.connection_matrix_from_features(g["X"], metric="cosine")
+    assert np.abs(D - g["cosine"]).max() <= COS_TOL
+    with pytest.raises(NotImplementedError):
+        skm.score.connection_matrix_from_features(g["X"] + 0.5, metric="cosine")
+    for case in gjson("g7_feature_matrix.json"):
+        rows, kl = skm.vectorize.make_feature_matrix([np.asarray(v, dtype=str) for v in case["vecs"]], case["min_filter"])
+        assert [str(x) for x in kl] == case["kmerlist"]
+        assert [r.tolist() for r in rows] == case["rows"]
+
+
+# ------------------------------------------------------------------ BASELINE sizes: properties
+@pytest.mark.parametrize("n", [10000])
+def test_config2_properties_and_sampled_rows(ctx, n):
+    """BASELINE configs[1]: 10k x 300 aa, red6 k=12.  Full oracle matrix is out of reach in
+    seconds, so: sampled rows against the oracle, symmetry, unit diagonal, checksum of row sums."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+
+    orc = _oracle()
+    lut = A.build_lut("red6")
+    k = 12
+    res, off, fam = synth_families(n, 300, family=100, seed=20250523 + 1)
+    batch = engine.SeqBatch(ctx, res, off)
+    pipe = engine.Pipeline(ctx, lut, k)
+    out = pipe.step(batch)
+    ld = out.shape[1]
+    rowptr, codes, counts, _ = pipe.csr.host()
+    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+    assert (rowptr == o_rowptr).all() and (codes.astype(np.uint64) == o_codes).all() and (counts == o_counts).all()
+    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
+    assert pipe.basis.ncols == len(ob)
+    rows = np.sort(np.random.default_rng(3).choice(n, size=96, replace=False))
+    ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), rows)
+    got = np.stack([out.download(n, offset=int(r) * ld) for r in rows])
+    assert np.abs(got - ref).max() <= COS_TOL
+    sub = got[:, rows]
+    assert np.abs(sub - sub.T).max() <= 2e-7
+    assert np.abs(np.diag(sub) - 1.0).max() <= 1e-6
+    # members of a family are each other's nearest neighbours
+    for r, row in zip(rows[:8], got[:8]):
+        top = np.argsort(-row)[1:6]
+        assert (fam[top] == fam[r]).all()

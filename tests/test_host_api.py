@@ -1,0 +1,129 @@
+"""CPU-side checks: host logic of the reference-shaped API, the C-ABI surface, and the
+no-fallback rule.  No kernel is launched here."""
+import ctypes
+import os
+import pickle
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import ensure_red6, gjson
+
+import snekmer_amd as skm
+from snekmer_amd import _hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ensure_red6()
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "snekmer_hip.h")).read()
+    declared = set(re.findall(r"\b(skm_[a-z0-9_]+)\s*\(", header))
+    declared.discard("skm_ctx")
+    lib = _hip.load_library()
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(_hip.EXPORTED_SYMBOLS) == declared
+    assert lib.skm_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if _hip.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_hip.HipUnavailable):
+        skm.vectorize.KmerVec("hydro", 4).reduce_vectorize("MKVLAAGIW")
+    with pytest.raises(_hip.HipUnavailable):
+        skm.vectorize.reduce("MKVL", "hydro")
+    with pytest.raises(_hip.HipUnavailable):
+        skm.score.connection_matrix_from_features(np.eye(3), metric="cosine")
+
+
+def test_product_never_imports_the_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|oracle[./]", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "snekmer_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(text), f"{f} refers to oracle/"
+
+
+def test_kmerbasis_transform_matches_reference_fixture_and_errors():
+    g6 = gjson("g6_basis.json")
+    kb = skm.vectorize.KmerBasis()
+    kb.set_basis(g6["basis"])
+    out = kb.transform(np.asarray(g6["matrix"]), g6["vector_basis"])
+    assert out.tolist() == g6["out"]
+    errs = g6["errors"]
+    with pytest.raises(TypeError) as e:
+        skm.vectorize.KmerBasis().set_basis(5)
+    assert [type(e.value).__name__, str(e.value)] == errs["set_basis_type"]
+    with pytest.raises(TypeError) as e:
+        kb.transform(np.asarray(g6["matrix"]), 5)
+    assert [type(e.value).__name__, str(e.value)] == errs["vector_basis_type"]
+    with pytest.raises(ValueError) as e:
+        kb.transform(np.asarray(g6["matrix"]), g6["vector_basis"][:2])
+    assert [type(e.value).__name__, str(e.value)] == errs["shape_mismatch"]
+    with pytest.raises(IndexError):
+        kb.transform(np.asarray(g6["matrix"])[0], g6["vector_basis"])
+    assert errs["one_dim"][0] == "IndexError"
+    kv = skm.vectorize.KmerVec("hydro", 3)
+    kv.set_kmer_set(["SSS", "SSV", "VVV"])
+    assert kv.harmonize(np.array([[1.0, 2.0], [3.0, 4.0]]), ["VVV", "SVS"]).tolist() == g6["harmonize"]
+    assert sorted(kv.__dict__) == g6["kmervec_attrs"]
+    assert sorted(kv.kmer_set.__dict__) == g6["kmerset_attrs"]
+    assert list(kv.kmer_set.kmers) == g6["kmerset_kmers"]
+    kv2 = pickle.loads(pickle.dumps(kv))
+    assert kv2.char_set == kv.char_set and kv2.k == 3 and list(kv2.kmer_set.kmers) == g6["kmerset_kmers"]
+
+
+def test_kmerset_enumeration_and_alphabet_quirks():
+    ks = skm.vectorize.KmerSet("hydro", 3)
+    assert sorted(ks.kmers) == sorted("".join(p) for p in __import__("itertools").product("SV", repeat=3))
+    with pytest.raises(ValueError):
+        skm.alphabet.get_alphabet("RED0")
+    with pytest.raises(KeyError):
+        skm.alphabet.get_alphabet(6)
+    assert skm.alphabet.get_alphabet_keys(None) == set(skm.alphabet.StandardAlphabet)
+    assert skm.vectorize.KmerVec("red6", 8).char_set == set("ADFKNP")
+
+
+def test_lut_encode_decode_roundtrip_and_code_order():
+    lut = skm.alphabet.build_lut("standard")
+    rng = np.random.default_rng(0)
+    codes = np.sort(rng.integers(0, 7**12, size=500).astype(np.uint64))
+    strings = lut.decode(codes, 12)
+    assert list(strings) == sorted(strings)  # numeric order == lexicographic order
+    back, ok = lut.encode(list(strings), 12)
+    assert ok.all() and (back == codes).all()
+    _, ok = lut.encode(["AAAAAAAAAAAX", "AAA"], 12)
+    assert not ok.any()
+    assert lut.code_bits(8) == 32 and lut.code_bits(12) == 64
+    assert skm.alphabet.build_lut("red6").code_bits(12) == 32
+    with pytest.raises(ValueError):
+        skm.alphabet.build_lut(None).code_bits(15)
+
+
+def test_utils_contracts():
+    from helpers import gnpz
+
+    g = gnpz("g9_connection.npz")
+    X = g["X"]
+    np.testing.assert_array_equal(skm.utils.to_feature_matrix([list(r) for r in X], np.arange(1, 10)), g["tfm"])
+    np.testing.assert_array_equal(skm.utils.to_feature_matrix([list(r) for r in X]), g["tfm_default"])
+    assert skm.utils.check_list([1]) and skm.utils.check_list(np.zeros(2)) and not skm.utils.check_list(5)
+    data, off = skm.utils.pack_sequences(["MKV", "", "Ä€x"])
+    assert off.tolist() == [0, 3, 3, 6] and data[3] == 0xC4 and data[4] == skm.utils.SUBSTITUTE
+
+
+def test_synth_is_deterministic_and_shaped():
+    from snekmer_amd.synth import synth_families
+
+    a = synth_families(1000, 300, seed=5)
+    b = synth_families(1000, 300, seed=5)
+    assert all((x == y).all() for x, y in zip(a, b))
+    res, off, fam = a
+    lens = np.diff(off)
+    assert set(lens.tolist()) <= {300, 301} and (res[off[1:][lens == 301] - 1] == ord("*")).all()
+    assert len(set(fam.tolist())) == 10
