@@ -20,8 +20,25 @@
 //   - the epilogue converts the chunk to float32, scales by 1/|x_i| * 1/|y_j| and streams it out
 //     with 16-byte stores (each wave store instruction writes 1 KiB of one output row).
 //
+// That cursor kernel (k_cosine_strip) is correct for any density but pays one dependent memory
+// round trip per posting consumed, so it is now the FALLBACK.  The fast path splits the work:
+//
+//   k_gram_sparse   workgroup = 2 rows.  All (task, posting) pairs of the strip are flattened
+//                   (LDS prefix sum of posting-list lengths, binary search per pair), so every
+//                   posting is read exactly once with independent, coalesced loads; products go
+//                   into per-row LDS hash tables (4096 slots) keyed by the neighbour row j.  Each
+//                   row's entries are appended to a global neighbour list (j, exact int32 dot)
+//                   grouped by 1024-column output chunk (LDS counting sort).  Rows with > 2048
+//                   neighbours or strips with > 768 non-zeros are flagged for the cursor kernel.
+//   k_cosine_write  workgroup = 8 rows, pure streaming writer: per 1024-column chunk it drops the
+//                   few neighbour entries of the chunk into a zeroed LDS tile, scales to float32
+//                   and stores 16 B per lane (1 KiB per wave instruction).  Bound by HBM writes.
+//
 // The dense small-basis case (a true dense GEMM) is served by the i8 MFMA kernel in
 // skm_dense.hip instead.
+#include <cstdlib>
+#include <cstring>
+
 #include "skm_common.h"
 
 namespace {
@@ -33,7 +50,7 @@ constexpr int Q = 10;  // register-resident tasks per thread -> Q*TB = 2560 task
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE, bool VEC>
+template <int MODE, bool VEC, int ABL>
 __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__ xrowptr,
                                                      const uint32_t *__restrict__ xcolidx,
                                                      const uint32_t *__restrict__ xcounts,
@@ -42,13 +59,19 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
                                                      const uint32_t *__restrict__ yprow,
                                                      const uint32_t *__restrict__ ypval,
                                                      const float *__restrict__ yrnorm, int64_t row0, int64_t row1,
-                                                     float *__restrict__ out, int64_t ld)
+                                                     float *__restrict__ out, int64_t ld,
+                                                     const uint32_t *__restrict__ strip_list,
+                                                     const uint32_t *__restrict__ strip_count)
 {
     __shared__ __attribute__((aligned(16))) int s_acc[R][CH];
     __shared__ int64_t s_rp[R + 1];
     __shared__ float s_rni[R];
     const int tid = threadIdx.x;
-    const int64_t i0 = row0 + (int64_t)blockIdx.x * R;
+    // With a strip list the grid is sized for the worst case and surplus workgroups leave at once.
+    if (strip_list && blockIdx.x >= *strip_count)
+        return;
+    const int64_t strip = strip_list ? strip_list[blockIdx.x] : blockIdx.x;
+    const int64_t i0 = row0 + strip * R;
     const int rows = (int)min((int64_t)R, row1 - i0);
 
     if (tid <= R) {
@@ -70,7 +93,7 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
         const int64_t t = (int64_t)tid + (int64_t)q * TB;
         nj[q] = NONE;
         cur[q] = rem[q] = nv[q] = liv[q] = 0;
-        if (t < ntasks) {
+        if (ABL != 1 && t < ntasks) {
             const int64_t e = e0 + t;
             int li = 0;
 #pragma unroll
@@ -92,24 +115,39 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
     for (int64_t j0 = 0; j0 < m; j0 += CH) {
         const int64_t j1 = min(j0 + (int64_t)CH, m);
         const uint32_t j1u = (uint32_t)j1, j0u = (uint32_t)j0;
-        // ---- accumulate: advance every cursor through [j0, j1)
+        // ---- accumulate: advance every cursor through [j0, j1).  One pass handles at most one
+        // posting per task; the loads that fetch each task's next posting are all issued before
+        // any of them is waited for, so a pass costs one memory round trip, not Q of them.
+        bool more;
+        do {
+            uint32_t tj[Q], tv[Q];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            while (nj[q] < j1u) {
-                const int li = (int)(liv[q] >> 28);
-                const int v = (int)(liv[q] & 0x0FFFFFFFu);
-                atomicAdd(&s_acc[li][nj[q] - j0u], v * (int)nv[q]);
-                ++cur[q];
-                if (--rem[q]) {
-                    nj[q] = yprow[cur[q]];
-                    nv[q] = ypval[cur[q]];
-                } else {
-                    nj[q] = NONE;
+            for (int q = 0; q < Q; ++q) {
+                tj[q] = nj[q];
+                tv[q] = nv[q];
+                if (nj[q] < j1u) {
+                    const int li = (int)(liv[q] >> 28);
+                    const int v = (int)(liv[q] & 0x0FFFFFFFu);
+                    atomicAdd(&s_acc[li][nj[q] - j0u], v * (int)nv[q]);
+                    ++cur[q];
+                    --rem[q];
+                    tj[q] = NONE;
+                    if (rem[q]) {
+                        tj[q] = yprow[cur[q]];
+                        tv[q] = ypval[cur[q]];
+                    }
                 }
             }
-        }
+            more = false;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                nj[q] = tj[q];
+                nv[q] = tv[q];
+                more |= nj[q] < j1u;
+            }
+        } while (__any(more));
         // ---- strips with more than Q*TB non-zeros (very long sequences): stateless tasks
-        for (int64_t t = (int64_t)Q * TB + tid; t < ntasks; t += TB) {
+        for (int64_t t = (int64_t)Q * TB + tid; ABL != 1 && t < ntasks; t += TB) {
             const int64_t e = e0 + t;
             int li = 0;
 #pragma unroll
@@ -135,6 +173,355 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
         }
         __syncthreads();
         // ---- epilogue: scale, store, clear
+        const int64_t jc = j0 + 4 * tid;
+        float rj[4] = {0.f, 0.f, 0.f, 0.f};
+        if (VEC && jc + 3 < m) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(yrnorm + jc);
+            rj[0] = t4.x, rj[1] = t4.y, rj[2] = t4.z, rj[3] = t4.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (jc + u < m)
+                    rj[u] = yrnorm[jc + u];
+        }
+#pragma unroll
+        for (int li = 0; li < R; ++li) {
+            int4 a = *reinterpret_cast<int4 *>(&s_acc[li][4 * tid]);
+            *reinterpret_cast<int4 *>(&s_acc[li][4 * tid]) = make_int4(0, 0, 0, 0);
+            if (li < rows) {
+                const float ri = s_rni[li];
+                float o[4] = {(float)a.x * ri * rj[0], (float)a.y * ri * rj[1], (float)a.z * ri * rj[2],
+                              (float)a.w * ri * rj[3]};
+                const int64_t i = i0 + li;
+                if (MODE == 1) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float d = 1.0f - o[u];
+                        d = fminf(fmaxf(d, 0.0f), 2.0f);
+                        o[u] = (jc + u == i) ? 0.0f : d;
+                    }
+                }
+                float *dst = out + (i - row0) * ld + jc;
+                if (ABL == 2) {
+                    asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+                } else if (VEC && jc + 3 < m) {
+                    f32x4 pack = {o[0], o[1], o[2], o[3]};
+                    if (ABL == 3)
+                        *reinterpret_cast<f32x4 *>(dst) = pack;
+                    else
+                        __builtin_nontemporal_store(pack, reinterpret_cast<f32x4 *>(dst));
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (jc + u < m)
+                            dst[u] = o[u];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------- sparse Gram
+constexpr int GR = 2;          // rows per workgroup
+constexpr int GT = 512;
+constexpr int GQ = 2;          // tasks per thread -> GTCAP tasks per strip
+constexpr int GTCAP = GQ * GT;
+constexpr int GH = 4096;       // hash slots per row
+constexpr int GMAXD = GH / 2;  // distinct neighbours per row handled here
+constexpr int GNB = 1024;      // output chunks (of CH columns) a neighbour list can be grouped by
+constexpr uint32_t G_OVERFLOW = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ xrowptr,
+                                                    const uint32_t *__restrict__ xcolidx,
+                                                    const uint32_t *__restrict__ xcounts,
+                                                    const uint32_t *__restrict__ ycolptr,
+                                                    const uint32_t *__restrict__ yprow,
+                                                    const uint32_t *__restrict__ ypval, int64_t row0, int64_t row1,
+                                                    uint64_t *__restrict__ g_ent, unsigned long long cap_ent,
+                                                    unsigned long long *__restrict__ g_counter,
+                                                    uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len)
+{
+    // tasks (pair phase) and chunk histograms (emit phase) share one region
+    __shared__ uint32_t s_u[3 * GTCAP + 1 > GR * GNB ? 3 * GTCAP + 1 : GR * GNB];
+    __shared__ uint32_t hkeys[GR][GH];
+    __shared__ int hvals[GR][GH];
+    __shared__ int64_t s_rp[GR + 1];
+    __shared__ uint32_t s_wsum[GT / 64];
+    __shared__ uint32_t s_distinct[GR];
+    __shared__ unsigned long long s_off[GR];
+    __shared__ int s_over;
+    uint32_t *t_start = s_u, *t_scan = s_u + GTCAP, *t_liv = s_u + 2 * GTCAP + 1;
+    uint32_t *hist = s_u;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t i0 = row0 + (int64_t)blockIdx.x * GR;
+    const int rows = (int)min((int64_t)GR, row1 - i0);
+
+    if (tid <= GR)
+        s_rp[tid] = xrowptr[i0 + (tid <= rows ? tid : rows)];
+    if (tid < GR)
+        s_distinct[tid] = 0;
+    if (tid == 0)
+        s_over = 0;
+    for (int z = tid; z < GR * GH; z += GT) {
+        (&hkeys[0][0])[z] = 0u;
+        (&hvals[0][0])[z] = 0;
+    }
+    __syncthreads();
+    const int64_t e0 = s_rp[0];
+    const int64_t ntasks64 = s_rp[GR] - e0;
+    if (ntasks64 > GTCAP) {
+        if (tid < rows)
+            g_len[i0 - row0 + tid] = G_OVERFLOW;
+        return;
+    }
+    const int ntasks = (int)ntasks64;
+
+    // posting-list length of every task + exclusive prefix sum over the strip
+    uint32_t mydf[GQ];
+    uint32_t mysum = 0;
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) {
+        const int t = tid * GQ + q;
+        mydf[q] = 0;
+        if (t < ntasks) {
+            const int64_t e = e0 + t;
+            int li = 0;
+#pragma unroll
+            for (int r = 1; r < GR; ++r)
+                li += (e >= s_rp[r]) ? 1 : 0;
+            const uint32_t c = xcolidx[e];
+            const uint32_t pb = ycolptr[c], pe = ycolptr[c + 1];
+            t_start[t] = pb;
+            t_liv[t] = ((uint32_t)li << 28) | (xcounts[e] & 0x0FFFFFFFu);
+            mydf[q] = pe - pb;
+        }
+        mysum += mydf[q];
+    }
+    uint32_t incl = mysum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t up = __shfl_up(incl, o);
+        if (lane >= o)
+            incl += up;
+    }
+    if (lane == 63)
+        s_wsum[wid] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < GT / 64; ++q) {
+        wbase += q < wid ? s_wsum[q] : 0;
+        total += s_wsum[q];
+    }
+    uint32_t run = wbase + incl - mysum;
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) {
+        const int t = tid * GQ + q;
+        if (t < ntasks)
+            t_scan[t] = run;
+        run += mydf[q];
+    }
+    if (tid == 0)
+        t_scan[ntasks] = total;
+    __syncthreads();
+
+    // every (task, posting) pair once: independent coalesced loads, LDS hash accumulate.
+    // GU pairs per thread are in flight together (lock-step branch-free binary searches, then all
+    // posting loads, then the inserts) so that LDS and memory latencies overlap.
+    constexpr int GU = 4;
+    for (uint32_t g0 = tid; g0 < total; g0 += GT * GU) {
+        if (s_over)
+            break;
+        uint32_t gg[GU];
+        int lo[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            gg[u] = g0 + u * GT;
+            lo[u] = 0;
+        }
+#pragma unroll
+        for (int w = GTCAP / 2; w > 0; w >>= 1) {
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int cand = lo[u] + w;
+                if (cand < ntasks && t_scan[cand] <= gg[u])
+                    lo[u] = cand;
+            }
+        }
+        uint32_t jj[GU], ww[GU], lv[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            jj[u] = 0;
+            ww[u] = 0;
+            lv[u] = 0;
+            if (gg[u] < total) {
+                const uint32_t p = t_start[lo[u]] + (gg[u] - t_scan[lo[u]]);
+                jj[u] = yprow[p];
+                ww[u] = ypval[p];
+                lv[u] = t_liv[lo[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            if (gg[u] < total) {
+                const uint32_t j = jj[u];
+                const int prod = (int)(lv[u] & 0x0FFFFFFFu) * (int)ww[u];
+                const int li = (int)(lv[u] >> 28);
+                const uint32_t key = j + 1u;
+                uint32_t h = (j * 2654435761u) >> 20;
+                for (int probe = 0; probe < GH; ++probe) {
+                    const uint32_t old = atomicCAS(&hkeys[li][h], 0u, key);
+                    if (old == 0u && atomicAdd(&s_distinct[li], 1u) >= (uint32_t)GMAXD)
+                        s_over = 1;
+                    if (old == 0u || old == key) {
+                        atomicAdd(&hvals[li][h], prod);
+                        break;
+                    }
+                    h = (h + 1) & (GH - 1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (s_over) {
+        if (tid < rows)
+            g_len[i0 - row0 + tid] = G_OVERFLOW;
+        return;
+    }
+
+    // emit each row's neighbours grouped by output chunk (counting sort on j / CH); the order
+    // inside a group is unspecified and does not matter to the writer
+    for (int z = tid; z < GR * GNB; z += GT)
+        hist[z] = 0;
+    if (tid < GR) {
+        unsigned long long off = 0;
+        if (tid < rows)
+            off = atomicAdd(g_counter, (unsigned long long)s_distinct[tid]);
+        s_off[tid] = off;
+    }
+    __syncthreads();
+    for (int z = tid; z < GR * GH; z += GT) {
+        const uint32_t key = (&hkeys[0][0])[z];
+        if (key)
+            atomicAdd(&hist[(z / GH) * GNB + ((key - 1u) / CH)], 1u);
+    }
+    __syncthreads();
+    {   // exclusive scan of each row's GNB counters: wave w handles row w (GR <= waves)
+        if (wid < GR) {
+            uint32_t *hrow = hist + wid * GNB;
+            uint32_t carry = 0;
+            for (int base = 0; base < GNB; base += 64) {
+                const uint32_t x = hrow[base + lane];
+                uint32_t inc = x;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    uint32_t up = __shfl_up(inc, o);
+                    if (lane >= o)
+                        inc += up;
+                }
+                hrow[base + lane] = carry + inc - x;
+                carry += __shfl(inc, 63);
+            }
+        }
+    }
+    __syncthreads();
+    bool fits[GR];
+#pragma unroll
+    for (int r = 0; r < GR; ++r)
+        fits[r] = s_off[r] + (unsigned long long)s_distinct[r] <= cap_ent;
+    for (int z = tid; z < GR * GH; z += GT) {
+        const uint32_t key = (&hkeys[0][0])[z];
+        const int r = z / GH;
+        if (key && fits[r]) {
+            const uint32_t pos = atomicAdd(&hist[r * GNB + ((key - 1u) / CH)], 1u);
+            g_ent[s_off[r] + pos] = ((uint64_t)(key - 1u) << 32) | (uint32_t)(&hvals[0][0])[z];
+        }
+    }
+    if (tid < rows) {
+        g_start[i0 - row0 + tid] = s_off[tid];
+        g_len[i0 - row0 + tid] = fits[tid] ? s_distinct[tid] : G_OVERFLOW;
+    }
+}
+
+// ------------------------------------------------------------------------------- streaming writer
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(TB) void k_cosine_write(const uint64_t *__restrict__ g_ent,
+                                                     const uint64_t *__restrict__ g_start,
+                                                     const uint32_t *__restrict__ g_len,
+                                                     const float *__restrict__ xrnorm,
+                                                     const float *__restrict__ yrnorm, int64_t m, int64_t row0,
+                                                     int64_t row1, float *__restrict__ out, int64_t ld,
+                                                     uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_count)
+{
+    __shared__ __attribute__((aligned(16))) int s_acc[R][CH];
+    __shared__ uint64_t s_start[R];
+    __shared__ uint32_t s_len[R];
+    __shared__ float s_rni[R];
+    __shared__ int s_skip;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t i0 = row0 + (int64_t)blockIdx.x * R;
+    const int rows = (int)min((int64_t)R, row1 - i0);
+    if (tid == 0)
+        s_skip = 0;
+    __syncthreads();
+    if (tid < R) {
+        uint32_t len = 0;
+        uint64_t st = 0;
+        float rn = 0.0f;
+        if (tid < rows) {
+            len = g_len[i0 - row0 + tid];
+            st = g_start[i0 - row0 + tid];
+            rn = xrnorm[i0 + tid];
+            if (len == G_OVERFLOW)
+                s_skip = 1;
+        }
+        s_len[tid] = len;
+        s_start[tid] = st;
+        s_rni[tid] = rn;
+    }
+    for (int z = tid; z < R * CH / 4; z += TB)
+        reinterpret_cast<int4 *>(&s_acc[0][0])[z] = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    if (s_skip) {
+        // some row of this strip exceeded the sparse kernel's capacities: leave it to the cursor kernel
+        if (tid == 0)
+            fb_list[atomicAdd(fb_count, 1u)] = blockIdx.x;
+        return;
+    }
+
+    // each wave feeds two rows; it keeps a 64-entry window of the row's sorted neighbour list in
+    // registers and reloads only when the window is used up
+    const int lrow[2] = {wid, wid + 4};
+    uint32_t wbase[2] = {0, 0};
+    uint64_t went[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t e = wbase[u] + lane;
+        went[u] = e < s_len[lrow[u]] ? g_ent[s_start[lrow[u]] + e] : ~0ull;
+    }
+
+    for (int64_t j0 = 0; j0 < m; j0 += CH) {
+        const int64_t j1 = min(j0 + (int64_t)CH, m);
+        const uint32_t j1u = (uint32_t)j1, j0u = (uint32_t)j0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int li = lrow[u];
+            while (true) {
+                const uint32_t j = (uint32_t)(went[u] >> 32);
+                const bool take = went[u] != ~0ull && j >= j0u && j < j1u;
+                if (take)
+                    s_acc[li][j - j0u] = (int)(uint32_t)went[u];
+                // window exhausted within this chunk -> load the next 64 entries and continue
+                const bool last_taken = __shfl((int)take, 63) != 0;
+                if (!last_taken || wbase[u] + 64 >= s_len[li])
+                    break;
+                wbase[u] += 64;
+                const uint32_t e = wbase[u] + lane;
+                went[u] = e < s_len[li] ? g_ent[s_start[li] + e] : ~0ull;
+            }
+        }
+        __syncthreads();
         const int64_t jc = j0 + 4 * tid;
         float rj[4] = {0.f, 0.f, 0.f, 0.f};
         if (VEC && jc + 3 < m) {
@@ -196,25 +583,108 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         return SKM_OK;
     SKM_REQUIRE(d_xrowptr && d_xrnorm && d_ycolptr && d_yrnorm && d_out, SKM_E_BADARG, "skm_cosine_csr: null array");
     SKM_HIP(hipSetDevice(ctx->device));
-    const int64_t strips = skm_ceil_div(row1 - row0, R);
+    const int64_t nrows = row1 - row0;
+    const int64_t strips = skm_ceil_div(nrows, R);
     SKM_REQUIRE(strips < ((int64_t)1 << 31), SKM_E_OVERFLOW, "skm_cosine_csr: too many rows in one call");
     const bool vec = (ld % 4 == 0) && (((uintptr_t)d_out & 15) == 0) && (((uintptr_t)d_yrnorm & 15) == 0);
-    SKM_PROF(ctx, "k_cosine_strip");
-#define SKM_LAUNCH(MODE, VEC)                                                                                        \
-    k_cosine_strip<MODE, VEC><<<(unsigned)strips, TB, 0, ctx->stream>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, \
-                                                                         d_ycolptr, d_yprow, d_ypval, d_yrnorm, row0, \
-                                                                         row1, d_out, ld)
-    if (mode == 0) {
-        if (vec)
-            SKM_LAUNCH(0, true);
+    hipStream_t st = ctx->stream;
+
+#define SKM_LAUNCH_A(MODE, VEC, ABL, GRID, LIST, COUNT)                                                             \
+    k_cosine_strip<MODE, VEC, ABL><<<(unsigned)(GRID), TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m,   \
+                                                                     d_ycolptr, d_yprow, d_ypval, d_yrnorm, row0,   \
+                                                                     row1, d_out, ld, LIST, COUNT)
+    // Diagnostic builds of the cursor kernel (tools/ablate_cosine.py): results are NOT valid.
+    const char *abl_env = getenv("SKM_COSINE_ABLATE");
+    const int abl = abl_env ? atoi(abl_env) : 0;
+    if (abl >= 1 && abl <= 3 && mode == 0 && vec) {
+        SKM_PROF(ctx, "k_cosine_strip");
+        if (abl == 1)
+            SKM_LAUNCH_A(0, true, 1, strips, nullptr, nullptr);
+        else if (abl == 2)
+            SKM_LAUNCH_A(0, true, 2, strips, nullptr, nullptr);
         else
-            SKM_LAUNCH(0, false);
-    } else {
-        if (vec)
-            SKM_LAUNCH(1, true);
-        else
-            SKM_LAUNCH(1, false);
+            SKM_LAUNCH_A(0, true, 3, strips, nullptr, nullptr);
+        return skm_check_launch("k_cosine_strip");
     }
-#undef SKM_LAUNCH
+    const char *path_env = getenv("SKM_COSINE_PATH");  // "cursor" forces the fallback kernel everywhere
+    const bool cursor_only = (path_env && strcmp(path_env, "cursor") == 0) || skm_ceil_div(m, CH) > GNB;
+    if (cursor_only) {
+        SKM_PROF(ctx, "k_cosine_strip");
+        if (mode == 0) {
+            if (vec)
+                SKM_LAUNCH_A(0, true, 0, strips, nullptr, nullptr);
+            else
+                SKM_LAUNCH_A(0, false, 0, strips, nullptr, nullptr);
+        } else {
+            if (vec)
+                SKM_LAUNCH_A(1, true, 0, strips, nullptr, nullptr);
+            else
+                SKM_LAUNCH_A(1, false, 0, strips, nullptr, nullptr);
+        }
+        return skm_check_launch("k_cosine_strip");
+    }
+
+    // ---- fast path: sparse Gram -> streaming writer -> cursor kernel for flagged strips
+    int64_t *h_rp = (int64_t *)ctx->h_pinned;
+    SKM_HIP(hipMemcpyAsync(h_rp, d_xrowptr + row0, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    SKM_HIP(hipMemcpyAsync(h_rp + 1, d_xrowptr + row1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    SKM_HIP(hipStreamSynchronize(st));
+    const int64_t xnnz = h_rp[1] - h_rp[0];
+    const unsigned long long cap_ent = (unsigned long long)(8 * xnnz + (1 << 20));
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_A, sizeof(uint64_t) * (size_t)cap_ent, &p));
+    uint64_t *g_ent = (uint64_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_B, sizeof(uint64_t) * (size_t)(nrows + 8), &p));
+    uint64_t *g_start = (uint64_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_C, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
+    uint32_t *g_len = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)(strips + 8), &p));
+    uint32_t *fb_list = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
+    unsigned long long *g_counter = (unsigned long long *)((uint8_t *)p + 2048);
+    uint32_t *fb_count = (uint32_t *)((uint8_t *)p + 2048 + 8);
+    SKM_HIP(hipMemsetAsync(g_counter, 0, 16, st));
+    {
+        SKM_PROF(ctx, "k_gram_sparse");
+        k_gram_sparse<<<(unsigned)skm_ceil_div(nrows, GR), GT, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_yprow,
+                                                                         d_ypval, row0, row1, g_ent, cap_ent, g_counter,
+                                                                         g_start, g_len);
+    }
+    SKM_TRY(skm_check_launch("k_gram_sparse"));
+    {
+        SKM_PROF(ctx, "k_cosine_write");
+#define SKM_LAUNCH_W(MODE, VEC)                                                                                       \
+    k_cosine_write<MODE, VEC><<<(unsigned)strips, TB, 0, st>>>(g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, row1, \
+                                                                d_out, ld, fb_list, fb_count)
+        if (mode == 0) {
+            if (vec)
+                SKM_LAUNCH_W(0, true);
+            else
+                SKM_LAUNCH_W(0, false);
+        } else {
+            if (vec)
+                SKM_LAUNCH_W(1, true);
+            else
+                SKM_LAUNCH_W(1, false);
+        }
+#undef SKM_LAUNCH_W
+    }
+    SKM_TRY(skm_check_launch("k_cosine_write"));
+    {
+        // strips flagged by the two kernels above; the grid is the worst case, surplus workgroups exit at once
+        SKM_PROF(ctx, "k_cosine_strip");
+        if (mode == 0) {
+            if (vec)
+                SKM_LAUNCH_A(0, true, 0, strips, fb_list, fb_count);
+            else
+                SKM_LAUNCH_A(0, false, 0, strips, fb_list, fb_count);
+        } else {
+            if (vec)
+                SKM_LAUNCH_A(1, true, 0, strips, fb_list, fb_count);
+            else
+                SKM_LAUNCH_A(1, false, 0, strips, fb_list, fb_count);
+        }
+    }
+#undef SKM_LAUNCH_A
     return skm_check_launch("k_cosine_strip");
 }

@@ -17,6 +17,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "skm_common.h"
+#include "skm_wave_sort.h"
 
 namespace {
 
@@ -94,7 +95,21 @@ __global__ void k_classify(const uint8_t *__restrict__ seq, const int64_t *__res
             bucket = 5;
         else
             bucket = 6;
-        uint32_t slot = atomicAdd(&bucket_fill[bucket], 1u);
+        // one atomic per (wave, bucket) instead of one per sequence
+        const int lane = threadIdx.x & 63;
+        uint32_t slot = 0;
+        for (int bk = 0; bk < NBUCKET; ++bk) {
+            unsigned long long mask = __ballot(bucket == bk);
+            if (!mask)
+                continue;
+            uint32_t base = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if (lane == leader)
+                base = atomicAdd(&bucket_fill[bk], (uint32_t)__popcll(mask));
+            base = __shfl(base, leader);
+            if (bucket == bk)
+                slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        }
         lists[(int64_t)bucket * n + slot] = (uint32_t)i;
     }
 }
@@ -138,68 +153,6 @@ __global__ __launch_bounds__(64) void k_kmer_codes(skm_lut256 lut, int nsym, int
             int wt = min(TILE, w - t0);
             for (int p = lane; p < wt; p += 64)
                 codes[b + t0 + p] = window_code<K>(s_rank, p, k, nsym);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------- register bitonic
-template <typename K>
-__device__ __forceinline__ K shfl_xor_k(K v, int m)
-{
-    if constexpr (sizeof(K) == 8) {
-        uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-        lo = __shfl_xor(lo, m);
-        hi = __shfl_xor(hi, m);
-        return ((K)hi << 32) | lo;
-    } else {
-        return (K)__shfl_xor((uint32_t)v, m);
-    }
-}
-
-template <typename K>
-__device__ __forceinline__ K shfl_idx_k(K v, int src)
-{
-    if constexpr (sizeof(K) == 8) {
-        uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-        lo = __shfl(lo, src);
-        hi = __shfl(hi, src);
-        return ((K)hi << 32) | lo;
-    } else {
-        return (K)__shfl((uint32_t)v, src);
-    }
-}
-
-// Sort 512 keys laid out as element e = r*64 + lane, ascending in e.
-template <typename K>
-__device__ __forceinline__ void wave_bitonic_512(K (&v)[8], int lane)
-{
-#pragma unroll
-    for (int size = 2; size <= 512; size <<= 1) {
-#pragma unroll
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            if (stride >= 64) {
-                const int rs = stride >> 6;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    if ((r & rs) == 0) {
-                        const bool asc = ((r << 6) & size) == 0;  // size >= 128 here: depends on r only
-                        K a = v[r], b = v[r | rs];
-                        bool sw = asc ? (a > b) : (a < b);
-                        v[r] = sw ? b : a;
-                        v[r | rs] = sw ? a : b;
-                    }
-                }
-            } else {
-                const bool lower = (lane & stride) == 0;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const bool asc = size >= 64 ? (((r << 6) & size) == 0) : ((lane & size) == 0);
-                    K other = shfl_xor_k<K>(v[r], stride);
-                    K mn = v[r] < other ? v[r] : other;
-                    K mx = v[r] < other ? other : v[r];
-                    v[r] = (lower == asc) ? mn : mx;
-                }
-            }
         }
     }
 }

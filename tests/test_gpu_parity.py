@@ -258,6 +258,13 @@ def test_cosine_medium_vs_oracle_all_modes(ctx):
     # row-block call (what one rank computes) equals the corresponding rows
     blk = pipe.cosine(row0=501, row1=1203).download().reshape(pipe.out.shape)[: 1203 - 501, :n]
     assert (blk == S[501:1203]).all()
+    # the cursor (fallback) kernel alone gives the same bits as sparse-Gram + writer (+ fallback strips)
+    os.environ["SKM_COSINE_PATH"] = "cursor"
+    try:
+        S_cur = pipe.cosine().download().reshape(pipe.out.shape)[:n, :n]
+    finally:
+        del os.environ["SKM_COSINE_PATH"]
+    assert (S_cur == S).all()
     # distance mode
     b = pipe.basis
     D = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, b.ncols, b.colptr, b.prow, b.pval, pipe.rnorm, mode=1,

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Diagnostic: time k_cosine_strip variants in one process (interleaved rounds).
+SKM_COSINE_ABLATE: 0 real kernel, 1 no accumulate, 2 no global stores, 3 plain (not nt) stores."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from snekmer_amd import _hip, alphabet, engine
+from snekmer_amd.synth import BASE_SEED, synth_families
+
+alphabet.register_alphabet("red6", alphabet.RED6_GROUPS)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+ctx = _hip.Context(0)
+lut = alphabet.build_lut("red6")
+res, off, _ = synth_families(n, 300, family=100, seed=BASE_SEED + 2)
+batch = engine.SeqBatch(ctx, res, off)
+pipe = engine.Pipeline(ctx, lut, 12)
+pipe.step(batch)
+ctx.sync()
+ctx.profile_enable(True)
+results = {}
+for rnd in range(4):
+    for abl in (0, 1, 2, 3):
+        os.environ["SKM_COSINE_ABLATE"] = str(abl)
+        ctx.profile_reset()
+        pipe.cosine()
+        cnt, ms = ctx.profile_read("k_cosine_strip")
+        results.setdefault(abl, []).append(ms)
+os.environ["SKM_COSINE_ABLATE"] = "0"
+for abl, v in results.items():
+    print(f"ABL={abl}: min {min(v):.3f} ms  median {sorted(v)[len(v)//2]:.3f} ms  all {['%.2f' % x for x in v]}")
