@@ -118,19 +118,19 @@ int skm_count_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code
  *   d_total[B]        total occurrences (what `min_filter` tests, kmerize.smk:96-104)
  *   d_firstkey[B]     (row << 32 | first window); ascending order == the reference's first-seen order
  *   d_fs_order[B]     basis columns listed in first-seen order (needs d_firstpos)
- *   d_colptr[nnz+1], d_prow[nnz], d_pval[nnz]   the same matrix column-major (postings: for each
- *                     basis column the rows holding it, ascending, and their counts);
+ *   d_colptr[nnz+1], d_post[nnz]   the same matrix column-major (postings: for each basis column
+ *                     the rows holding it, ascending; entry = row | (uint64)count << 32);
  *                     only d_colptr[0..B] is meaningful. */
 int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int64_t n, int64_t nnz, const int64_t *d_rowptr,
                     const void *d_codes, const uint32_t *d_counts, const uint32_t *d_firstpos,
                     int64_t *h_ncols, void *d_basis, uint32_t *d_colidx, uint32_t *d_df,
                     uint64_t *d_total, uint64_t *d_firstkey, uint32_t *d_fs_order,
-                    uint32_t *d_colptr, uint32_t *d_prow, uint32_t *d_pval);
+                    uint32_t *d_colptr, uint64_t *d_post);
 
 /* Column-major copy (postings) of any CSR with column ids < ncols; rows ascending per column. */
 int skm_csr_transpose(skm_ctx *ctx, int64_t n, int64_t nnz, int64_t ncols, const int64_t *d_rowptr,
                       const uint32_t *d_colidx, const uint32_t *d_counts, uint32_t *d_colptr,
-                      uint32_t *d_prow, uint32_t *d_pval);
+                      uint64_t *d_post);
 
 /* Row pointers of `nparts` CSR pieces laid end to end: d_local holds the pieces' own rowptr arrays
  * back to back (piece p has h_nrows[p]+1 entries starting at 0); d_rowptr receives the
@@ -164,7 +164,7 @@ int skm_row_norms_csr(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const ui
  * (1 - s clipped to [0,2]; exact 0 where i == j, square case only). */
 int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
                    const uint32_t *d_xcounts, const float *d_xrnorm, int64_t m, int64_t ncols,
-                   const uint32_t *d_ycolptr, const uint32_t *d_yprow, const uint32_t *d_ypval,
+                   const uint32_t *d_ycolptr, const uint64_t *d_ypost,
                    const float *d_yrnorm, int64_t row0, int64_t row1, int mode, float *d_out,
                    int64_t ld);
 

@@ -61,15 +61,15 @@ _SIGNATURES = {
     ),
     "skm_basis_build": (
         C.c_int,
-        [_p, C.c_int, C.c_int, _i64, _i64, _p, _p, _p, _p, C.POINTER(_i64), _p, _p, _p, _p, _p, _p, _p, _p, _p],
+        [_p, C.c_int, C.c_int, _i64, _i64, _p, _p, _p, _p, C.POINTER(_i64), _p, _p, _p, _p, _p, _p, _p, _p],
     ),
-    "skm_csr_transpose": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p]),
+    "skm_csr_transpose": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p]),
     "skm_csr_concat_rowptr": (C.c_int, [_p, C.c_int, _p, _p, _p, _p]),
     "skm_csr_to_dense": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, C.c_int, C.c_int, _p, _i64]),
     "skm_row_norms_csr": (C.c_int, [_p, _i64, _p, _p, _p, _p]),
     "skm_cosine_csr": (
         C.c_int,
-        [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i64, C.c_int, _p, _i64],
+        [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, C.c_int, _p, _i64],
     ),
     "skm_pair_work": (C.c_int, [_p, _i64, _p, C.POINTER(C.c_uint64)]),
     "skm_count_dense": (C.c_int, [_p, _p, C.c_int, C.c_int, _p, _p, _i64, C.c_int, _p, _i64]),

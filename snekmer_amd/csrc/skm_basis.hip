@@ -60,8 +60,8 @@ __global__ __launch_bounds__(BLK) void k_basis_scatter(int64_t nnz, const K *__r
                                                        const uint32_t *__restrict__ counts,
                                                        const uint32_t *__restrict__ firstpos,
                                                        K *__restrict__ basis, uint32_t *__restrict__ colidx,
-                                                       uint32_t *__restrict__ colptr, uint32_t *__restrict__ prow,
-                                                       uint32_t *__restrict__ pval, uint64_t *__restrict__ firstkey)
+                                                       uint32_t *__restrict__ colptr, uint64_t *__restrict__ post,
+                                                       uint64_t *__restrict__ firstkey)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -72,12 +72,10 @@ __global__ __launch_bounds__(BLK) void k_basis_scatter(int64_t nnz, const K *__r
         const bool head = t == 0 || skeys[t - 1] != key;
         colidx[e] = c;
         uint32_t row = 0;
-        if (prow || (head && firstkey))
+        if (post || (head && firstkey))
             row = rowid[e];
-        if (prow) {
-            prow[t] = row;
-            pval[t] = counts[e];
-        }
+        if (post)
+            post[t] = (uint64_t)row | ((uint64_t)counts[e] << 32);
         if (head) {
             if (basis)
                 basis[c] = key;
@@ -89,7 +87,7 @@ __global__ __launch_bounds__(BLK) void k_basis_scatter(int64_t nnz, const K *__r
     }
 }
 
-__global__ void k_col_stats(int64_t ncols, const uint32_t *__restrict__ colptr, const uint32_t *__restrict__ pval,
+__global__ void k_col_stats(int64_t ncols, const uint32_t *__restrict__ colptr, const uint64_t *__restrict__ post,
                             uint32_t *__restrict__ df, uint64_t *__restrict__ total)
 {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -101,7 +99,7 @@ __global__ void k_col_stats(int64_t ncols, const uint32_t *__restrict__ colptr, 
     if (total) {
         uint64_t s = 0;
         for (uint32_t t = b; t < e; ++t)
-            s += pval[t];
+            s += post[t] >> 32;
         total[c] = s;
     }
 }
@@ -140,14 +138,13 @@ __global__ void k_colptr_search(int64_t ncols, int64_t nnz, const uint32_t *__re
 
 __global__ void k_gather_postings(int64_t nnz, const uint32_t *__restrict__ sidx,
                                   const uint32_t *__restrict__ rowid, const uint32_t *__restrict__ counts,
-                                  uint32_t *__restrict__ prow, uint32_t *__restrict__ pval)
+                                  uint64_t *__restrict__ post)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; t < nnz; t += stride) {
         uint32_t e = sidx[t];
-        prow[t] = rowid[e];
-        pval[t] = counts[e];
+        post[t] = (uint64_t)rowid[e] | ((uint64_t)counts[e] << 32);
     }
 }
 
@@ -233,7 +230,7 @@ template <typename K>
 int basis_impl(skm_ctx *ctx, int key_bits, int64_t n, int64_t nnz, const int64_t *d_rowptr, const K *d_codes,
                const uint32_t *d_counts, const uint32_t *d_firstpos, int64_t *h_ncols, K *d_basis, uint32_t *d_colidx,
                uint32_t *d_df, uint64_t *d_total, uint64_t *d_firstkey, uint32_t *d_fs_order, uint32_t *d_colptr,
-               uint32_t *d_prow, uint32_t *d_pval)
+               uint64_t *d_post)
 {
     hipStream_t st = ctx->stream;
     void *p;
@@ -250,20 +247,15 @@ int basis_impl(skm_ctx *ctx, int key_bits, int64_t n, int64_t nnz, const int64_t
 
     const bool need_stats = d_df || d_total;
     const bool need_fs = d_fs_order != nullptr;
-    uint32_t *colptr = d_colptr, *prow = d_prow, *pval = d_pval;
+    uint32_t *colptr = d_colptr;
+    uint64_t *post = d_post;
     if (need_stats && !colptr) {
         SKM_TRY(skm_ws(ctx, WS_F, sizeof(uint32_t) * (size_t)(nnz + 1), &p));
         colptr = (uint32_t *)p;
     }
-    if ((need_stats && d_total && !pval) || (prow && !pval) || (pval && !prow)) {
-        if (!prow) {
-            SKM_TRY(skm_ws(ctx, WS_G, sizeof(uint32_t) * (size_t)nnz, &p));
-            prow = (uint32_t *)p;
-        }
-        if (!pval) {
-            SKM_TRY(skm_ws(ctx, WS_H, sizeof(uint32_t) * (size_t)nnz, &p));
-            pval = (uint32_t *)p;
-        }
+    if (need_stats && d_total && !post) {
+        SKM_TRY(skm_ws(ctx, WS_G, sizeof(uint64_t) * (size_t)nnz, &p));
+        post = (uint64_t *)p;
     }
     uint64_t *firstkey = d_firstkey;
     if (need_fs && !firstkey) {
@@ -293,7 +285,7 @@ int basis_impl(skm_ctx *ctx, int key_bits, int64_t n, int64_t nnz, const int64_t
     {
         SKM_PROF(ctx, "k_basis_scatter");
         k_basis_scatter<K><<<g_ent, BLK, 0, st>>>(nnz, skeys, sidx, colid1, rowid, d_counts, d_firstpos, d_basis,
-                                                   d_colidx, colptr, prow, pval, firstkey);
+                                                   d_colidx, colptr, post, firstkey);
     }
     SKM_TRY(skm_check_launch("k_basis_scatter"));
     uint32_t *h_b = (uint32_t *)ctx->h_pinned;
@@ -306,7 +298,7 @@ int basis_impl(skm_ctx *ctx, int key_bits, int64_t n, int64_t nnz, const int64_t
     }
     if (need_stats) {
         SKM_PROF(ctx, "k_col_stats");
-        k_col_stats<<<(unsigned)skm_ceil_div(B, BLK), BLK, 0, st>>>(B, colptr, pval, d_df, d_total);
+        k_col_stats<<<(unsigned)skm_ceil_div(B, BLK), BLK, 0, st>>>(B, colptr, post, d_df, d_total);
         SKM_TRY(skm_check_launch("k_col_stats"));
     }
     if (need_fs) {
@@ -325,7 +317,7 @@ extern "C" int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int64_
                                const int64_t *d_rowptr, const void *d_codes, const uint32_t *d_counts,
                                const uint32_t *d_firstpos, int64_t *h_ncols, void *d_basis, uint32_t *d_colidx,
                                uint32_t *d_df, uint64_t *d_total, uint64_t *d_firstkey, uint32_t *d_fs_order,
-                               uint32_t *d_colptr, uint32_t *d_prow, uint32_t *d_pval)
+                               uint32_t *d_colptr, uint64_t *d_post)
 {
     SKM_REQUIRE(ctx && h_ncols && n >= 0 && nnz >= 0, SKM_E_BADARG, "skm_basis_build: bad argument");
     SKM_REQUIRE(code_bits == 32 || code_bits == 64, SKM_E_BADARG, "skm_basis_build: code_bits must be 32 or 64");
@@ -344,15 +336,15 @@ extern "C" int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int64_
     if (code_bits == 32)
         return basis_impl<uint32_t>(ctx, key_bits, n, nnz, d_rowptr, (const uint32_t *)d_codes, d_counts, d_firstpos,
                                     h_ncols, (uint32_t *)d_basis, d_colidx, d_df, d_total, d_firstkey, d_fs_order,
-                                    d_colptr, d_prow, d_pval);
+                                    d_colptr, d_post);
     return basis_impl<uint64_t>(ctx, key_bits, n, nnz, d_rowptr, (const uint64_t *)d_codes, d_counts, d_firstpos,
                                 h_ncols, (uint64_t *)d_basis, d_colidx, d_df, d_total, d_firstkey, d_fs_order, d_colptr,
-                                d_prow, d_pval);
+                                d_post);
 }
 
 extern "C" int skm_csr_transpose(skm_ctx *ctx, int64_t n, int64_t nnz, int64_t ncols, const int64_t *d_rowptr,
                                  const uint32_t *d_colidx, const uint32_t *d_counts, uint32_t *d_colptr,
-                                 uint32_t *d_prow, uint32_t *d_pval)
+                                 uint64_t *d_post)
 {
     SKM_REQUIRE(ctx && d_colptr && n >= 0 && nnz >= 0 && ncols >= 0, SKM_E_BADARG, "skm_csr_transpose: bad argument");
     SKM_REQUIRE(nnz < ((int64_t)1 << 32) - 1 && ncols < ((int64_t)1 << 32) - 1, SKM_E_OVERFLOW,
@@ -363,7 +355,7 @@ extern "C" int skm_csr_transpose(skm_ctx *ctx, int64_t n, int64_t nnz, int64_t n
         SKM_HIP(hipMemsetAsync(d_colptr, 0, sizeof(uint32_t) * (size_t)(ncols + 1), st));
         return SKM_OK;
     }
-    SKM_REQUIRE(d_rowptr && d_colidx && d_counts && d_prow && d_pval, SKM_E_BADARG, "skm_csr_transpose: null array");
+    SKM_REQUIRE(d_rowptr && d_colidx && d_counts && d_post, SKM_E_BADARG, "skm_csr_transpose: null array");
     void *p;
     SKM_TRY(skm_ws(ctx, WS_A, sizeof(uint32_t) * (size_t)nnz, &p));
     uint32_t *skeys = (uint32_t *)p;
@@ -386,7 +378,7 @@ extern "C" int skm_csr_transpose(skm_ctx *ctx, int64_t n, int64_t nnz, int64_t n
     }
     {
         SKM_PROF(ctx, "k_gather_postings");
-        k_gather_postings<<<g_ent, BLK, 0, st>>>(nnz, sidx, rowid, d_counts, d_prow, d_pval);
+        k_gather_postings<<<g_ent, BLK, 0, st>>>(nnz, sidx, rowid, d_counts, d_post);
     }
     return skm_check_launch("k_gather_postings");
 }

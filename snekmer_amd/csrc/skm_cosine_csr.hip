@@ -56,8 +56,7 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
                                                      const uint32_t *__restrict__ xcounts,
                                                      const float *__restrict__ xrnorm, int64_t m,
                                                      const uint32_t *__restrict__ ycolptr,
-                                                     const uint32_t *__restrict__ yprow,
-                                                     const uint32_t *__restrict__ ypval,
+                                                     const uint64_t *__restrict__ ypost,
                                                      const float *__restrict__ yrnorm, int64_t row0, int64_t row1,
                                                      float *__restrict__ out, int64_t ld,
                                                      const uint32_t *__restrict__ strip_list,
@@ -106,8 +105,9 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
             rem[q] = pe - pb;
             liv[q] = ((uint32_t)li << 28) | (v & 0x0FFFFFFFu);
             if (pe > pb) {
-                nj[q] = yprow[pb];
-                nv[q] = ypval[pb];
+                const uint64_t pw = ypost[pb];
+                nj[q] = (uint32_t)pw;
+                nv[q] = (uint32_t)(pw >> 32);
             }
         }
     }
@@ -133,8 +133,9 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
                     --rem[q];
                     tj[q] = NONE;
                     if (rem[q]) {
-                        tj[q] = yprow[cur[q]];
-                        tv[q] = ypval[cur[q]];
+                        const uint64_t pw = ypost[cur[q]];
+                        tj[q] = (uint32_t)pw;
+                        tv[q] = (uint32_t)(pw >> 32);
                     }
                 }
             }
@@ -159,16 +160,17 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
             const uint32_t pe = hi;
             while (lo < hi) {
                 uint32_t mid = lo + ((hi - lo) >> 1);
-                if (yprow[mid] < j0u)
+                if ((uint32_t)ypost[mid] < j0u)
                     lo = mid + 1;
                 else
                     hi = mid;
             }
             for (; lo < pe; ++lo) {
-                const uint32_t j = yprow[lo];
+                const uint64_t pw = ypost[lo];
+                const uint32_t j = (uint32_t)pw;
                 if (j >= j1u)
                     break;
-                atomicAdd(&s_acc[li][j - j0u], v * (int)ypval[lo]);
+                atomicAdd(&s_acc[li][j - j0u], v * (int)(uint32_t)(pw >> 32));
             }
         }
         __syncthreads();
@@ -223,226 +225,7 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
 }
 
 // ------------------------------------------------------------------------------- sparse Gram
-constexpr int GR = 2;          // rows per workgroup
-constexpr int GT = 512;
-constexpr int GQ = 2;          // tasks per thread -> GTCAP tasks per strip
-constexpr int GTCAP = GQ * GT;
-constexpr int GH = 4096;       // hash slots per row
-constexpr int GMAXD = GH / 2;  // distinct neighbours per row handled here
-constexpr int GNB = 1024;      // output chunks (of CH columns) a neighbour list can be grouped by
-constexpr uint32_t G_OVERFLOW = 0xFFFFFFFFu;
-
-__global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ xrowptr,
-                                                    const uint32_t *__restrict__ xcolidx,
-                                                    const uint32_t *__restrict__ xcounts,
-                                                    const uint32_t *__restrict__ ycolptr,
-                                                    const uint32_t *__restrict__ yprow,
-                                                    const uint32_t *__restrict__ ypval, int64_t row0, int64_t row1,
-                                                    uint64_t *__restrict__ g_ent, unsigned long long cap_ent,
-                                                    unsigned long long *__restrict__ g_counter,
-                                                    uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len)
-{
-    // tasks (pair phase) and chunk histograms (emit phase) share one region
-    __shared__ uint32_t s_u[3 * GTCAP + 1 > GR * GNB ? 3 * GTCAP + 1 : GR * GNB];
-    __shared__ uint32_t hkeys[GR][GH];
-    __shared__ int hvals[GR][GH];
-    __shared__ int64_t s_rp[GR + 1];
-    __shared__ uint32_t s_wsum[GT / 64];
-    __shared__ uint32_t s_distinct[GR];
-    __shared__ unsigned long long s_off[GR];
-    __shared__ int s_over;
-    uint32_t *t_start = s_u, *t_scan = s_u + GTCAP, *t_liv = s_u + 2 * GTCAP + 1;
-    uint32_t *hist = s_u;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int64_t i0 = row0 + (int64_t)blockIdx.x * GR;
-    const int rows = (int)min((int64_t)GR, row1 - i0);
-
-    if (tid <= GR)
-        s_rp[tid] = xrowptr[i0 + (tid <= rows ? tid : rows)];
-    if (tid < GR)
-        s_distinct[tid] = 0;
-    if (tid == 0)
-        s_over = 0;
-    for (int z = tid; z < GR * GH; z += GT) {
-        (&hkeys[0][0])[z] = 0u;
-        (&hvals[0][0])[z] = 0;
-    }
-    __syncthreads();
-    const int64_t e0 = s_rp[0];
-    const int64_t ntasks64 = s_rp[GR] - e0;
-    if (ntasks64 > GTCAP) {
-        if (tid < rows)
-            g_len[i0 - row0 + tid] = G_OVERFLOW;
-        return;
-    }
-    const int ntasks = (int)ntasks64;
-
-    // posting-list length of every task + exclusive prefix sum over the strip
-    uint32_t mydf[GQ];
-    uint32_t mysum = 0;
-#pragma unroll
-    for (int q = 0; q < GQ; ++q) {
-        const int t = tid * GQ + q;
-        mydf[q] = 0;
-        if (t < ntasks) {
-            const int64_t e = e0 + t;
-            int li = 0;
-#pragma unroll
-            for (int r = 1; r < GR; ++r)
-                li += (e >= s_rp[r]) ? 1 : 0;
-            const uint32_t c = xcolidx[e];
-            const uint32_t pb = ycolptr[c], pe = ycolptr[c + 1];
-            t_start[t] = pb;
-            t_liv[t] = ((uint32_t)li << 28) | (xcounts[e] & 0x0FFFFFFFu);
-            mydf[q] = pe - pb;
-        }
-        mysum += mydf[q];
-    }
-    uint32_t incl = mysum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t up = __shfl_up(incl, o);
-        if (lane >= o)
-            incl += up;
-    }
-    if (lane == 63)
-        s_wsum[wid] = incl;
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-#pragma unroll
-    for (int q = 0; q < GT / 64; ++q) {
-        wbase += q < wid ? s_wsum[q] : 0;
-        total += s_wsum[q];
-    }
-    uint32_t run = wbase + incl - mysum;
-#pragma unroll
-    for (int q = 0; q < GQ; ++q) {
-        const int t = tid * GQ + q;
-        if (t < ntasks)
-            t_scan[t] = run;
-        run += mydf[q];
-    }
-    if (tid == 0)
-        t_scan[ntasks] = total;
-    __syncthreads();
-
-    // every (task, posting) pair once: independent coalesced loads, LDS hash accumulate.
-    // GU pairs per thread are in flight together (lock-step branch-free binary searches, then all
-    // posting loads, then the inserts) so that LDS and memory latencies overlap.
-    constexpr int GU = 4;
-    for (uint32_t g0 = tid; g0 < total; g0 += GT * GU) {
-        if (s_over)
-            break;
-        uint32_t gg[GU];
-        int lo[GU];
-#pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            gg[u] = g0 + u * GT;
-            lo[u] = 0;
-        }
-#pragma unroll
-        for (int w = GTCAP / 2; w > 0; w >>= 1) {
-#pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int cand = lo[u] + w;
-                if (cand < ntasks && t_scan[cand] <= gg[u])
-                    lo[u] = cand;
-            }
-        }
-        uint32_t jj[GU], ww[GU], lv[GU];
-#pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            jj[u] = 0;
-            ww[u] = 0;
-            lv[u] = 0;
-            if (gg[u] < total) {
-                const uint32_t p = t_start[lo[u]] + (gg[u] - t_scan[lo[u]]);
-                jj[u] = yprow[p];
-                ww[u] = ypval[p];
-                lv[u] = t_liv[lo[u]];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            if (gg[u] < total) {
-                const uint32_t j = jj[u];
-                const int prod = (int)(lv[u] & 0x0FFFFFFFu) * (int)ww[u];
-                const int li = (int)(lv[u] >> 28);
-                const uint32_t key = j + 1u;
-                uint32_t h = (j * 2654435761u) >> 20;
-                for (int probe = 0; probe < GH; ++probe) {
-                    const uint32_t old = atomicCAS(&hkeys[li][h], 0u, key);
-                    if (old == 0u && atomicAdd(&s_distinct[li], 1u) >= (uint32_t)GMAXD)
-                        s_over = 1;
-                    if (old == 0u || old == key) {
-                        atomicAdd(&hvals[li][h], prod);
-                        break;
-                    }
-                    h = (h + 1) & (GH - 1);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (s_over) {
-        if (tid < rows)
-            g_len[i0 - row0 + tid] = G_OVERFLOW;
-        return;
-    }
-
-    // emit each row's neighbours grouped by output chunk (counting sort on j / CH); the order
-    // inside a group is unspecified and does not matter to the writer
-    for (int z = tid; z < GR * GNB; z += GT)
-        hist[z] = 0;
-    if (tid < GR) {
-        unsigned long long off = 0;
-        if (tid < rows)
-            off = atomicAdd(g_counter, (unsigned long long)s_distinct[tid]);
-        s_off[tid] = off;
-    }
-    __syncthreads();
-    for (int z = tid; z < GR * GH; z += GT) {
-        const uint32_t key = (&hkeys[0][0])[z];
-        if (key)
-            atomicAdd(&hist[(z / GH) * GNB + ((key - 1u) / CH)], 1u);
-    }
-    __syncthreads();
-    {   // exclusive scan of each row's GNB counters: wave w handles row w (GR <= waves)
-        if (wid < GR) {
-            uint32_t *hrow = hist + wid * GNB;
-            uint32_t carry = 0;
-            for (int base = 0; base < GNB; base += 64) {
-                const uint32_t x = hrow[base + lane];
-                uint32_t inc = x;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    uint32_t up = __shfl_up(inc, o);
-                    if (lane >= o)
-                        inc += up;
-                }
-                hrow[base + lane] = carry + inc - x;
-                carry += __shfl(inc, 63);
-            }
-        }
-    }
-    __syncthreads();
-    bool fits[GR];
-#pragma unroll
-    for (int r = 0; r < GR; ++r)
-        fits[r] = s_off[r] + (unsigned long long)s_distinct[r] <= cap_ent;
-    for (int z = tid; z < GR * GH; z += GT) {
-        const uint32_t key = (&hkeys[0][0])[z];
-        const int r = z / GH;
-        if (key && fits[r]) {
-            const uint32_t pos = atomicAdd(&hist[r * GNB + ((key - 1u) / CH)], 1u);
-            g_ent[s_off[r] + pos] = ((uint64_t)(key - 1u) << 32) | (uint32_t)(&hvals[0][0])[z];
-        }
-    }
-    if (tid < rows) {
-        g_start[i0 - row0 + tid] = s_off[tid];
-        g_len[i0 - row0 + tid] = fits[tid] ? s_distinct[tid] : G_OVERFLOW;
-    }
-}
+#include "skm_gram_kernel.h"
 
 // ------------------------------------------------------------------------------- streaming writer
 template <int MODE, bool VEC>
@@ -570,7 +353,7 @@ __global__ __launch_bounds__(TB) void k_cosine_write(const uint64_t *__restrict_
 
 extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
                               const uint32_t *d_xcounts, const float *d_xrnorm, int64_t m, int64_t ncols,
-                              const uint32_t *d_ycolptr, const uint32_t *d_yprow, const uint32_t *d_ypval,
+                              const uint32_t *d_ycolptr, const uint64_t *d_ypost,
                               const float *d_yrnorm, int64_t row0, int64_t row1, int mode, float *d_out, int64_t ld)
 {
     SKM_REQUIRE(ctx && n >= 0 && m >= 0 && ncols >= 0, SKM_E_BADARG, "skm_cosine_csr: bad argument");
@@ -591,7 +374,7 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
 
 #define SKM_LAUNCH_A(MODE, VEC, ABL, GRID, LIST, COUNT)                                                             \
     k_cosine_strip<MODE, VEC, ABL><<<(unsigned)(GRID), TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m,   \
-                                                                     d_ycolptr, d_yprow, d_ypval, d_yrnorm, row0,   \
+                                                                     d_ycolptr, d_ypost, d_yrnorm, row0,            \
                                                                      row1, d_out, ld, LIST, COUNT)
     // Diagnostic builds of the cursor kernel (tools/ablate_cosine.py): results are NOT valid.
     const char *abl_env = getenv("SKM_COSINE_ABLATE");
@@ -646,9 +429,34 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     SKM_HIP(hipMemsetAsync(g_counter, 0, 16, st));
     {
         SKM_PROF(ctx, "k_gram_sparse");
-        k_gram_sparse<<<(unsigned)skm_ceil_div(nrows, GR), GT, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_yprow,
-                                                                         d_ypval, row0, row1, g_ent, cap_ent, g_counter,
-                                                                         g_start, g_len);
+        const char *gabl_env = getenv("SKM_GRAM_ABLATE");  // diagnostic only: results NOT valid
+        const int gabl = gabl_env ? atoi(gabl_env) : 0;
+        const char *gvar_env = getenv("SKM_GRAM_VARIANT");  // tuning aid; every variant is exact
+        const int gvar = gvar_env ? atoi(gvar_env) : 0;
+#define SKM_LAUNCH_G(GABL, GR, GH, GT, GQ, SL)                                                                        \
+    k_gram_sparse<GABL, GR, GH, GT, GQ, SL><<<(unsigned)skm_ceil_div(nrows, GR), GT, 0, st>>>(                          \
+        d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, (int)skm_ceil_div(m, CH), g_ent, cap_ent, g_counter, g_start, g_len)
+        if (gabl == 1)
+            SKM_LAUNCH_G(1, 2, 4096, 512, 2, 4);
+        else if (gabl == 2)
+            SKM_LAUNCH_G(2, 2, 4096, 512, 2, 4);
+        else if (gvar == 1)
+            SKM_LAUNCH_G(0, 1, 4096, 256, 2, 4);
+        else if (gvar == 2)
+            SKM_LAUNCH_G(0, 2, 2048, 512, 2, 4);
+        else if (gvar == 3)
+            SKM_LAUNCH_G(0, 2, 4096, 512, 2, 8);
+        else if (gvar == 4)
+            SKM_LAUNCH_G(0, 1, 4096, 256, 2, 8);
+        else if (gvar == 5)
+            SKM_LAUNCH_G(0, 1, 2048, 256, 2, 4);
+        else if (gvar == 6)
+            SKM_LAUNCH_G(0, 2, 4096, 512, 2, 2);
+        else if (gvar == 7)
+            SKM_LAUNCH_G(0, 2, 4096, 512, 2, 4);
+        else
+            SKM_LAUNCH_G(0, 1, 4096, 256, 2, 4);
+#undef SKM_LAUNCH_G
     }
     SKM_TRY(skm_check_launch("k_gram_sparse"));
     {

@@ -1,0 +1,235 @@
+// k_gram_sparse: exact sparse Gram rows (neighbour lists) of X against the postings of Y.
+// Included by skm_cosine_csr.hip inside its anonymous namespace (needs CH from there).
+//
+// For the rows of one strip every non-zero (row i, column c, count v) is a task whose posting list
+// (rows j of Y holding c, with counts v') contributes v*v' to G[i][j].  All (task, posting) pairs
+// of the strip are flattened with an LDS prefix sum over the posting-list lengths, so each
+// posting is read exactly once, by independent and mostly coalesced loads; products are summed in
+// per-row LDS hash tables keyed by j.  Finally each row's (j, dot) entries are appended to a
+// global list, grouped by 1024-column output chunk (LDS counting sort) for the streaming writer.
+#pragma once
+
+constexpr int GNB = 1024;  // output chunks (of CH columns) a neighbour list can be grouped by
+constexpr uint32_t G_OVERFLOW = 0xFFFFFFFFu;
+
+// GABL  diagnostic ablation (0 = real kernel)
+// GR    rows per workgroup           GH  hash slots per row (at most GH/2 distinct neighbours)
+// GT    threads per workgroup        GQ  tasks per thread (GQ*GT non-zeros per strip)
+// SL    consecutive pairs a thread handles per step
+template <int GABL, int GR, int GH, int GT, int GQ, int SL>
+__global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ xrowptr,
+                                                    const uint32_t *__restrict__ xcolidx,
+                                                    const uint32_t *__restrict__ xcounts,
+                                                    const uint32_t *__restrict__ ycolptr,
+                                                    const uint64_t *__restrict__ ypost, int64_t row0, int64_t row1,
+                                                    int nchunk, uint64_t *__restrict__ g_ent, unsigned long long cap_ent,
+                                                    unsigned long long *__restrict__ g_counter,
+                                                    uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len)
+{
+    constexpr int GTCAP = GQ * GT;
+    constexpr int GMAXD = GH / 2;
+    constexpr int HBITS = __builtin_ctz(GH);
+    // tasks (pair phase) and chunk histograms (emit phase) share one region
+    __shared__ uint32_t s_u[3 * GTCAP + 1 > GR * GNB ? 3 * GTCAP + 1 : GR * GNB];
+    __shared__ uint32_t hkeys[GR][GH];
+    __shared__ int hvals[GR][GH];
+    __shared__ int64_t s_rp[GR + 1];
+    __shared__ uint32_t s_wsum[GT / 64];
+    __shared__ uint32_t s_distinct[GR];
+    __shared__ unsigned long long s_off[GR];
+    __shared__ int s_over;
+    uint32_t *t_start = s_u, *t_scan = s_u + GTCAP, *t_liv = s_u + 2 * GTCAP + 1;
+    uint32_t *hist = s_u;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t i0 = row0 + (int64_t)blockIdx.x * GR;
+    const int rows = (int)min((int64_t)GR, row1 - i0);
+
+    if (tid <= GR)
+        s_rp[tid] = xrowptr[i0 + (tid <= rows ? tid : rows)];
+    if (tid < GR)
+        s_distinct[tid] = 0;
+    if (tid == 0)
+        s_over = 0;
+    for (int z = tid; z < GR * GH; z += GT) {
+        (&hkeys[0][0])[z] = 0u;
+        (&hvals[0][0])[z] = 0;
+    }
+    __syncthreads();
+    const int64_t e0 = s_rp[0];
+    const int64_t ntasks64 = s_rp[GR] - e0;
+    if (ntasks64 > GTCAP) {
+        if (tid < rows)
+            g_len[i0 - row0 + tid] = G_OVERFLOW;
+        return;
+    }
+    const int ntasks = (int)ntasks64;
+
+    // posting-list length of every task + exclusive prefix sum over the strip
+    uint32_t mydf[GQ];
+    uint32_t mysum = 0;
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) {
+        const int t = tid * GQ + q;
+        mydf[q] = 0;
+        if (t < ntasks) {
+            const int64_t e = e0 + t;
+            int li = 0;
+#pragma unroll
+            for (int r = 1; r < GR; ++r)
+                li += (e >= s_rp[r]) ? 1 : 0;
+            const uint32_t c = xcolidx[e];
+            const uint32_t pb = ycolptr[c], pe = ycolptr[c + 1];
+            t_start[t] = pb;
+            t_liv[t] = ((uint32_t)li << 28) | (xcounts[e] & 0x0FFFFFFFu);
+            mydf[q] = pe - pb;
+        }
+        mysum += mydf[q];
+    }
+    uint32_t incl = mysum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t up = __shfl_up(incl, o);
+        if (lane >= o)
+            incl += up;
+    }
+    if (lane == 63)
+        s_wsum[wid] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < GT / 64; ++q) {
+        wbase += q < wid ? s_wsum[q] : 0;
+        total += s_wsum[q];
+    }
+    uint32_t run = wbase + incl - mysum;
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) {
+        const int t = tid * GQ + q;
+        if (t < ntasks)
+            t_scan[t] = run;
+        run += mydf[q];
+    }
+    if (tid == 0)
+        t_scan[ntasks] = total;
+    __syncthreads();
+
+    // every (task, posting) pair once.  A thread takes SL consecutive pairs per step: one
+    // branch-free binary search locates the first pair's task, the rest walk forward; all posting
+    // loads of the step are issued before the first hash insert.
+    for (uint32_t g0 = (uint32_t)tid * SL; GABL != 1 && g0 < total; g0 += GT * SL) {
+        if (s_over)
+            break;
+        int t = 0;
+#pragma unroll
+        for (int w = GTCAP / 2; w > 0; w >>= 1) {
+            const int cand = t + w;
+            if (cand < ntasks && t_scan[cand] <= g0)
+                t = cand;
+        }
+        uint32_t jj[SL], ww[SL], lv[SL];
+#pragma unroll
+        for (int u = 0; u < SL; ++u) {
+            const uint32_t g = g0 + u;
+            jj[u] = ww[u] = lv[u] = 0;
+            if (g < total) {
+                while (t_scan[t + 1] <= g)
+                    ++t;
+                const uint64_t pw = ypost[t_start[t] + (g - t_scan[t])];
+                jj[u] = (uint32_t)pw;
+                ww[u] = (uint32_t)(pw >> 32);
+                lv[u] = t_liv[t];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SL; ++u) {
+            if (g0 + u < total) {
+                const uint32_t j = jj[u];
+                const int prod = (int)(lv[u] & 0x0FFFFFFFu) * (int)ww[u];
+                const int li = (int)(lv[u] >> 28);
+                const uint32_t key = j + 1u;
+                uint32_t h = (j * 2654435761u) >> (32 - HBITS);
+                // Most pairs hit a key that is already present, so look with a plain LDS read first
+                // and pay for the compare-and-swap only when the slot still looks empty.
+                for (int probe = 0; probe < GH; ++probe) {
+                    uint32_t seen = __atomic_load_n(&hkeys[li][h], __ATOMIC_RELAXED);
+                    if (seen == 0u) {
+                        seen = atomicCAS(&hkeys[li][h], 0u, key);
+                        if (seen == 0u) {
+                            seen = key;
+                            if (atomicAdd(&s_distinct[li], 1u) >= (uint32_t)GMAXD)
+                                s_over = 1;
+                        }
+                    }
+                    if (seen == key) {
+                        atomicAdd(&hvals[li][h], prod);
+                        break;
+                    }
+                    h = (h + 1) & (GH - 1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (s_over) {
+        if (tid < rows)
+            g_len[i0 - row0 + tid] = G_OVERFLOW;
+        return;
+    }
+    if (GABL == 2) {
+        if (tid < rows)
+            g_len[i0 - row0 + tid] = 0;
+        return;
+    }
+
+    // emit each row's neighbours grouped by output chunk (counting sort on j / CH); the order inside a group is unspecified and does not matter to the writer
+    for (int z = tid; z < GR * GNB; z += GT)
+        if ((z & (GNB - 1)) < nchunk)
+            hist[z] = 0;
+    if (tid < GR) {
+        unsigned long long off = 0;
+        if (tid < rows)
+            off = atomicAdd(g_counter, (unsigned long long)s_distinct[tid]);
+        s_off[tid] = off;
+    }
+    __syncthreads();
+    for (int z = tid; z < GR * GH; z += GT) {
+        const uint32_t key = (&hkeys[0][0])[z];
+        if (key)
+            atomicAdd(&hist[(z / GH) * GNB + ((key - 1u) / CH)], 1u);
+    }
+    __syncthreads();
+    if (wid < GR) {  // exclusive scan of row wid's chunk counters by one wave
+        uint32_t *hrow = hist + wid * GNB;
+        uint32_t carry = 0;
+        for (int base = 0; base < nchunk; base += 64) {
+            const uint32_t x = base + lane < nchunk ? hrow[base + lane] : 0u;
+            uint32_t inc = x;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t up = __shfl_up(inc, o);
+                if (lane >= o)
+                    inc += up;
+            }
+            if (base + lane < nchunk)
+                hrow[base + lane] = carry + inc - x;
+            carry += __shfl(inc, 63);
+        }
+    }
+    __syncthreads();
+    bool fits[GR];
+#pragma unroll
+    for (int r = 0; r < GR; ++r)
+        fits[r] = s_off[r] + (unsigned long long)s_distinct[r] <= cap_ent;
+    for (int z = tid; z < GR * GH; z += GT) {
+        const uint32_t key = (&hkeys[0][0])[z];
+        const int r = z / GH;
+        if (key && fits[r]) {
+            const uint32_t pos = atomicAdd(&hist[r * GNB + ((key - 1u) / CH)], 1u);
+            g_ent[s_off[r] + pos] = ((uint64_t)(key - 1u) << 32) | (uint32_t)(&hvals[0][0])[z];
+        }
+    }
+    if (tid < rows) {
+        g_start[i0 - row0 + tid] = s_off[tid];
+        g_len[i0 - row0 + tid] = fits[tid] ? s_distinct[tid] : G_OVERFLOW;
+    }
+}

@@ -135,6 +135,6 @@ class ShardedPipeline:
         if self.out is None:
             self.out = ctx.empty((max(hi - lo, 1), ld), np.float32)
         b = self.basis
-        e.cosine_matrix(ctx, self.full, self.rnorm, self.n_total, b.ncols, b.colptr, b.prow, b.pval, self.rnorm,
+        e.cosine_matrix(ctx, self.full, self.rnorm, self.n_total, b.ncols, b.colptr, b.post, self.rnorm,
                         row0=lo, row1=hi, out=self.out, ld=ld)
         return self.out

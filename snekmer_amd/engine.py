@@ -93,7 +93,7 @@ class Basis:
     def __init__(self):
         self.ncols = 0
         self.codes = self.df = self.total = self.firstkey = self.fs_order = None
-        self.colptr = self.prow = self.pval = None
+        self.colptr = self.post = None
 
 
 def recode(ctx: _hip.Context, batch: SeqBatch, lut: AlphabetLUT) -> Tuple[np.ndarray, np.ndarray]:
@@ -168,15 +168,14 @@ def build_basis(ctx, csr: CountsCSR, nsym: int, k: int, stats: bool = False, fir
         b.fs_order = need(b.fs_order, cap, np.uint32)
     if postings:
         b.colptr = need(b.colptr, cap + 1, np.uint32)
-        b.prow = need(b.prow, cap, np.uint32)
-        b.pval = need(b.pval, cap, np.uint32)
+        b.post = need(b.post, cap, np.uint64)
     ncols = _i64(0)
     ctx.call(
         "skm_basis_build", csr.code_bits, key_bits(nsym, k), _i64(csr.n), _i64(nnz), _ptr(csr.rowptr), _ptr(csr.codes),
         _ptr(csr.counts), _ptr(csr.firstpos if first_seen else None), C.byref(ncols), _ptr(b.codes), _ptr(csr.colidx),
         _ptr(b.df if stats else None), _ptr(b.total if stats else None), _ptr(b.firstkey if first_seen else None),
         _ptr(b.fs_order if first_seen else None), _ptr(b.colptr if postings else None),
-        _ptr(b.prow if postings else None), _ptr(b.pval if postings else None),
+        _ptr(b.post if postings else None),
     )
     b.ncols = int(ncols.value)
     return b
@@ -190,14 +189,13 @@ def row_norms(ctx, n: int, rowptr, counts, out=None) -> _hip.DeviceArray:
 
 def transpose(ctx, n: int, nnz: int, ncols: int, rowptr, colidx, counts):
     colptr = ctx.empty(ncols + 1, np.uint32)
-    prow = ctx.empty(max(nnz, 1), np.uint32)
-    pval = ctx.empty(max(nnz, 1), np.uint32)
+    post = ctx.empty(max(nnz, 1), np.uint64)
     ctx.call("skm_csr_transpose", _i64(n), _i64(nnz), _i64(ncols), _ptr(rowptr), _ptr(colidx), _ptr(counts),
-             _ptr(colptr), _ptr(prow), _ptr(pval))
-    return colptr, prow, pval
+             _ptr(colptr), _ptr(post))
+    return colptr, post
 
 
-def cosine_matrix(ctx, x: CountsCSR, x_rnorm, m: int, ncols: int, colptr, prow, pval, y_rnorm,
+def cosine_matrix(ctx, x: CountsCSR, x_rnorm, m: int, ncols: int, colptr, post, y_rnorm,
                   row0: int = 0, row1: Optional[int] = None, mode: int = 0, out=None, ld: Optional[int] = None):
     """a13/a14: float32 block [row1-row0, m] of cosine similarities (mode 0) or distances (mode 1)."""
     row1 = x.n if row1 is None else row1
@@ -207,7 +205,7 @@ def cosine_matrix(ctx, x: CountsCSR, x_rnorm, m: int, ncols: int, colptr, prow, 
         out = ctx.empty((max(rows, 1), max(ld, 1)), np.float32)
     ctx.call(
         "skm_cosine_csr", _i64(x.n), _ptr(x.rowptr), _ptr(x.colidx), _ptr(x.counts), _ptr(x_rnorm), _i64(m), _i64(ncols),
-        _ptr(colptr), _ptr(prow), _ptr(pval), _ptr(y_rnorm), _i64(row0), _i64(row1), mode, _ptr(out), _i64(ld),
+        _ptr(colptr), _ptr(post), _ptr(y_rnorm), _i64(row0), _i64(row1), mode, _ptr(out), _i64(ld),
     )
     return out
 
@@ -250,7 +248,7 @@ class Pipeline:
             self.out = None
             self.out = self.ctx.empty((max(rows, 1), max(ld, 1)), np.float32)
         b = self.basis
-        cosine_matrix(self.ctx, self.csr, self.rnorm, n, b.ncols, b.colptr, b.prow, b.pval, self.rnorm,
+        cosine_matrix(self.ctx, self.csr, self.rnorm, n, b.ncols, b.colptr, b.post, self.rnorm,
                       row0=row0, row1=row1, out=self.out, ld=ld)
         return self.out
 

@@ -63,9 +63,9 @@ def cosine_similarity(X, Y=None, mode: int = 0, ctx=None) -> np.ndarray:
             raise ValueError(f"Incompatible dimension for X and Y matrices: X.shape[1] == {kx} while Y.shape[1] == {ky}")
     xr = engine.row_norms(ctx, x.n, x.rowptr, x.counts)
     yr = xr if y is x else engine.row_norms(ctx, y.n, y.rowptr, y.counts)
-    colptr, prow, pval = engine.transpose(ctx, y.n, y.nnz, ky, y.rowptr, y.colidx, y.counts)
+    colptr, post = engine.transpose(ctx, y.n, y.nnz, ky, y.rowptr, y.colidx, y.counts)
     ld = (y.n + 3) // 4 * 4
-    out = engine.cosine_matrix(ctx, x, xr, y.n, ky, colptr, prow, pval, yr, mode=mode, ld=ld)
+    out = engine.cosine_matrix(ctx, x, xr, y.n, ky, colptr, post, yr, mode=mode, ld=ld)
     return out.download().reshape(max(x.n, 1), max(ld, 1))[: x.n, : y.n]
 
 

@@ -128,7 +128,8 @@ def test_count_csr_and_basis_vs_oracle(ctx, name, k):
     assert (b.fs_order.download(B) == np.argsort(ofk, kind="stable")).all()
     # postings = column-major copy, rows ascending inside a column
     colptr = b.colptr.download(B + 1)
-    prow, pval = b.prow.download(csr.nnz), b.pval.download(csr.nnz)
+    post = b.post.download(csr.nnz)
+    prow, pval = (post & np.uint64(0xFFFFFFFF)).astype(np.int64), (post >> np.uint64(32)).astype(np.uint32)
     assert colptr[0] == 0 and colptr[B] == csr.nnz and (np.diff(colptr.astype(np.int64)) == odf).all()
     row_of = np.repeat(np.arange(batch.n), np.diff(o_rowptr))
     order = np.lexsort((row_of, ocol))
@@ -267,7 +268,7 @@ def test_cosine_medium_vs_oracle_all_modes(ctx):
     assert (S_cur == S).all()
     # distance mode
     b = pipe.basis
-    D = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, b.ncols, b.colptr, b.prow, b.pval, pipe.rnorm, mode=1,
+    D = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, b.ncols, b.colptr, b.post, pipe.rnorm, mode=1,
                              ld=pipe.out.shape[1]).download().reshape(-1, pipe.out.shape[1])[:n, :n]
     refD = np.clip(1.0 - ref, 0, 2)
     np.fill_diagonal(refD, 0.0)
