@@ -3,6 +3,7 @@
 import collections
 import csv
 import glob
+import re
 import sys
 
 root, flt = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
@@ -10,7 +11,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if flt in r["Kernel_Name"]:
-            name = r["Kernel_Name"].split("(")[0].split("::")[-1][:40]
+            m = re.search(r"(k_[a-z0-9_]+|radix_sort[a-z_]*|scan[a-z_]*|__amd_rocclr_[A-Za-z]+)", r["Kernel_Name"])
+            name = m.group(1) if m else r["Kernel_Name"][:40]
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k)
