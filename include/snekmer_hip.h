@@ -147,6 +147,9 @@ int skm_csr_to_dense(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const uin
                      const uint32_t *d_counts, const uint32_t *d_colmap, int64_t ncols_out,
                      int mode, int dtype, void *d_out, int64_t ld);
 
+/* Largest count in a CSR (host-synchronous): the int8 dense path needs it to be <= 127. */
+int skm_csr_max_count(skm_ctx *ctx, int64_t nnz, const uint32_t *d_counts, uint32_t *h_max);
+
 /* ---- a13/a14: cosine ----------------------------------------------------------------------- */
 /* 1/||row|| (float32; 1.0 for an all-zero row, as sklearn's normalize does) and optionally the
  * exact squared norms. */

@@ -104,6 +104,19 @@ __global__ void k_col_stats(int64_t ncols, const uint32_t *__restrict__ colptr, 
     }
 }
 
+__global__ void k_max_u32(int64_t n, const uint32_t *__restrict__ v, unsigned int *out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned int mx = 0;
+    for (; i < n; i += stride)
+        mx = max(mx, v[i]);
+    for (int o = 32; o > 0; o >>= 1)
+        mx = max(mx, (unsigned int)__shfl_down(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx)
+        atomicMax(out, mx);
+}
+
 __global__ void k_pair_work(int64_t ncols, const uint32_t *__restrict__ colptr, unsigned long long *out)
 {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -442,6 +455,25 @@ extern "C" int skm_row_norms_csr(skm_ctx *ctx, int64_t n, const int64_t *d_rowpt
     k_row_norms<<<skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16), BLK, 0, ctx->stream>>>(n, d_rowptr, d_counts, d_rnorm,
                                                                                           d_normsq);
     return skm_check_launch("k_row_norms");
+}
+
+extern "C" int skm_csr_max_count(skm_ctx *ctx, int64_t nnz, const uint32_t *d_counts, uint32_t *h_max)
+{
+    SKM_REQUIRE(ctx && h_max && nnz >= 0, SKM_E_BADARG, "skm_csr_max_count: bad argument");
+    *h_max = 0;
+    if (nnz == 0)
+        return SKM_OK;
+    SKM_HIP(hipSetDevice(ctx->device));
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
+    unsigned int *acc = (unsigned int *)((uint8_t *)p + 1536);
+    SKM_HIP(hipMemsetAsync(acc, 0, 4, ctx->stream));
+    k_max_u32<<<skm_grid_cap(ctx, skm_ceil_div(nnz, BLK), 8), BLK, 0, ctx->stream>>>(nnz, d_counts, acc);
+    SKM_TRY(skm_check_launch("k_max_u32"));
+    SKM_HIP(hipMemcpyAsync(ctx->h_pinned, acc, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SKM_HIP(hipStreamSynchronize(ctx->stream));
+    *h_max = *(uint32_t *)ctx->h_pinned;
+    return SKM_OK;
 }
 
 extern "C" int skm_pair_work(skm_ctx *ctx, int64_t ncols, const uint32_t *d_colptr, uint64_t *h_pairs)

@@ -1,16 +1,235 @@
-// Dense small-basis path (placeholder until the MFMA kernel lands in this round).
+// Dense small-basis path: the full |S|^k feature basis materialised (north_star's
+// "N x |S|^k count matrix") and the cosine matrix as a true dense GEMM on the matrix cores.
+//
+// Reference behaviour being replaced:
+//   count matrix over a full basis        snekmer/vectorize.py:259-290 (intent), rules/learn.smk:359-383
+//   sklearn cosine_similarity(X, Y)       snekmer/rules/apply.smk:282-284, rules/learn.smk:821-823
+//
+// Only legitimate when |S|^k is small (hydro k<=20, solvacc k<=12, ...: SURVEY.md D2); at
+// |S|^k = 6^12 the sparse path of skm_cosine_csr.hip is the only one that fits.
+//
+//   k_count_dense       wave per sequence: class ranks staged in LDS, window codes formed from LDS,
+//                       one atomic increment per valid window into row i of the count matrix
+//                       (uint32 words; uint16 cells are incremented through their containing word).
+//   k_cosine_dense_i8   128x128 output tile per workgroup, K-step 64, int8 operands staged in LDS,
+//                       v_mfma_i32_32x32x32_i8 with int32 accumulation (exact), float32 epilogue
+//                       acc * rnorm_x[i] * rnorm_y[j].
+#include <cstring>
+
 #include "skm_common.h"
 
-extern "C" int skm_count_dense(skm_ctx *, const uint8_t *, int, int, const uint8_t *, const int64_t *, int64_t, int,
-                               void *, int64_t)
+namespace {
+
+// ------------------------------------------------------------------------------- count scatter
+template <typename CELL>
+__global__ __launch_bounds__(64) void k_count_dense(skm_lut256 lut, int nsym, int k,
+                                                    const uint8_t *__restrict__ seq,
+                                                    const int64_t *__restrict__ off, int64_t n,
+                                                    CELL *__restrict__ out, int64_t ld, int *__restrict__ overflow)
 {
-    skm_set_error("skm_count_dense: not built yet");
-    return SKM_E_UNSUPPORTED;
+    constexpr int TILE = 1024;
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t s_rank[TILE + 64];
+    const int lane = threadIdx.x;
+    reinterpret_cast<uint32_t *>(s_lut)[lane] = reinterpret_cast<const uint32_t *>(lut.b)[lane];
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const int64_t b = off[i];
+        int64_t e = off[i + 1];
+        while (e > b && seq[e - 1] == '*')  // every lane walks the same few bytes
+            --e;
+        const int len = (int)(e - b);
+        const int w = len - k + 1;
+        if (sizeof(CELL) == 2 && w > 65535 && lane == 0)
+            *overflow = 1;
+        CELL *row = out + i * ld;
+        for (int t0 = 0; t0 < w; t0 += TILE) {
+            __syncthreads();
+            const int span = min(TILE + k - 1, len - t0);
+            for (int p = lane; p < span; p += 64)
+                s_rank[p] = s_lut[seq[b + t0 + p]];
+            __syncthreads();
+            const int wt = min(TILE, w - t0);
+            for (int p = lane; p < wt; p += 64) {
+                uint32_t c = 0, bad = 0;
+                for (int j = 0; j < k; ++j) {
+                    const uint32_t r = s_rank[p + j];
+                    bad |= (r == 0xFFu);
+                    c = c * (uint32_t)nsym + r;
+                }
+                if (!bad) {
+                    if (sizeof(CELL) == 4) {
+                        atomicAdd(reinterpret_cast<unsigned int *>(row) + c, 1u);
+                    } else {
+                        // 16-bit cell inside its aligned 32-bit word (row base is 4-byte aligned: ld even)
+                        unsigned int *word = reinterpret_cast<unsigned int *>(row) + (c >> 1);
+                        atomicAdd(word, (c & 1u) ? 0x10000u : 1u);
+                    }
+                }
+            }
+        }
+    }
 }
 
-extern "C" int skm_cosine_dense_i8(skm_ctx *, int64_t, int64_t, int64_t, const int8_t *, const int8_t *, const float *,
-                                   const float *, int, float *, int64_t)
+// ------------------------------------------------------------------------------- i8 MFMA cosine
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDS_ROW = BK + 16;  // 80-byte rows: 16-byte reads of 32 consecutive rows spread over the banks
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cosine_dense_i8(int64_t n, int64_t m, int64_t kdim,
+                                                         const int8_t *__restrict__ X,
+                                                         const int8_t *__restrict__ Y,
+                                                         const float *__restrict__ xr,
+                                                         const float *__restrict__ yr, float *__restrict__ out,
+                                                         int64_t ld)
 {
-    skm_set_error("skm_cosine_dense_i8: not built yet");
-    return SKM_E_UNSUPPORTED;
+    __shared__ __attribute__((aligned(16))) int8_t s_a[BM * LDS_ROW];
+    __shared__ __attribute__((aligned(16))) int8_t s_b[BN * LDS_ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;  // 2 x 2 waves, each 64 x 64 of the tile
+    const int64_t row0 = (int64_t)blockIdx.y * BM, col0 = (int64_t)blockIdx.x * BN;
+
+    i32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[a][b][r] = 0;
+
+    // staging: 256 threads x 16 B = 64 rows x 64 B per pass, two passes per operand
+    const int st_row = tid >> 2, st_chunk = tid & 3;
+    for (int64_t k0 = 0; k0 < kdim; k0 += BK) {
+        i32x4 va[2], vb[2];
+#pragma unroll
+        for (int pss = 0; pss < 2; ++pss) {
+            const int r = st_row + pss * 64;
+            const int64_t gi = row0 + r, gj = col0 + r;
+            va[pss] = gi < n ? *reinterpret_cast<const i32x4 *>(X + gi * kdim + k0 + st_chunk * 16) : (i32x4){0, 0, 0, 0};
+            vb[pss] = gj < m ? *reinterpret_cast<const i32x4 *>(Y + gj * kdim + k0 + st_chunk * 16) : (i32x4){0, 0, 0, 0};
+        }
+        __syncthreads();  // previous step's fragment reads are done
+#pragma unroll
+        for (int pss = 0; pss < 2; ++pss) {
+            const int r = st_row + pss * 64;
+            *reinterpret_cast<i32x4 *>(s_a + r * LDS_ROW + st_chunk * 16) = va[pss];
+            *reinterpret_cast<i32x4 *>(s_b + r * LDS_ROW + st_chunk * 16) = vb[pss];
+        }
+        __syncthreads();
+        // fragment of v_mfma_i32_32x32x32_i8: lane l holds 16 consecutive k of row (l & 31),
+        // k offset 16 * (l >> 5)
+        const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            i32x4 fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = *reinterpret_cast<const i32x4 *>(s_a + (wr * 64 + t * 32 + fr) * LDS_ROW + ks * 32 + fh * 16);
+                fb[t] = *reinterpret_cast<const i32x4 *>(s_b + (wc * 64 + t * 32 + fr) * LDS_ROW + ks * 32 + fh * 16);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // epilogue: C/D layout of the 32x32 shapes: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int ccol = lane & 31, chalf = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int64_t j = col0 + wc * 64 + b * 32 + ccol;
+            const float rj = j < m ? yr[j] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t i = row0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+                if (i < n && j < m) {
+                    float o = (float)acc[a][b][r] * xr[i] * rj;
+                    if (MODE == 1) {
+                        o = fminf(fmaxf(1.0f - o, 0.0f), 2.0f);
+                        if (i == j)
+                            o = 0.0f;
+                    }
+                    out[i * ld + j] = o;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int skm_count_dense(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, const uint8_t *d_seq,
+                               const int64_t *d_off, int64_t n, int dtype, void *d_out, int64_t ld)
+{
+    SKM_REQUIRE(ctx && h_rank && d_off && n >= 0, SKM_E_BADARG, "skm_count_dense: bad argument");
+    SKM_REQUIRE(dtype == 0 || dtype == 1, SKM_E_BADARG, "skm_count_dense: dtype must be 0 (uint16) or 1 (uint32)");
+    SKM_REQUIRE(nsym >= 1 && nsym <= 254 && k >= 1 && k <= 64, SKM_E_BADARG, "skm_count_dense: bad nsym/k");
+    int64_t space = 1;
+    for (int j = 0; j < k; ++j) {
+        space *= nsym;
+        SKM_REQUIRE(space <= ((int64_t)1 << 26), SKM_E_UNSUPPORTED,
+                    "skm_count_dense: |S|^k = %d^%d exceeds 2^26 dense columns; use skm_count_csr", nsym, k);
+    }
+    SKM_REQUIRE(ld >= space && (dtype == 1 || ld % 2 == 0), SKM_E_BADARG,
+                "skm_count_dense: ld (%lld) must be >= %lld (and even for uint16)", (long long)ld, (long long)space);
+    if (n == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_out && d_seq, SKM_E_BADARG, "skm_count_dense: null buffer");
+    SKM_HIP(hipSetDevice(ctx->device));
+    skm_lut256 lut;
+    memcpy(lut.b, h_rank, 256);
+    const size_t cell = dtype == 0 ? 2 : 4;
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
+    int *flag = (int *)((uint8_t *)p + 3072);
+    SKM_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+    {
+        SKM_PROF(ctx, "memset_count_dense");
+        SKM_HIP(hipMemsetAsync(d_out, 0, cell * (size_t)n * (size_t)ld, ctx->stream));
+    }
+    {
+        SKM_PROF(ctx, "k_count_dense");
+        const int grid = skm_grid_cap(ctx, n, 64);
+        if (dtype == 0)
+            k_count_dense<uint16_t><<<grid, 64, 0, ctx->stream>>>(lut, nsym, k, d_seq, d_off, n, (uint16_t *)d_out, ld, flag);
+        else
+            k_count_dense<uint32_t><<<grid, 64, 0, ctx->stream>>>(lut, nsym, k, d_seq, d_off, n, (uint32_t *)d_out, ld, flag);
+    }
+    SKM_TRY(skm_check_launch("k_count_dense"));
+    if (dtype == 0) {
+        SKM_HIP(hipMemcpyAsync(ctx->h_pinned, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SKM_HIP(hipStreamSynchronize(ctx->stream));
+        SKM_REQUIRE(*(int *)ctx->h_pinned == 0, SKM_E_OVERFLOW,
+                    "skm_count_dense: a sequence has more than 65535 windows; use dtype uint32");
+    }
+    return SKM_OK;
+}
+
+extern "C" int skm_cosine_dense_i8(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim, const int8_t *d_x,
+                                   const int8_t *d_y, const float *d_xrnorm, const float *d_yrnorm, int mode,
+                                   float *d_out, int64_t ld)
+{
+    SKM_REQUIRE(ctx && n >= 0 && m >= 0 && kdim >= 0, SKM_E_BADARG, "skm_cosine_dense_i8: bad argument");
+    SKM_REQUIRE(kdim % 64 == 0, SKM_E_BADARG, "skm_cosine_dense_i8: kdim (%lld) must be a multiple of 64", (long long)kdim);
+    SKM_REQUIRE(ld >= m, SKM_E_BADARG, "skm_cosine_dense_i8: ld < m");
+    SKM_REQUIRE(mode == 0 || mode == 1, SKM_E_BADARG, "skm_cosine_dense_i8: mode must be 0 or 1");
+    if (n == 0 || m == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_x && d_y && d_xrnorm && d_yrnorm && d_out, SKM_E_BADARG, "skm_cosine_dense_i8: null array");
+    SKM_REQUIRE((((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0, SKM_E_BADARG, "skm_cosine_dense_i8: operands must be 16-byte aligned");
+    SKM_HIP(hipSetDevice(ctx->device));
+    dim3 grid((unsigned)skm_ceil_div(m, BN), (unsigned)skm_ceil_div(n, BM));
+    SKM_PROF(ctx, "k_cosine_dense_i8");
+    if (mode == 0)
+        k_cosine_dense_i8<0><<<grid, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+    else
+        k_cosine_dense_i8<1><<<grid, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+    return skm_check_launch("k_cosine_dense_i8");
 }

@@ -219,6 +219,62 @@ def csr_to_dense(ctx, n: int, rowptr, colidx, counts, ncols_out: int, colmap=Non
     return out
 
 
+def count_dense(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int, dtype=np.uint16) -> _hip.DeviceArray:
+    """North-star dense count matrix [n x |S|^k] by atomic scatter (small bases only)."""
+    space = lut.nsym**k
+    ld = space + (space & 1)
+    out = ctx.empty((max(batch.n, 1), ld), dtype)
+    code = {np.dtype(np.uint16): 0, np.dtype(np.uint32): 1}[np.dtype(dtype)]
+    ctx.call("skm_count_dense", _ptr(lut.rank), lut.nsym, k, _ptr(batch.d_seq), _ptr(batch.d_off), _i64(batch.n), code,
+             _ptr(out), _i64(ld))
+    return out
+
+
+def csr_max_count(ctx, csr: CountsCSR) -> int:
+    mx = C.c_uint32(0)
+    ctx.call("skm_csr_max_count", _i64(csr.nnz), _ptr(csr.counts), C.byref(mx))
+    return int(mx.value)
+
+
+def cosine_dense_i8(ctx, n: int, m: int, kdim: int, x_i8, y_i8, x_rnorm, y_rnorm, mode: int = 0, out=None,
+                    ld: Optional[int] = None):
+    """a13 on the matrix cores: float32 [n x m] from int8 count matrices [n x kdim], [m x kdim]."""
+    ld = (m + 3) // 4 * 4 if ld is None else ld
+    if out is None:
+        out = ctx.empty((max(n, 1), max(ld, 1)), np.float32)
+    ctx.call("skm_cosine_dense_i8", _i64(n), _i64(m), _i64(kdim), _ptr(x_i8), _ptr(y_i8), _ptr(x_rnorm), _ptr(y_rnorm),
+             mode, _ptr(out), _i64(ld))
+    return out
+
+
+class DensePipeline:
+    """Small-basis variant of Pipeline: the full |S|^k basis as dense int8 counts, cosine by MFMA.
+
+    Column id == k-mer code, so no basis sort is needed.  Raises if a count exceeds 127 (the
+    int8 operand range); use Pipeline (exact for any count) in that case."""
+
+    def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int):
+        space = lut.nsym**k
+        if space > 2**26 or lut.code_bits(k) != 32:
+            raise ValueError(f"dense path needs |S|^k <= 2^26 (got {lut.nsym}^{k})")
+        self.ctx, self.lut, self.k = ctx, lut, k
+        self.space = space
+        self.kdim = (space + 63) // 64 * 64
+        self.csr = self.rnorm = self.dense = self.out = None
+
+    def step(self, batch: SeqBatch, mode: int = 0):
+        ctx = self.ctx
+        self.csr = count_csr(ctx, batch, self.lut, self.k, out=self.csr)
+        if csr_max_count(ctx, self.csr) > 127:
+            raise OverflowError("a k-mer count exceeds 127: int8 dense path not applicable")
+        n = self.csr.n
+        self.rnorm = row_norms(ctx, n, self.csr.rowptr, self.csr.counts, out=self.rnorm)
+        # codes double as column ids of the full basis
+        self.dense = csr_to_dense(ctx, n, self.csr.rowptr, self.csr.codes, self.csr.counts, self.kdim, dtype=np.int8)
+        self.out = cosine_dense_i8(ctx, n, n, self.kdim, self.dense, self.dense, self.rnorm, self.rnorm, mode=mode)
+        return self.out
+
+
 class Pipeline:
     """vectorize + all-pairs cosine for one batch, reusing every device buffer between steps.
 

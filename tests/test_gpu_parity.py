@@ -322,3 +322,68 @@ def test_config2_properties_and_sampled_rows(ctx, n):
     for r, row in zip(rows[:8], got[:8]):
         top = np.argsort(-row)[1:6]
         assert (fam[top] == fam[r]).all()
+
+
+# ------------------------------------------------------------------ dense small-basis path
+@pytest.mark.parametrize("name,k,dtype", [("hydro", 10, np.uint16), ("solvacc", 6, np.uint32), ("hydro", 14, np.uint16)])
+def test_count_dense_scatter_matches_oracle(ctx, name, k, dtype):
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+
+    orc = _oracle()
+    lut = A.build_lut(name)
+    seqs, (res, off) = _mixed_batch(seed=3, n=300, long_lengths=(700, 3000))
+    batch = engine.SeqBatch(ctx, res, off)
+    out = engine.count_dense(ctx, batch, lut, k, dtype=dtype)
+    M = out.download().reshape(out.shape)
+    rowptr, codes, counts, _ = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+    ref = np.zeros((batch.n, out.shape[1]), dtype=np.int64)
+    row_of = np.repeat(np.arange(batch.n), np.diff(rowptr))
+    ref[row_of, codes.astype(np.int64)] = counts
+    assert (M.astype(np.int64) == ref).all()
+
+
+def test_cosine_dense_i8_mfma_exact_gram_and_scaling(ctx):
+    """Asymmetric integer operands (guide: an A = I or symmetric check can hide a transposed
+    fragment map): the int32 accumulators must equal the numpy Gram exactly."""
+    from snekmer_amd import engine
+
+    rng = np.random.default_rng(0)
+    n, m, kdim = 200, 333, 192
+    X = rng.integers(-128, 128, size=(n, kdim)).astype(np.int8)
+    Y = rng.integers(-128, 128, size=(m, kdim)).astype(np.int8)
+    ones_n = ctx.to_device(np.ones(n + 4, dtype=np.float32))
+    ones_m = ctx.to_device(np.ones(m + 4, dtype=np.float32))
+    # small enough values that float32 holds every dot product exactly
+    Xs, Ys = (X // 16).astype(np.int8), (Y // 16).astype(np.int8)
+    out = engine.cosine_dense_i8(ctx, n, m, kdim, ctx.to_device(Xs), ctx.to_device(Ys), ones_n, ones_m)
+    G = out.download().reshape(out.shape)[:n, :m]
+    ref = Xs.astype(np.int64) @ Ys.astype(np.int64).T
+    assert (G.astype(np.int64) == ref).all()
+
+
+@pytest.mark.parametrize("name,k", [("hydro", 12), ("solvacc", 7), ("hydro", 14)])
+def test_dense_pipeline_matches_sparse_pipeline_and_oracle(ctx, name, k):
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+
+    orc = _oracle()
+    lut = A.build_lut(name)
+    res, off, _ = synth_families(700, 300, family=20, seed=77)
+    batch = engine.SeqBatch(ctx, res, off)
+    dense = engine.DensePipeline(ctx, lut, k)
+    out = dense.step(batch)
+    n = batch.n
+    S = out.download().reshape(out.shape)[:n, :n]
+    rowptr, codes, counts, first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+    ref = orc.cosine_rows(rowptr, codes.astype(np.uint32), counts, lut.nsym**k, np.arange(n))
+    assert np.abs(S - ref).max() <= COS_TOL
+    sparse = engine.Pipeline(ctx, lut, k)
+    o2 = sparse.step(batch)
+    S2 = o2.download().reshape(o2.shape)[:n, :n]
+    assert np.abs(S - S2).max() <= 2e-7
+    D = dense.step(batch, mode=1).download().reshape(out.shape)[:n, :n]
+    refD = np.clip(1.0 - ref, 0, 2)
+    np.fill_diagonal(refD, 0.0)
+    assert np.abs(D - refD).max() <= COS_TOL
