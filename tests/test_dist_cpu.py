@@ -1,0 +1,118 @@
+"""World-size-2 checks (gloo, CPU) of the host-side sharding plan in snekmer_amd/dist.py.
+
+Two ranks each count the k-mers of their row block (with the oracle standing in for the device
+kernel, which is what tests may do), exchange the CSR shards through gloo exactly as
+ShardedPipeline does through RCCL (sizes first, then three variable-size all-gathers), rebuild
+the row pointers with the host statement of skm_csr_concat_rowptr and compute their row block
+of the cosine matrix.  The assembled result must equal the unsharded oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    from oracle import c_oracle
+    from snekmer_amd import alphabet as A
+    from snekmer_amd.dist import concat_rowptr_host, plan_allgather, shard_bounds
+    from snekmer_amd.synth import synth_families
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if "red6" not in A.ALPHABETS:
+            A.register_alphabet("red6", A.RED6_GROUPS)
+        lut = A.build_lut("red6")
+        k, n = 12, 301  # odd on purpose: uneven shards
+        res, off, _ = synth_families(n, 300, family=25, seed=99)
+        bounds = shard_bounds(n, world)
+        lo, hi = bounds[rank]
+        loc_rp, loc_codes, loc_counts, _ = c_oracle.count_csr(
+            lut.rank, lut.nsym, k, res[off[lo] : off[hi]], off[lo : hi + 1] - off[lo]
+        )
+
+        def allgather_i64(v):
+            t = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(t, torch.tensor([v], dtype=torch.int64))
+            return [int(x.item()) for x in t]
+
+        def allgatherv(buf: np.ndarray, nbytes):
+            raw = np.frombuffer(buf.tobytes(), dtype=np.uint8)
+            assert raw.size == nbytes[rank]
+            mx = max(nbytes)
+            pad = np.zeros(mx, dtype=np.uint8)
+            pad[: raw.size] = raw
+            outs = [torch.zeros(mx, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(outs, torch.from_numpy(pad))
+            return np.concatenate([o.numpy()[: nbytes[r]] for r, o in enumerate(outs)])
+
+        nnz = allgather_i64(len(loc_codes))
+        rows = [b - a for a, b in bounds]
+        plan = plan_allgather(nnz, rows, 4)
+        codes = allgatherv(loc_codes.astype(np.uint32), plan["codes"]).view(np.uint32)
+        counts = allgatherv(loc_counts.astype(np.uint32), plan["counts"]).view(np.uint32)
+        rp_all = allgatherv(loc_rp.astype(np.int64), plan["rowptr"]).view(np.int64)
+        pieces, pos = [], 0
+        for r in rows:
+            pieces.append(rp_all[pos : pos + r + 1])
+            pos += r + 1
+        rowptr = concat_rowptr_host(pieces)
+
+        # every rank now holds the full CSR; compare with the unsharded oracle
+        f_rp, f_codes, f_counts, f_first = c_oracle.count_csr(lut.rank, lut.nsym, k, res, off)
+        assert (rowptr == f_rp).all() and (codes == f_codes.astype(np.uint32)).all() and (counts == f_counts).all()
+        b, _, _, _, col = c_oracle.basis(rowptr, codes.astype(np.uint64), counts, np.zeros(len(codes), np.uint32))
+        block = c_oracle.cosine_rows(rowptr, col, counts, len(b), np.arange(lo, hi))
+        np.save(os.path.join(outdir, f"block{rank}.npy"), block)
+        dist.barrier()
+        if rank == 0:
+            full = np.concatenate([np.load(os.path.join(outdir, f"block{r}.npy")) for r in range(world)])
+            fb, _, _, _, fcol = c_oracle.basis(f_rp, f_codes, f_counts, f_first)
+            ref = c_oracle.cosine_rows(f_rp, fcol, f_counts, len(fb), np.arange(n))
+            assert full.shape == ref.shape and np.abs(full - ref).max() < 1e-12
+            open(os.path.join(outdir, "ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_csr_exchange_plan(tmp_path):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def test_shard_bounds_cover_and_balance():
+    from snekmer_amd.dist import concat_rowptr_host, plan_allgather, shard_bounds, shard_bounds_by_residues
+
+    for n, w in [(0, 2), (1, 2), (7, 8), (100000, 8), (100001, 3)]:
+        b = shard_bounds(n, w)
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1
+    off = np.concatenate([[0], np.cumsum(np.r_[np.full(50, 1000), np.full(950, 100)])])
+    b = shard_bounds_by_residues(off, 4)
+    assert b[0][0] == 0 and b[-1][1] == 1000 and all(b[i][1] == b[i + 1][0] for i in range(3))
+    res = [off[hi] - off[lo] for lo, hi in b]
+    assert max(res) - min(res) <= 2 * 1000  # within two of the longest sequences
+    plan = plan_allgather([10, 0, 5], [3, 2, 4], 8)
+    assert plan == {"codes": [80, 0, 40], "counts": [40, 0, 20], "rowptr": [32, 24, 40]}
+    rp = concat_rowptr_host([np.array([0, 2, 5]), np.array([0]), np.array([0, 1, 1, 4])])
+    assert rp.tolist() == [0, 2, 5, 6, 6, 9]
