@@ -98,8 +98,13 @@ def main():
     if "red6" not in alphabet.ALPHABETS:
         alphabet.register_alphabet("red6", alphabet.RED6_GROUPS)
 
+    # SKM_BENCH_FORCE_SHARDED=1 runs the multi-GPU code path (gloo control plane, RCCL exchange,
+    # ShardedPipeline) even with one rank, so that a 1-GPU box can exercise it.
+    sharded = world > 1 or os.environ.get("SKM_BENCH_FORCE_SHARDED") == "1"
     dist = None
-    if world > 1:
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         # torch.distributed (gloo) is control plane only: id broadcast, barriers, max-over-ranks.
         import torch
         import torch.distributed as dist
@@ -113,7 +118,7 @@ def main():
     n_total = args.n
     residues_total = int(off[-1])
 
-    if world == 1:
+    if not sharded:
         batch = engine.SeqBatch(ctx, res, off)
         pipe = engine.Pipeline(ctx, lut, args.k)
         step = lambda: pipe.step(batch)
@@ -162,7 +167,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         launches, strip_ms = prof.get("k_cosine_write", (0, 0.0))
         strip_avg_ms = strip_ms / max(launches, 1)
-        csr = pipe.csr if world == 1 else pipe.full
+        csr = pipe.full if sharded else pipe.csr
         nnz = csr.nnz
         ld = (n_total + 3) // 4 * 4
         # algorithmic bytes of one k_cosine_write launch (DESIGN.md "Kernels"): the float32 output
@@ -190,7 +195,7 @@ def main():
                 "residues": residues_total,
                 "nnz": nnz,
                 "basis_columns": pipe.basis.ncols,
-                "parallelism": "single GPU" if world == 1 else f"row-sharded x{world}, 1 RCCL all-gather of CSR",
+                "parallelism": f"row-sharded x{world}, 1 RCCL all-gather of CSR" if sharded else "single GPU",
             },
             "residues_per_s": residues_total / (elapsed / args.steps),
             "stage_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},

@@ -387,3 +387,32 @@ def test_dense_pipeline_matches_sparse_pipeline_and_oracle(ctx, name, k):
     refD = np.clip(1.0 - ref, 0, 2)
     np.fill_diagonal(refD, 0.0)
     assert np.abs(D - refD).max() <= COS_TOL
+
+
+# ------------------------------------------------------------------ RCCL path, one rank
+def test_sharded_pipeline_over_rccl_single_rank_equals_pipeline(ctx):
+    """The multi-GPU step (count shard -> RCCL all-gather of CSR -> concat rowptr -> basis ->
+    row-block cosine) run with a one-rank communicator must reproduce the single-GPU pipeline."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.dist import RcclExchange, ShardedPipeline, shard_bounds
+    from snekmer_amd.synth import synth_families
+
+    lut = A.build_lut("red6")
+    res, off, _ = synth_families(900, 300, family=30, seed=21)
+    batch = engine.SeqBatch(ctx, res, off)
+    ref = engine.Pipeline(ctx, lut, 12)
+    S = ref.step(batch)
+    n = batch.n
+    S = S.download().reshape(S.shape)[:n, :n]
+    ex = RcclExchange(ctx, 1, 0, RcclExchange.new_unique_id())
+    try:
+        sp = ShardedPipeline(ctx, lut, 12, ex, shard_bounds(n, 1), int(off[-1]))
+        out = sp.step(batch)
+        T = out.download().reshape(out.shape)[:n, :n]
+        assert (T == S).all()
+        assert sp.full.nnz == ref.csr.nnz and sp.basis.ncols == ref.basis.ncols
+        out = sp.step(batch)  # buffers are reused on the second step
+        assert (out.download().reshape(out.shape)[:n, :n] == S).all()
+    finally:
+        ctx.call("skm_comm_destroy")
