@@ -416,3 +416,51 @@ def test_sharded_pipeline_over_rccl_single_rank_equals_pipeline(ctx):
         assert (out.download().reshape(out.shape)[:n, :n] == S).all()
     finally:
         ctx.call("skm_comm_destroy")
+
+
+# ------------------------------------------------------------------ BASELINE full sizes
+def _sampled_row_check(ctx, name, k, n, seed_idx, nsample=48, family=100):
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+
+    orc = _oracle()
+    lut = A.build_lut(name)
+    res, off, fam = synth_families(n, 300, family=family, seed=20250523 + seed_idx)
+    batch = engine.SeqBatch(ctx, res, off)
+    pipe = engine.Pipeline(ctx, lut, k)
+    out = pipe.step(batch)
+    ld = out.shape[1]
+    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+    rowptr, codes, counts, _ = pipe.csr.host()
+    assert (rowptr == o_rowptr).all() and (codes.astype(np.uint64) == o_codes).all() and (counts == o_counts).all()
+    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
+    assert pipe.basis.ncols == len(ob)
+    assert (pipe.csr.colidx.download(pipe.csr.nnz) == ocol).all()
+    rows = np.sort(np.random.default_rng(seed_idx).choice(n, size=nsample, replace=False))
+    ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), rows)
+    got = np.stack([out.download(n, offset=int(r) * ld) for r in rows])
+    assert np.abs(got - ref).max() <= COS_TOL
+    sub = got[:, rows]
+    assert np.abs(sub - sub.T).max() <= 2e-7
+    nz = np.diff(o_rowptr)[rows] > 0
+    assert np.abs(np.diag(sub)[nz] - 1.0).max() <= 1e-6
+    # checksum of checksums: total of the sampled rows equals the oracle's to float32 accumulation error
+    assert abs(float(got.sum(dtype=np.float64)) - float(ref.sum())) <= 1e-3 * max(1.0, float(ref.sum()))
+    return pipe
+
+
+def test_config3_full_size_100k_red6_k12(ctx):
+    """BASELINE configs[2], the benchmarked workload, at full size (40 GB result in HBM)."""
+    _sampled_row_check(ctx, "red6", 12, 100000, seed_idx=2)
+
+
+def test_config3_real_alphabet_standard_k12_u64_codes(ctx):
+    """Same shape with the nearest reference alphabet (`standard`, 7^12 needs uint64 codes)."""
+    _sampled_row_check(ctx, "standard", 12, 30000, seed_idx=2)
+
+
+def test_config5_hydro_k20_full_basis_stress(ctx):
+    """BASELINE configs[4] alphabet/k (2^20 basis, every column populated): rows have thousands of
+    neighbours, which exercises the cursor-kernel fallback at scale."""
+    _sampled_row_check(ctx, "hydro", 20, 20000, seed_idx=5, nsample=24)
