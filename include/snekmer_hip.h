@@ -171,6 +171,13 @@ int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint
                    const float *d_yrnorm, int64_t row0, int64_t row1, int mode, float *d_out,
                    int64_t ld);
 
+/* The reference's metric="jaccard" branch (snekmer/score.py:166-168) is 1 - hamming distance on the
+ * binary presence matrix: 1 - (|a| + |b| - 2|a&b|) / ncols.  Given d_out holding the exact
+ * intersection sizes |a&b| (skm_cosine_csr on a 0/1 CSR with all norms = 1), rewrite it in place.
+ * d_xcount[i], d_ycount[j] are the rows' set sizes as float. */
+int skm_hamming_similarity_from_gram(skm_ctx *ctx, int64_t n, int64_t m, int64_t ncols, const float *d_xcount,
+                                     const float *d_ycount, float *d_out, int64_t ld);
+
 /* Exact sum over columns of df*(df) pairs the sparse kernel will visit (cost model input). */
 int skm_pair_work(skm_ctx *ctx, int64_t ncols, const uint32_t *d_colptr, uint64_t *h_pairs);
 

@@ -104,6 +104,19 @@ __global__ void k_col_stats(int64_t ncols, const uint32_t *__restrict__ colptr, 
     }
 }
 
+__global__ void k_hamming_from_gram(int64_t n, int64_t m, float inv_cols, const float *__restrict__ xc,
+                                    const float *__restrict__ yc, float *__restrict__ out, int64_t ld)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m)
+        return;
+    const float cj = yc[j];
+    for (int64_t i = blockIdx.y; i < n; i += gridDim.y) {
+        const float g = out[i * ld + j];
+        out[i * ld + j] = 1.0f - (xc[i] + cj - 2.0f * g) * inv_cols;
+    }
+}
+
 __global__ void k_max_u32(int64_t n, const uint32_t *__restrict__ v, unsigned int *out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -455,6 +468,20 @@ extern "C" int skm_row_norms_csr(skm_ctx *ctx, int64_t n, const int64_t *d_rowpt
     k_row_norms<<<skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16), BLK, 0, ctx->stream>>>(n, d_rowptr, d_counts, d_rnorm,
                                                                                           d_normsq);
     return skm_check_launch("k_row_norms");
+}
+
+extern "C" int skm_hamming_similarity_from_gram(skm_ctx *ctx, int64_t n, int64_t m, int64_t ncols, const float *d_xcount,
+                                                const float *d_ycount, float *d_out, int64_t ld)
+{
+    SKM_REQUIRE(ctx && n >= 0 && m >= 0 && ncols > 0 && ld >= m, SKM_E_BADARG, "skm_hamming_similarity_from_gram: bad argument");
+    if (n == 0 || m == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_xcount && d_ycount && d_out, SKM_E_BADARG, "skm_hamming_similarity_from_gram: null array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    dim3 grid((unsigned)skm_ceil_div(m, BLK), (unsigned)(n < 1024 ? n : 1024));
+    SKM_PROF(ctx, "k_hamming_from_gram");
+    k_hamming_from_gram<<<grid, BLK, 0, ctx->stream>>>(n, m, 1.0f / (float)ncols, d_xcount, d_ycount, d_out, ld);
+    return skm_check_launch("k_hamming_from_gram");
 }
 
 extern "C" int skm_csr_max_count(skm_ctx *ctx, int64_t nnz, const uint32_t *d_counts, uint32_t *h_max)

@@ -228,8 +228,9 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
 #include "skm_gram_kernel.h"
 
 // ------------------------------------------------------------------------------- streaming writer
-template <int MODE, bool VEC>
-__global__ __launch_bounds__(TB) void k_cosine_write(const uint64_t *__restrict__ g_ent,
+// WR rows per workgroup, WCH columns per chunk, WCH/4 threads (4 columns per thread and chunk).
+template <int MODE, bool VEC, int WR, int WCH>
+__global__ __launch_bounds__(WCH / 4) void k_cosine_write(const uint64_t *__restrict__ g_ent,
                                                      const uint64_t *__restrict__ g_start,
                                                      const uint32_t *__restrict__ g_len,
                                                      const float *__restrict__ xrnorm,
@@ -237,6 +238,8 @@ __global__ __launch_bounds__(TB) void k_cosine_write(const uint64_t *__restrict_
                                                      int64_t row1, float *__restrict__ out, int64_t ld,
                                                      uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_count)
 {
+    constexpr int R = WR, CH = WCH, TB = WCH / 4, NW = TB / 64;
+    constexpr int RPW = (R + NW - 1) / NW;  // rows fed by each wave
     __shared__ __attribute__((aligned(16))) int s_acc[R][CH];
     __shared__ uint64_t s_start[R];
     __shared__ uint32_t s_len[R];
@@ -268,29 +271,34 @@ __global__ __launch_bounds__(TB) void k_cosine_write(const uint64_t *__restrict_
     __syncthreads();
     if (s_skip) {
         // some row of this strip exceeded the sparse kernel's capacities: leave it to the cursor kernel
-        if (tid == 0)
-            fb_list[atomicAdd(fb_count, 1u)] = blockIdx.x;
+        // (cursor strips are 8 rows; a strip listed twice is merely computed twice)
+        constexpr int CURSOR_R = 8;
+        if (tid < (R + CURSOR_R - 1) / CURSOR_R)
+            fb_list[atomicAdd(fb_count, 1u)] = (uint32_t)((i0 - row0) / CURSOR_R) + tid;
         return;
     }
 
     // each wave feeds two rows; it keeps a 64-entry window of the row's sorted neighbour list in
     // registers and reloads only when the window is used up
-    const int lrow[2] = {wid, wid + 4};
-    uint32_t wbase[2] = {0, 0};
-    uint64_t went[2];
+    int lrow[RPW];
+    uint32_t wbase[RPW];
+    uint64_t went[RPW];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const uint32_t e = wbase[u] + lane;
-        went[u] = e < s_len[lrow[u]] ? g_ent[s_start[lrow[u]] + e] : ~0ull;
+    for (int u = 0; u < RPW; ++u) {
+        lrow[u] = wid + u * NW;
+        wbase[u] = 0;
+        went[u] = ~0ull;
+        if (lrow[u] < R && (uint32_t)lane < s_len[lrow[u]])
+            went[u] = g_ent[s_start[lrow[u]] + lane];
     }
 
     for (int64_t j0 = 0; j0 < m; j0 += CH) {
         const int64_t j1 = min(j0 + (int64_t)CH, m);
         const uint32_t j1u = (uint32_t)j1, j0u = (uint32_t)j0;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < RPW; ++u) {
             const int li = lrow[u];
-            while (true) {
+            while (li < R) {
                 const uint32_t j = (uint32_t)(went[u] >> 32);
                 const bool take = went[u] != ~0ull && j >= j0u && j < j1u;
                 if (take)
@@ -421,12 +429,15 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     uint64_t *g_start = (uint64_t *)p;
     SKM_TRY(skm_ws(ctx, WS_C, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
     uint32_t *g_len = (uint32_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)(strips + 8), &p));
+    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)(2 * strips + 8), &p));
     uint32_t *fb_list = (uint32_t *)p;
     SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
     unsigned long long *g_counter = (unsigned long long *)((uint8_t *)p + 2048);
     uint32_t *fb_count = (uint32_t *)((uint8_t *)p + 2048 + 8);
+    uint32_t *over_count = (uint32_t *)((uint8_t *)p + 2048 + 12);
     SKM_HIP(hipMemsetAsync(g_counter, 0, 16, st));
+    SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
+    uint32_t *over_list = (uint32_t *)p;
     {
         SKM_PROF(ctx, "k_gram_sparse");
         const char *gabl_env = getenv("SKM_GRAM_ABLATE");  // diagnostic only: results NOT valid
@@ -435,7 +446,8 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         const int gvar = gvar_env ? atoi(gvar_env) : 0;
 #define SKM_LAUNCH_G(GABL, GR, GH, GT, GQ, SL)                                                                        \
     k_gram_sparse<GABL, GR, GH, GT, GQ, SL><<<(unsigned)skm_ceil_div(nrows, GR), GT, 0, st>>>(                          \
-        d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, (int)skm_ceil_div(m, CH), g_ent, cap_ent, g_counter, g_start, g_len)
+        d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, (int)skm_ceil_div(m, CH), g_ent, cap_ent, g_counter, g_start, g_len, \
+        over_list, over_count)
         if (gabl == 1)
             SKM_LAUNCH_G(1, 2, 4096, 512, 2, 4);
         else if (gabl == 2)
@@ -460,10 +472,29 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     }
     SKM_TRY(skm_check_launch("k_gram_sparse"));
     {
+        // rows with more neighbours than the small tables hold: 16384-slot table, one row per workgroup
+        SKM_PROF(ctx, "k_gram_sparse_big");
+        k_gram_sparse_big<16384, 512, 2, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
+            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, (int)skm_ceil_div(m, CH), g_ent, cap_ent,
+            g_counter, g_start, g_len, over_list, over_count);
+    }
+    SKM_TRY(skm_check_launch("k_gram_sparse_big"));
+    {
         SKM_PROF(ctx, "k_cosine_write");
-#define SKM_LAUNCH_W(MODE, VEC)                                                                                       \
-    k_cosine_write<MODE, VEC><<<(unsigned)strips, TB, 0, st>>>(g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, row1, \
-                                                                d_out, ld, fb_list, fb_count)
+        const char *wv_env = getenv("SKM_WRITE_VARIANT");  // tuning aid; every variant is exact
+        const int wv = wv_env ? atoi(wv_env) : 0;
+#define SKM_LAUNCH_WV(MODE, VEC, WR)                                                                                    \
+    k_cosine_write<MODE, VEC, WR, CH><<<(unsigned)skm_ceil_div(nrows, WR), CH / 4, 0, st>>>(                              \
+        g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, row1, d_out, ld, fb_list, fb_count)
+#define SKM_LAUNCH_W(MODE, VEC)                                                                                         \
+    do {                                                                                                                \
+        if (wv == 1)                                                                                                    \
+            SKM_LAUNCH_WV(MODE, VEC, 4);                                                                                \
+        else if (wv == 2)                                                                                               \
+            SKM_LAUNCH_WV(MODE, VEC, 16);                                                                               \
+        else                                                                                                            \
+            SKM_LAUNCH_WV(MODE, VEC, 8);                                                                                \
+    } while (0)
         if (mode == 0) {
             if (vec)
                 SKM_LAUNCH_W(0, true);
@@ -476,6 +507,7 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
                 SKM_LAUNCH_W(1, false);
         }
 #undef SKM_LAUNCH_W
+#undef SKM_LAUNCH_WV
     }
     SKM_TRY(skm_check_launch("k_cosine_write"));
     {

@@ -17,14 +17,15 @@ constexpr uint32_t G_OVERFLOW = 0xFFFFFFFFu;
 // GT    threads per workgroup        GQ  tasks per thread (GQ*GT non-zeros per strip)
 // SL    consecutive pairs a thread handles per step
 template <int GABL, int GR, int GH, int GT, int GQ, int SL>
-__global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ xrowptr,
+__device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__restrict__ xrowptr,
                                                     const uint32_t *__restrict__ xcolidx,
                                                     const uint32_t *__restrict__ xcounts,
                                                     const uint32_t *__restrict__ ycolptr,
                                                     const uint64_t *__restrict__ ypost, int64_t row0, int64_t row1,
                                                     int nchunk, uint64_t *__restrict__ g_ent, unsigned long long cap_ent,
                                                     unsigned long long *__restrict__ g_counter,
-                                                    uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len)
+                                                    uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len,
+                                                    uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_count)
 {
     constexpr int GTCAP = GQ * GT;
     constexpr int GMAXD = GH / 2;
@@ -41,8 +42,15 @@ __global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ 
     uint32_t *t_start = s_u, *t_scan = s_u + GTCAP, *t_liv = s_u + 2 * GTCAP + 1;
     uint32_t *hist = s_u;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int64_t i0 = row0 + (int64_t)blockIdx.x * GR;
     const int rows = (int)min((int64_t)GR, row1 - i0);
+    // rows this kernel cannot hold are flagged (and listed for the large-table pass)
+    auto flag_rows = [&]() {
+        if (tid < rows) {
+            g_len[i0 - row0 + tid] = G_OVERFLOW;
+            if (over_list)
+                over_list[atomicAdd(over_count, 1u)] = (uint32_t)(i0 - row0 + tid);
+        }
+    };
 
     if (tid <= GR)
         s_rp[tid] = xrowptr[i0 + (tid <= rows ? tid : rows)];
@@ -58,8 +66,7 @@ __global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ 
     const int64_t e0 = s_rp[0];
     const int64_t ntasks64 = s_rp[GR] - e0;
     if (ntasks64 > GTCAP) {
-        if (tid < rows)
-            g_len[i0 - row0 + tid] = G_OVERFLOW;
+        flag_rows();
         return;
     }
     const int ntasks = (int)ntasks64;
@@ -171,8 +178,7 @@ __global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ 
     }
     __syncthreads();
     if (s_over) {
-        if (tid < rows)
-            g_len[i0 - row0 + tid] = G_OVERFLOW;
+        flag_rows();
         return;
     }
     if (GABL == 2) {
@@ -231,5 +237,46 @@ __global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ 
     if (tid < rows) {
         g_start[i0 - row0 + tid] = s_off[tid];
         g_len[i0 - row0 + tid] = fits[tid] ? s_distinct[tid] : G_OVERFLOW;
+    }
+}
+
+// One strip of GR consecutive rows per workgroup.
+template <int GABL, int GR, int GH, int GT, int GQ, int SL>
+__global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ xrowptr,
+                                                    const uint32_t *__restrict__ xcolidx,
+                                                    const uint32_t *__restrict__ xcounts,
+                                                    const uint32_t *__restrict__ ycolptr,
+                                                    const uint64_t *__restrict__ ypost, int64_t row0, int64_t row1,
+                                                    int nchunk, uint64_t *__restrict__ g_ent, unsigned long long cap_ent,
+                                                    unsigned long long *__restrict__ g_counter,
+                                                    uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len,
+                                                    uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_count)
+{
+    gram_strip<GABL, GR, GH, GT, GQ, SL>(row0 + (int64_t)blockIdx.x * GR, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0,
+                                         row1, nchunk, g_ent, cap_ent, g_counter, g_start, g_len, over_list, over_count);
+}
+
+// Second pass with a large table (one row per workgroup) over the rows the first pass listed.
+// The grid is fixed; workgroups stride over the list, whose length is only known on the device.
+template <int GH, int GT, int GQ, int SL>
+__global__ __launch_bounds__(GT) void k_gram_sparse_big(const int64_t *__restrict__ xrowptr,
+                                                        const uint32_t *__restrict__ xcolidx,
+                                                        const uint32_t *__restrict__ xcounts,
+                                                        const uint32_t *__restrict__ ycolptr,
+                                                        const uint64_t *__restrict__ ypost, int64_t row0, int64_t row1,
+                                                        int nchunk, uint64_t *__restrict__ g_ent,
+                                                        unsigned long long cap_ent,
+                                                        unsigned long long *__restrict__ g_counter,
+                                                        uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len,
+                                                        const uint32_t *__restrict__ row_list,
+                                                        const uint32_t *__restrict__ row_count)
+{
+    const uint32_t cnt = *row_count;
+    for (uint32_t idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
+        const int64_t i0 = row0 + row_list[idx];
+        // a one-row strip: clamp row1 so that the strip never spills into the next row
+        gram_strip<0, 1, GH, GT, GQ, SL>(i0, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0, i0 + 1, nchunk, g_ent, cap_ent,
+                                         g_counter, g_start, g_len, nullptr, nullptr);
+        __syncthreads();
     }
 }

@@ -243,12 +243,24 @@ class KmerVec:
         Upstream's method of this name raises KeyError on its first iteration
         (snekmer/vectorize.py:282-285), so nothing can pin this; it implements the documented
         intent (:259-271).  Parity: unpinned."""
+        from . import engine
+
         lut = self._lut()
         ident = AlphabetLUT(np.arange(256, dtype=np.uint8), _rank_of_letters(lut), lut.letters)
-        kmers = self._windows_batch([str(sequence)], ident, strip=False)[0]
-        uniq, cnt = np.unique(kmers, return_counts=True) if kmers.size else (np.array([], dtype=str), np.array([], dtype=int))
-        lookup = dict(zip(uniq.tolist(), cnt.tolist()))
-        return np.array([lookup.get(str(w), 0) for w in self.kmer_set.kmers], dtype=np.int64)
+        seq = str(sequence)
+        if seq.endswith("*"):  # already-reduced input: a trailing '*' is an ordinary invalid character
+            seq += "\x00"
+        ctx = _ctx()
+        csr = engine.count_csr(ctx, engine.SeqBatch.from_strings(ctx, [seq]), ident, self.k)
+        _, codes, counts, _ = csr.host()
+        codes = codes.astype(np.uint64)
+        kmers = [str(w) for w in self.kmer_set.kmers]
+        want, ok = ident.encode(kmers, self.k)
+        if codes.size == 0:
+            return np.zeros(len(kmers), dtype=np.int64)
+        pos = np.clip(np.searchsorted(codes, want), 0, codes.size - 1)
+        hit = ok & (codes[pos] == want)
+        return np.where(hit, counts[pos], 0).astype(np.int64)
 
     def count_batch(self, sequences: Sequence[str], with_firstpos: bool = False):
         """Device-resident per-sequence (code, count) lists: see engine.count_csr."""

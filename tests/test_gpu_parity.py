@@ -81,6 +81,9 @@ def test_reduce_and_reduce_vectorize_edge_cases():
     assert skm.vectorize.reduce("MKVLAAGIWSTCX*", 1) == "AKAAAAAAFNNCX"
     assert list(kv._kmer_gen("VSVV*VVVS")) == ["VSVV", "VVVS"]
     assert list(kv._kmer_gen("VSVVV*")) == ["VSVV", "SVVV"]
+    # documented intent of the (upstream-broken) KmerVec.vectorize: counts in kmer_set order
+    kv.set_kmer_set(["VVVV", "VSVV", "SSSS", "SVVV", "VSV"])
+    assert kv.vectorize("VSVVVSVVV*").tolist() == [0, 2, 0, 2, 0]
 
 
 # ------------------------------------------------------------------ a12 counts, all size classes
@@ -283,6 +286,12 @@ def test_connection_matrix_and_feature_matrix_goldens(ctx):
     assert np.abs(D - g["cosine"]).max() <= COS_TOL
     with pytest.raises(NotImplementedError):
         skm.score.connection_matrix_from_features(g["X"] + 0.5, metric="cosine")
+    J = skm.score.connection_matrix_from_features(g["X"] > 0)  # default metric="jaccard" (= 1 - hamming upstream)
+    assert np.abs(J - g["jaccard"]).max() <= 1e-6
+    J2 = skm.score.connection_matrix_from_features((g["X"] > 0).astype(float), metric="jaccard")
+    assert (J2 == J).all()
+    with pytest.raises(NotImplementedError):
+        skm.score.connection_matrix_from_features(g["X"], metric="jaccard")  # non-binary counts
     for case in gjson("g7_feature_matrix.json"):
         rows, kl = skm.vectorize.make_feature_matrix([np.asarray(v, dtype=str) for v in case["vecs"]], case["min_filter"])
         assert [str(x) for x in kl] == case["kmerlist"]

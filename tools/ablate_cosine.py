@@ -22,16 +22,16 @@ ctx.sync()
 ctx.profile_enable(True)
 gres = {}
 for rnd in range(3):
-    for name, env in (("full", {}), ("no_pairs", {"SKM_GRAM_ABLATE": "1"}), ("no_emit", {"SKM_GRAM_ABLATE": "2"}),
+    for name, env in (("full", {}), ("w4", {"SKM_WRITE_VARIANT": "1"}), ("w16", {"SKM_WRITE_VARIANT": "2"}), ("no_pairs", {"SKM_GRAM_ABLATE": "1"}), ("no_emit", {"SKM_GRAM_ABLATE": "2"}),
                       ("v1", {"SKM_GRAM_VARIANT": "1"}), ("v2", {"SKM_GRAM_VARIANT": "2"}), ("v3", {"SKM_GRAM_VARIANT": "3"}),
                       ("v4", {"SKM_GRAM_VARIANT": "4"}), ("v5", {"SKM_GRAM_VARIANT": "5"}), ("v6", {"SKM_GRAM_VARIANT": "6"})):
-        for k in ("SKM_GRAM_ABLATE", "SKM_GRAM_VARIANT"):
+        for k in ("SKM_GRAM_ABLATE", "SKM_GRAM_VARIANT", "SKM_WRITE_VARIANT"):
             os.environ.pop(k, None)
         os.environ.update(env)
         ctx.profile_reset()
         pipe.cosine()
         gres.setdefault(name, []).append((ctx.profile_read("k_gram_sparse")[1], ctx.profile_read("k_cosine_write")[1], ctx.profile_read("k_cosine_strip")[1]))
-for k in ("SKM_GRAM_ABLATE", "SKM_GRAM_VARIANT"):
+for k in ("SKM_GRAM_ABLATE", "SKM_GRAM_VARIANT", "SKM_WRITE_VARIANT"):
     os.environ.pop(k, None)
 for name, v in gres.items():
     print(f"gram[{name}]: " + ", ".join(f"gram {a:.2f} write {b:.2f} cursor {c:.2f}" for a, b, c in v))
