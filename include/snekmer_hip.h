@@ -178,6 +178,21 @@ int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint
 int skm_hamming_similarity_from_gram(skm_ctx *ctx, int64_t n, int64_t m, int64_t ncols, const float *d_xcount,
                                      const float *d_ycount, float *d_out, int64_t ld);
 
+/* Apply epilogue (snekmer/rules/apply.smk:312-328, rules/learn.smk:831-849): for every row of a
+ * score matrix the two largest entries and their columns, i.e. np.argsort(-S, axis=1)[:, :2] with
+ * ties broken towards the lower column.  d_idx[2*i+{0,1}], d_val[2*i+{0,1}]; with m == 1 the
+ * second slot holds index 0xFFFFFFFF and value 0. */
+int skm_row_top2(skm_ctx *ctx, int64_t n, int64_t m, const float *d_scores, int64_t ld, uint32_t *d_idx,
+                 float *d_val);
+
+/* Learn aggregation (snekmer/rules/learn.smk:385-408): sum the count rows of each group
+ * (annotation).  Input CSR rows carry a group id < ngroups (d_group[n]); output is the CSR of the
+ * [ngroups x ncols] totals matrix with columns ascending per row: d_out_rowptr[ngroups+1],
+ * d_out_col / d_out_val with capacity nnz.  *h_out_nnz is host-synchronous. */
+int skm_csr_group_sum(skm_ctx *ctx, int64_t n, int64_t nnz, const int64_t *d_rowptr, const uint32_t *d_colidx,
+                      const uint32_t *d_counts, const uint32_t *d_group, int64_t ngroups, int64_t *d_out_rowptr,
+                      uint32_t *d_out_col, uint32_t *d_out_val, int64_t *h_out_nnz);
+
 /* Exact sum over columns of df*(df) pairs the sparse kernel will visit (cost model input). */
 int skm_pair_work(skm_ctx *ctx, int64_t ncols, const uint32_t *d_colptr, uint64_t *h_pairs);
 

@@ -473,3 +473,58 @@ def test_config5_hydro_k20_full_basis_stress(ctx):
     """BASELINE configs[4] alphabet/k (2^20 basis, every column populated): rows have thousands of
     neighbours, which exercises the cursor-kernel fallback at scale."""
     _sampled_row_check(ctx, "hydro", 20, 20000, seed_idx=5, nsample=24)
+
+
+# ------------------------------------------------------------------ learn/apply chain (next rows)
+@pytest.mark.parametrize("tag", ["hydro_k14_mf0", "standard_k8_mf0", "solvacc_k8_mf0"])
+def test_group_sum_cosine_vs_totals_and_top2(ctx, tag):
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import apply as skm_apply
+    from snekmer_amd import engine
+    from snekmer_amd.utils import pack_sequences
+
+    alphabet, k, _ = parse_tag(tag)
+    g = gnpz(f"g3_demo_{tag}.npz")
+    lut = A.build_lut(alphabet)
+    recs = demo_records()
+    res, off = pack_sequences([s for _, s in recs])
+    batch = engine.SeqBatch(ctx, res, off)
+    csr = engine.count_csr(ctx, batch, lut, k, with_firstpos=True)
+    basis = engine.build_basis(ctx, csr, lut.nsym, k, first_seen=True, postings=False)
+    groups = g["file_of"]
+    out = skm_apply.learn_apply(ctx, csr, basis.ncols, groups, 2)
+    # totals: compare in first-seen column order against the golden per-file sums
+    fs = basis.fs_order.download(basis.ncols).astype(np.int64)
+    rank = np.empty(basis.ncols, dtype=np.int64)
+    rank[fs] = np.arange(basis.ncols)
+    t = out["totals"]
+    rp = t.rowptr.download(3)
+    col, val = t.colidx.download(t.nnz), t.counts.download(t.nnz)
+    dense = np.zeros((2, basis.ncols), dtype=np.int64)
+    for r in range(2):
+        seg = slice(int(rp[r]), int(rp[r + 1]))
+        assert (np.diff(col[seg].astype(np.int64)) > 0).all()
+        dense[r, rank[col[seg]]] = val[seg]
+    assert (dense == g["totals"]).all()
+    n = batch.n
+    S = out["scores"].download().reshape(-1, out["ld"])[:n, :2]
+    assert np.abs(S - g["cosine_rect"]).max() <= COS_TOL
+    order = np.argsort(-g["cosine_rect"], axis=1, kind="stable")[:, :2]
+    assert (out["top2_index"] == order).all()
+    ref_val = np.take_along_axis(g["cosine_rect"], order, axis=1)
+    assert np.abs(out["top2_score"] - ref_val).max() <= COS_TOL
+    assert np.abs(out["delta"] - np.round(ref_val[:, 0] - ref_val[:, 1], 2)).max() <= 0.01 + 1e-9
+
+
+def test_row_top2_ties_and_edges(ctx):
+    from snekmer_amd import apply as skm_apply
+
+    rng = np.random.default_rng(1)
+    n, m, ld = 37, 301, 304
+    S = rng.integers(0, 6, size=(n, ld)).astype(np.float32) / 5.0  # many ties
+    d = ctx.to_device(S)
+    idx, val = skm_apply.row_top2(ctx, d, n, m, ld)
+    order = np.argsort(-S[:, :m], axis=1, kind="stable")[:, :2]
+    assert (idx == order).all() and (val == np.take_along_axis(S[:, :m], order, axis=1)).all()
+    idx1, val1 = skm_apply.row_top2(ctx, d, n, 1, ld)
+    assert (idx1[:, 0] == 0).all() and (idx1[:, 1] == 0xFFFFFFFF).all() and (val1[:, 1] == 0).all()
