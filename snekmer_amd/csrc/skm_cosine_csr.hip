@@ -466,8 +466,8 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
             SKM_LAUNCH_G(0, 2, 4096, 512, 2, 2);
         else if (gvar == 7)
             SKM_LAUNCH_G(0, 2, 4096, 512, 2, 4);
-        else
-            SKM_LAUNCH_G(0, 1, 4096, 256, 2, 4);
+        else  // default: one row per workgroup, 2048 slots (22 KB of LDS -> 7 workgroups per CU)
+            SKM_LAUNCH_G(0, 1, 2048, 256, 2, 4);
 #undef SKM_LAUNCH_G
     }
     SKM_TRY(skm_check_launch("k_gram_sparse"));
@@ -489,11 +489,11 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
 #define SKM_LAUNCH_W(MODE, VEC)                                                                                         \
     do {                                                                                                                \
         if (wv == 1)                                                                                                    \
-            SKM_LAUNCH_WV(MODE, VEC, 4);                                                                                \
+            SKM_LAUNCH_WV(MODE, VEC, 8);                                                                                \
         else if (wv == 2)                                                                                               \
             SKM_LAUNCH_WV(MODE, VEC, 16);                                                                               \
         else                                                                                                            \
-            SKM_LAUNCH_WV(MODE, VEC, 8);                                                                                \
+            SKM_LAUNCH_WV(MODE, VEC, 4);                                                                                \
     } while (0)
         if (mode == 0) {
             if (vec)

@@ -30,11 +30,11 @@ for rnd in range(3):
         os.environ.update(env)
         ctx.profile_reset()
         pipe.cosine()
-        gres.setdefault(name, []).append((ctx.profile_read("k_gram_sparse")[1], ctx.profile_read("k_cosine_write")[1], ctx.profile_read("k_cosine_strip")[1]))
+        gres.setdefault(name, []).append((ctx.profile_read("k_gram_sparse")[1], ctx.profile_read("k_cosine_write")[1], ctx.profile_read("k_cosine_strip")[1], ctx.profile_read("k_gram_sparse_big")[1]))
 for k in ("SKM_GRAM_ABLATE", "SKM_GRAM_VARIANT", "SKM_WRITE_VARIANT"):
     os.environ.pop(k, None)
 for name, v in gres.items():
-    print(f"gram[{name}]: " + ", ".join(f"gram {a:.2f} write {b:.2f} cursor {c:.2f}" for a, b, c in v))
+    print(f"gram[{name}]: " + ", ".join(f"gram {a:.2f} big {d:.2f} write {b:.2f} cursor {c:.2f}" for a, b, c, d in v))
 results = {}
 for rnd in range(0):
     for abl in (0, 1, 2, 3):
