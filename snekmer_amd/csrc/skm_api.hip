@@ -46,6 +46,7 @@ extern "C" int skm_create(int device_id, skm_ctx **out_ctx)
     SKM_HIP(hipGetDeviceProperties(&prop, device_id));
     ctx->num_cus = prop.multiProcessorCount;
     SKM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    SKM_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     SKM_HIP(hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocDefault));
     *out_ctx = ctx;
     return SKM_OK;
@@ -69,6 +70,12 @@ extern "C" int skm_destroy(skm_ctx *ctx)
             hipFree(ctx->ws[i]);
     if (ctx->h_pinned)
         hipHostFree(ctx->h_pinned);
+    for (auto e : ctx->sync_events)
+        hipEventDestroy(e);
+    if (ctx->aux_stream) {
+        hipStreamSynchronize(ctx->aux_stream);
+        hipStreamDestroy(ctx->aux_stream);
+    }
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return SKM_OK;
@@ -77,6 +84,7 @@ extern "C" int skm_destroy(skm_ctx *ctx)
 extern "C" int skm_sync(skm_ctx *ctx)
 {
     SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    SKM_HIP(hipStreamSynchronize(ctx->aux_stream));
     SKM_HIP(hipStreamSynchronize(ctx->stream));
     return SKM_OK;
 }
@@ -184,7 +192,7 @@ int skm_ws(skm_ctx *ctx, int slot, size_t bytes, void **out)
 }
 
 // ---------------------------------------------------------------------------- profiling
-skm_prof_scope::skm_prof_scope(skm_ctx *c, const char *name) : ctx(c)
+skm_prof_scope::skm_prof_scope(skm_ctx *c, const char *name, hipStream_t on) : ctx(c), st(on ? on : c->stream)
 {
     if (!ctx->profiling)
         return;
@@ -200,7 +208,7 @@ skm_prof_scope::skm_prof_scope(skm_ctx *c, const char *name) : ctx(c)
     };
     take(&ent.start);
     take(&ent.stop);
-    hipEventRecord(ent.start, ctx->stream);
+    hipEventRecord(ent.start, st);
     stop = ent.stop;
     ctx->prof.push_back(ent);
 }
@@ -208,7 +216,7 @@ skm_prof_scope::skm_prof_scope(skm_ctx *c, const char *name) : ctx(c)
 skm_prof_scope::~skm_prof_scope()
 {
     if (stop)
-        hipEventRecord(stop, ctx->stream);
+        hipEventRecord(stop, st);
 }
 
 extern "C" int skm_profile_enable(skm_ctx *ctx, int on)

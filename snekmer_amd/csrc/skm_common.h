@@ -51,6 +51,8 @@ struct skm_prof_entry {
 struct skm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;  // producer side of the gram/writer overlap (skm_cosine_csr)
+    std::vector<hipEvent_t> sync_events;
     int num_cus = 0;
     void *ws[WS_COUNT] = {};
     size_t ws_bytes[WS_COUNT] = {};
@@ -69,13 +71,15 @@ int skm_ws(skm_ctx *ctx, int slot, size_t bytes, void **out);
 // RAII bracket that records start/stop events around a launch when profiling is on.
 struct skm_prof_scope {
     skm_ctx *ctx;
+    hipStream_t st;
     hipEvent_t stop = nullptr;
-    skm_prof_scope(skm_ctx *c, const char *name);
+    skm_prof_scope(skm_ctx *c, const char *name, hipStream_t on = nullptr);
     ~skm_prof_scope();
 };
 #define SKM_CAT2(a, b) a##b
 #define SKM_CAT(a, b) SKM_CAT2(a, b)
 #define SKM_PROF(ctx, name) skm_prof_scope SKM_CAT(_prof_scope_, __LINE__)(ctx, name)
+#define SKM_PROF_ON(ctx, name, stream) skm_prof_scope SKM_CAT(_prof_scope_, __LINE__)(ctx, name, stream)
 
 static inline int skm_check_launch(const char *what)
 {

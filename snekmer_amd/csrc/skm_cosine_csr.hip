@@ -415,13 +415,21 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         return skm_check_launch("k_cosine_strip");
     }
 
-    // ---- fast path: sparse Gram -> streaming writer -> cursor kernel for flagged strips
+    // ---- fast path: sparse Gram -> streaming writer -> cursor kernel for flagged strips.
+    // Optional (SKM_COSINE_OVERLAP=1): cut the rows into blocks and produce block b's neighbour
+    // lists on the auxiliary stream while block b-1 is written on the main stream.  Measured on
+    // MI355X this LOSES (14.1 vs 13.1 ms/step at config 3): the Gram workgroups fill the CUs' LDS
+    // and wave slots and starve the writer, so the default is one block on one stream.
     int64_t *h_rp = (int64_t *)ctx->h_pinned;
     SKM_HIP(hipMemcpyAsync(h_rp, d_xrowptr + row0, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     SKM_HIP(hipMemcpyAsync(h_rp + 1, d_xrowptr + row1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     SKM_HIP(hipStreamSynchronize(st));
     const int64_t xnnz = h_rp[1] - h_rp[0];
     const unsigned long long cap_ent = (unsigned long long)(8 * xnnz + (1 << 20));
+    const char *ov_env = getenv("SKM_COSINE_OVERLAP");
+    const bool overlap = ov_env && atoi(ov_env) == 1 && nrows >= 4096;
+    constexpr int MAXB = 16;
+    const int nblk = overlap ? 8 : 1;
     void *p;
     SKM_TRY(skm_ws(ctx, WS_A, sizeof(uint64_t) * (size_t)cap_ent, &p));
     uint64_t *g_ent = (uint64_t *)p;
@@ -429,63 +437,80 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     uint64_t *g_start = (uint64_t *)p;
     SKM_TRY(skm_ws(ctx, WS_C, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
     uint32_t *g_len = (uint32_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)(2 * strips + 8), &p));
+    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)(2 * strips + 8 * MAXB), &p));
     uint32_t *fb_list = (uint32_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
-    unsigned long long *g_counter = (unsigned long long *)((uint8_t *)p + 2048);
-    uint32_t *fb_count = (uint32_t *)((uint8_t *)p + 2048 + 8);
-    uint32_t *over_count = (uint32_t *)((uint8_t *)p + 2048 + 12);
-    SKM_HIP(hipMemsetAsync(g_counter, 0, 16, st));
     SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
     uint32_t *over_list = (uint32_t *)p;
-    {
-        SKM_PROF(ctx, "k_gram_sparse");
-        const char *gabl_env = getenv("SKM_GRAM_ABLATE");  // diagnostic only: results NOT valid
-        const int gabl = gabl_env ? atoi(gabl_env) : 0;
-        const char *gvar_env = getenv("SKM_GRAM_VARIANT");  // tuning aid; every variant is exact
-        const int gvar = gvar_env ? atoi(gvar_env) : 0;
+    SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
+    unsigned long long *g_counter = (unsigned long long *)((uint8_t *)p + 2048);
+    uint32_t *fb_counts = (uint32_t *)((uint8_t *)p + 2048 + 8);            // [MAXB]
+    uint32_t *over_counts = (uint32_t *)((uint8_t *)p + 2048 + 8 + 4 * MAXB);  // [MAXB]
+    SKM_HIP(hipMemsetAsync(g_counter, 0, 8 + 8 * MAXB, st));
+    hipStream_t sg = overlap ? ctx->aux_stream : st;
+    while ((int)ctx->sync_events.size() < MAXB + 1) {
+        hipEvent_t ev;
+        SKM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->sync_events.push_back(ev);
+    }
+    if (overlap) {  // the producer stream starts after everything already queued on the main stream
+        SKM_HIP(hipEventRecord(ctx->sync_events[MAXB], st));
+        SKM_HIP(hipStreamWaitEvent(sg, ctx->sync_events[MAXB], 0));
+    }
+    const char *gabl_env = getenv("SKM_GRAM_ABLATE");  // diagnostic only: results NOT valid
+    const int gabl = gabl_env ? atoi(gabl_env) : 0;
+    const char *gvar_env = getenv("SKM_GRAM_VARIANT");  // tuning aids; every variant is exact
+    const int gvar = gvar_env ? atoi(gvar_env) : 0;
+    const char *wv_env = getenv("SKM_WRITE_VARIANT");
+    const int wv = wv_env ? atoi(wv_env) : 0;
+    const int nchunk = (int)skm_ceil_div(m, CH);
+    // block boundaries on multiples of 16 rows (writer strips are 4, 8 or 16 rows; cursor strips 8)
+    const int64_t per = (skm_ceil_div(nrows, nblk) + 15) / 16 * 16;
+    for (int b = 0; b < nblk; ++b) {
+        const int64_t r0 = row0 + (int64_t)b * per, r1 = min(row1, r0 + per);
+        if (r0 >= r1)
+            break;
+        const int64_t rows_b = r1 - r0, rel = r0 - row0;
+        uint64_t *gs = g_start + rel;
+        uint32_t *gl = g_len + rel;
+        uint32_t *ol = over_list + rel, *oc = over_counts + b;
+        uint32_t *fl = fb_list + 2 * (rel / R) + 8 * b, *fc = fb_counts + b;
+        float *outb = d_out + rel * ld;
+        {
+            SKM_PROF_ON(ctx, "k_gram_sparse", sg);
 #define SKM_LAUNCH_G(GABL, GR, GH, GT, GQ, SL)                                                                        \
-    k_gram_sparse<GABL, GR, GH, GT, GQ, SL><<<(unsigned)skm_ceil_div(nrows, GR), GT, 0, st>>>(                          \
-        d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, (int)skm_ceil_div(m, CH), g_ent, cap_ent, g_counter, g_start, g_len, \
-        over_list, over_count)
-        if (gabl == 1)
-            SKM_LAUNCH_G(1, 2, 4096, 512, 2, 4);
-        else if (gabl == 2)
-            SKM_LAUNCH_G(2, 2, 4096, 512, 2, 4);
-        else if (gvar == 1)
-            SKM_LAUNCH_G(0, 1, 4096, 256, 2, 4);
-        else if (gvar == 2)
-            SKM_LAUNCH_G(0, 2, 2048, 512, 2, 4);
-        else if (gvar == 3)
-            SKM_LAUNCH_G(0, 2, 4096, 512, 2, 8);
-        else if (gvar == 4)
-            SKM_LAUNCH_G(0, 1, 4096, 256, 2, 8);
-        else if (gvar == 5)
-            SKM_LAUNCH_G(0, 1, 2048, 256, 2, 4);
-        else if (gvar == 6)
-            SKM_LAUNCH_G(0, 2, 4096, 512, 2, 2);
-        else if (gvar == 7)
-            SKM_LAUNCH_G(0, 2, 4096, 512, 2, 4);
-        else  // default: one row per workgroup, 2048 slots (22 KB of LDS -> 7 workgroups per CU)
-            SKM_LAUNCH_G(0, 1, 2048, 256, 2, 4);
+    k_gram_sparse<GABL, GR, GH, GT, GQ, SL><<<(unsigned)skm_ceil_div(rows_b, GR), GT, 0, sg>>>(                         \
+        d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, r0, r1, nchunk, g_ent, cap_ent, g_counter, gs, gl, ol, oc)
+            if (gabl == 1)
+                SKM_LAUNCH_G(1, 1, 2048, 256, 2, 4);
+            else if (gabl == 2)
+                SKM_LAUNCH_G(2, 1, 2048, 256, 2, 4);
+            else if (gvar == 1)
+                SKM_LAUNCH_G(0, 1, 4096, 256, 2, 4);
+            else if (gvar == 2)
+                SKM_LAUNCH_G(0, 2, 2048, 512, 2, 4);
+            else if (gvar == 7)
+                SKM_LAUNCH_G(0, 2, 4096, 512, 2, 4);
+            else  // default: one row per workgroup, 2048 slots (22 KB of LDS -> 7 workgroups per CU)
+                SKM_LAUNCH_G(0, 1, 2048, 256, 2, 4);
 #undef SKM_LAUNCH_G
-    }
-    SKM_TRY(skm_check_launch("k_gram_sparse"));
-    {
-        // rows with more neighbours than the small tables hold: 16384-slot table, one row per workgroup
-        SKM_PROF(ctx, "k_gram_sparse_big");
-        k_gram_sparse_big<16384, 512, 2, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
-            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, (int)skm_ceil_div(m, CH), g_ent, cap_ent,
-            g_counter, g_start, g_len, over_list, over_count);
-    }
-    SKM_TRY(skm_check_launch("k_gram_sparse_big"));
-    {
-        SKM_PROF(ctx, "k_cosine_write");
-        const char *wv_env = getenv("SKM_WRITE_VARIANT");  // tuning aid; every variant is exact
-        const int wv = wv_env ? atoi(wv_env) : 0;
+        }
+        SKM_TRY(skm_check_launch("k_gram_sparse"));
+        {
+            // rows with more neighbours than the small tables hold: 16384-slot table, one row per workgroup
+            SKM_PROF_ON(ctx, "k_gram_sparse_big", sg);
+            k_gram_sparse_big<16384, 512, 2, 4><<<skm_grid_cap(ctx, rows_b, 1), 512, 0, sg>>>(
+                d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, r0, r1, nchunk, g_ent, cap_ent, g_counter, gs, gl, ol, oc);
+        }
+        SKM_TRY(skm_check_launch("k_gram_sparse_big"));
+        if (overlap) {
+            SKM_HIP(hipEventRecord(ctx->sync_events[b], sg));
+            SKM_HIP(hipStreamWaitEvent(st, ctx->sync_events[b], 0));
+        }
+        {
+            SKM_PROF(ctx, "k_cosine_write");
 #define SKM_LAUNCH_WV(MODE, VEC, WR)                                                                                    \
-    k_cosine_write<MODE, VEC, WR, CH><<<(unsigned)skm_ceil_div(nrows, WR), CH / 4, 0, st>>>(                              \
-        g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, row1, d_out, ld, fb_list, fb_count)
+    k_cosine_write<MODE, VEC, WR, CH><<<(unsigned)skm_ceil_div(rows_b, WR), CH / 4, 0, st>>>(                             \
+        g_ent, gs, gl, d_xrnorm, d_yrnorm, m, r0, r1, outb, ld, fl, fc)
 #define SKM_LAUNCH_W(MODE, VEC)                                                                                         \
     do {                                                                                                                \
         if (wv == 1)                                                                                                    \
@@ -495,34 +520,40 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         else                                                                                                            \
             SKM_LAUNCH_WV(MODE, VEC, 4);                                                                                \
     } while (0)
-        if (mode == 0) {
-            if (vec)
-                SKM_LAUNCH_W(0, true);
-            else
-                SKM_LAUNCH_W(0, false);
-        } else {
-            if (vec)
-                SKM_LAUNCH_W(1, true);
-            else
-                SKM_LAUNCH_W(1, false);
-        }
+            if (mode == 0) {
+                if (vec)
+                    SKM_LAUNCH_W(0, true);
+                else
+                    SKM_LAUNCH_W(0, false);
+            } else {
+                if (vec)
+                    SKM_LAUNCH_W(1, true);
+                else
+                    SKM_LAUNCH_W(1, false);
+            }
 #undef SKM_LAUNCH_W
 #undef SKM_LAUNCH_WV
-    }
-    SKM_TRY(skm_check_launch("k_cosine_write"));
-    {
-        // strips flagged by the two kernels above; the grid is the worst case, surplus workgroups exit at once
-        SKM_PROF(ctx, "k_cosine_strip");
-        if (mode == 0) {
-            if (vec)
-                SKM_LAUNCH_A(0, true, 0, strips, fb_list, fb_count);
-            else
-                SKM_LAUNCH_A(0, false, 0, strips, fb_list, fb_count);
-        } else {
-            if (vec)
-                SKM_LAUNCH_A(1, true, 0, strips, fb_list, fb_count);
-            else
-                SKM_LAUNCH_A(1, false, 0, strips, fb_list, fb_count);
+        }
+        SKM_TRY(skm_check_launch("k_cosine_write"));
+        {
+            // strips flagged by the kernels above; worst-case grid, surplus workgroups exit at once
+            SKM_PROF(ctx, "k_cosine_strip");
+            const int64_t strips_b = skm_ceil_div(rows_b, R);
+#define SKM_LAUNCH_C(MODE, VEC)                                                                                       \
+    k_cosine_strip<MODE, VEC, 0><<<(unsigned)strips_b, TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m,      \
+                                                                     d_ycolptr, d_ypost, d_yrnorm, r0, r1, outb, ld, fl, fc)
+            if (mode == 0) {
+                if (vec)
+                    SKM_LAUNCH_C(0, true);
+                else
+                    SKM_LAUNCH_C(0, false);
+            } else {
+                if (vec)
+                    SKM_LAUNCH_C(1, true);
+                else
+                    SKM_LAUNCH_C(1, false);
+            }
+#undef SKM_LAUNCH_C
         }
     }
 #undef SKM_LAUNCH_A
