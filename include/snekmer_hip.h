@@ -120,8 +120,13 @@ int skm_count_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code
  *   d_fs_order[B]     basis columns listed in first-seen order (needs d_firstpos)
  *   d_colptr[nnz+1], d_post[nnz]   the same matrix column-major (postings: for each basis column
  *                     the rows holding it, ascending; entry = row | (uint64)count << 32);
- *                     only d_colptr[0..B] is meaningful. */
-int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int64_t n, int64_t nnz, const int64_t *d_rowptr,
+ *                     only d_colptr[0..B] is meaningful.
+ * flags: SKM_BASIS_ELIDE_SINGLETONS (only with postings and without df/total/first-seen outputs):
+ *   k-mers found in a single sequence can only ever contribute to that row's own norm, so their
+ *   CSR entries get d_colidx = 0xFFFFFFFF and no posting is written for them; skm_cosine_csr treats
+ *   such an entry as "pairs with its own row only".  Saves a third of the random traffic. */
+#define SKM_BASIS_ELIDE_SINGLETONS 1
+int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int flags, int64_t n, int64_t nnz, const int64_t *d_rowptr,
                     const void *d_codes, const uint32_t *d_counts, const uint32_t *d_firstpos,
                     int64_t *h_ncols, void *d_basis, uint32_t *d_colidx, uint32_t *d_df,
                     uint64_t *d_total, uint64_t *d_firstkey, uint32_t *d_fs_order,

@@ -61,7 +61,7 @@ _SIGNATURES = {
     ),
     "skm_basis_build": (
         C.c_int,
-        [_p, C.c_int, C.c_int, _i64, _i64, _p, _p, _p, _p, C.POINTER(_i64), _p, _p, _p, _p, _p, _p, _p, _p],
+        [_p, C.c_int, C.c_int, C.c_int, _i64, _i64, _p, _p, _p, _p, C.POINTER(_i64), _p, _p, _p, _p, _p, _p, _p, _p],
     ),
     "skm_csr_transpose": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p]),
     "skm_csr_concat_rowptr": (C.c_int, [_p, C.c_int, _p, _p, _p, _p]),

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(BLK) void k_basis_scatter(int64_t nnz, const K *__r
                                                        const uint32_t *__restrict__ firstpos,
                                                        K *__restrict__ basis, uint32_t *__restrict__ colidx,
                                                        uint32_t *__restrict__ colptr, uint64_t *__restrict__ post,
-                                                       uint64_t *__restrict__ firstkey)
+                                                       uint64_t *__restrict__ firstkey, int elide)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -70,6 +70,14 @@ __global__ __launch_bounds__(BLK) void k_basis_scatter(int64_t nnz, const K *__r
         const uint32_t e = sidx[t];
         const K key = skeys[t];
         const bool head = t == 0 || skeys[t - 1] != key;
+        if (elide && head && (t == nnz - 1 || skeys[t + 1] != key)) {
+            // a k-mer seen in one sequence only: no posting, colidx stays 0xFFFFFFFF (pre-filled)
+            if (basis)
+                basis[c] = key;
+            if (colptr)
+                colptr[c] = (uint32_t)t;
+            continue;
+        }
         colidx[e] = c;
         uint32_t row = 0;
         if (post || (head && firstkey))
@@ -340,7 +348,7 @@ int sort_pairs(skm_ctx *ctx, const K *kin, K *kout, const uint32_t *vin, uint32_
 }
 
 template <typename K>
-int basis_impl(skm_ctx *ctx, int key_bits, int64_t n, int64_t nnz, const int64_t *d_rowptr, const K *d_codes,
+int basis_impl(skm_ctx *ctx, int key_bits, int flags, int64_t n, int64_t nnz, const int64_t *d_rowptr, const K *d_codes,
                const uint32_t *d_counts, const uint32_t *d_firstpos, int64_t *h_ncols, K *d_basis, uint32_t *d_colidx,
                uint32_t *d_df, uint64_t *d_total, uint64_t *d_firstkey, uint32_t *d_fs_order, uint32_t *d_colptr,
                uint64_t *d_post)
@@ -395,10 +403,13 @@ int basis_impl(skm_ctx *ctx, int key_bits, int64_t n, int64_t nnz, const int64_t
         SKM_PROF(ctx, "rocprim_scan_heads");
         SKM_HIP(rocprim::inclusive_scan(p, tmp, in, colid1, (size_t)nnz, rocprim::plus<uint32_t>(), st));
     }
+    const int elide = (flags & SKM_BASIS_ELIDE_SINGLETONS) ? 1 : 0;
+    if (elide)
+        SKM_HIP(hipMemsetAsync(d_colidx, 0xFF, sizeof(uint32_t) * (size_t)nnz, st));
     {
         SKM_PROF(ctx, "k_basis_scatter");
         k_basis_scatter<K><<<g_ent, BLK, 0, st>>>(nnz, skeys, sidx, colid1, rowid, d_counts, d_firstpos, d_basis,
-                                                   d_colidx, colptr, post, firstkey);
+                                                   d_colidx, colptr, post, firstkey, elide);
     }
     SKM_TRY(skm_check_launch("k_basis_scatter"));
     uint32_t *h_b = (uint32_t *)ctx->h_pinned;
@@ -426,7 +437,7 @@ int basis_impl(skm_ctx *ctx, int key_bits, int64_t n, int64_t nnz, const int64_t
 
 }  // namespace
 
-extern "C" int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int64_t n, int64_t nnz,
+extern "C" int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int flags, int64_t n, int64_t nnz,
                                const int64_t *d_rowptr, const void *d_codes, const uint32_t *d_counts,
                                const uint32_t *d_firstpos, int64_t *h_ncols, void *d_basis, uint32_t *d_colidx,
                                uint32_t *d_df, uint64_t *d_total, uint64_t *d_firstkey, uint32_t *d_fs_order,
@@ -436,6 +447,8 @@ extern "C" int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int64_
     SKM_REQUIRE(code_bits == 32 || code_bits == 64, SKM_E_BADARG, "skm_basis_build: code_bits must be 32 or 64");
     SKM_REQUIRE(nnz < ((int64_t)1 << 32) - 1, SKM_E_OVERFLOW, "skm_basis_build: nnz >= 2^32; split the batch");
     SKM_REQUIRE(!d_fs_order || d_firstpos, SKM_E_BADARG, "skm_basis_build: d_fs_order needs d_firstpos");
+    SKM_REQUIRE(!(flags & SKM_BASIS_ELIDE_SINGLETONS) || (d_post && !d_df && !d_total && !d_firstkey && !d_fs_order),
+                SKM_E_BADARG, "skm_basis_build: ELIDE_SINGLETONS needs postings and no df/total/first-seen outputs");
     *h_ncols = 0;
     if (nnz == 0) {
         if (d_colptr)
@@ -447,10 +460,10 @@ extern "C" int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int64_
         key_bits = code_bits;
     SKM_HIP(hipSetDevice(ctx->device));
     if (code_bits == 32)
-        return basis_impl<uint32_t>(ctx, key_bits, n, nnz, d_rowptr, (const uint32_t *)d_codes, d_counts, d_firstpos,
+        return basis_impl<uint32_t>(ctx, key_bits, flags, n, nnz, d_rowptr, (const uint32_t *)d_codes, d_counts, d_firstpos,
                                     h_ncols, (uint32_t *)d_basis, d_colidx, d_df, d_total, d_firstkey, d_fs_order,
                                     d_colptr, d_post);
-    return basis_impl<uint64_t>(ctx, key_bits, n, nnz, d_rowptr, (const uint64_t *)d_codes, d_counts, d_firstpos,
+    return basis_impl<uint64_t>(ctx, key_bits, flags, n, nnz, d_rowptr, (const uint64_t *)d_codes, d_counts, d_firstpos,
                                 h_ncols, (uint64_t *)d_basis, d_colidx, d_df, d_total, d_firstkey, d_fs_order, d_colptr,
                                 d_post);
 }

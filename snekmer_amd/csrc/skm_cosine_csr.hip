@@ -100,14 +100,20 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
                 li += (e >= s_rp[r]) ? 1 : 0;
             const uint32_t c = xcolidx[e];
             const uint32_t v = xcounts[e];
-            const uint32_t pb = ycolptr[c], pe = ycolptr[c + 1];
-            cur[q] = pb;
-            rem[q] = pe - pb;
             liv[q] = ((uint32_t)li << 28) | (v & 0x0FFFFFFFu);
-            if (pe > pb) {
-                const uint64_t pw = ypost[pb];
-                nj[q] = (uint32_t)pw;
-                nv[q] = (uint32_t)(pw >> 32);
+            if (c == 0xFFFFFFFFu) {  // singleton k-mer (ELIDE_SINGLETONS): pairs with its own row only
+                rem[q] = 1;
+                nj[q] = (uint32_t)(i0 + li);
+                nv[q] = v;
+            } else {
+                const uint32_t pb = ycolptr[c], pe = ycolptr[c + 1];
+                cur[q] = pb;
+                rem[q] = pe - pb;
+                if (pe > pb) {
+                    const uint64_t pw = ypost[pb];
+                    nj[q] = (uint32_t)pw;
+                    nv[q] = (uint32_t)(pw >> 32);
+                }
             }
         }
     }
@@ -156,6 +162,12 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
                 li += (e >= s_rp[r]) ? 1 : 0;
             const uint32_t c = xcolidx[e];
             const int v = (int)xcounts[e];
+            if (c == 0xFFFFFFFFu) {
+                const uint32_t j = (uint32_t)(i0 + li);
+                if (j >= j0u && j < j1u)
+                    atomicAdd(&s_acc[li][j - j0u], v * v);
+                continue;
+            }
             uint32_t lo = ycolptr[c], hi = ycolptr[c + 1];
             const uint32_t pe = hi;
             while (lo < hi) {

@@ -11,6 +11,7 @@
 
 constexpr int GNB = 1024;  // output chunks (of CH columns) a neighbour list can be grouped by
 constexpr uint32_t G_OVERFLOW = 0xFFFFFFFFu;
+constexpr uint32_t G_SINGLETON = 0xFFFFFFFFu;  // colidx of a k-mer that occurs in one row only
 
 // GABL  diagnostic ablation (0 = real kernel)
 // GR    rows per workgroup           GH  hash slots per row (at most GH/2 distinct neighbours)
@@ -85,10 +86,15 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
             for (int r = 1; r < GR; ++r)
                 li += (e >= s_rp[r]) ? 1 : 0;
             const uint32_t c = xcolidx[e];
-            const uint32_t pb = ycolptr[c], pe = ycolptr[c + 1];
-            t_start[t] = pb;
             t_liv[t] = ((uint32_t)li << 28) | (xcounts[e] & 0x0FFFFFFFu);
-            mydf[q] = pe - pb;
+            if (c == G_SINGLETON) {  // k-mer of this row only (skm_basis_build, ELIDE_SINGLETONS)
+                t_start[t] = G_SINGLETON;
+                mydf[q] = 1;
+            } else {
+                const uint32_t pb = ycolptr[c], pe = ycolptr[c + 1];
+                t_start[t] = pb;
+                mydf[q] = pe - pb;
+            }
         }
         mysum += mydf[q];
     }
@@ -141,10 +147,15 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
             if (g < total) {
                 while (t_scan[t + 1] <= g)
                     ++t;
-                const uint64_t pw = ypost[t_start[t] + (g - t_scan[t])];
-                jj[u] = (uint32_t)pw;
-                ww[u] = (uint32_t)(pw >> 32);
                 lv[u] = t_liv[t];
+                if (t_start[t] == G_SINGLETON) {  // pairs with its own row only
+                    jj[u] = (uint32_t)(i0 + (lv[u] >> 28));
+                    ww[u] = lv[u] & 0x0FFFFFFFu;
+                } else {
+                    const uint64_t pw = ypost[t_start[t] + (g - t_scan[t])];
+                    jj[u] = (uint32_t)pw;
+                    ww[u] = (uint32_t)(pw >> 32);
+                }
             }
         }
 #pragma unroll

@@ -128,7 +128,7 @@ class ShardedPipeline:
         ctx.call("skm_csr_concat_rowptr", len(self.rows), h_rows.ctypes.data_as(_p), h_nnz.ctypes.data_as(_p),
                  _p(self.g_rowptr_local.ptr), _p(self.full.rowptr.ptr))
         self.full.nnz = int(h_nnz.sum())
-        self.basis = e.build_basis(ctx, self.full, self.lut.nsym, self.k, out=self.basis)
+        self.basis = e.build_basis(ctx, self.full, self.lut.nsym, self.k, out=self.basis, elide_singletons=True)
         self.rnorm = e.row_norms(ctx, self.n_total, self.full.rowptr, self.full.counts, out=self.rnorm)
         lo, hi = self.bounds[self.rank]
         ld = (self.n_total + 3) // 4 * 4

@@ -143,9 +143,10 @@ def count_csr(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int, with_firstpos: boo
 
 
 def build_basis(ctx, csr: CountsCSR, nsym: int, k: int, stats: bool = False, first_seen: bool = False,
-                postings: bool = True, out: Optional[Basis] = None) -> Basis:
+                postings: bool = True, out: Optional[Basis] = None, elide_singletons: bool = False) -> Basis:
     """a11: observed basis (ascending codes), column ids for `csr`, optional stats / first-seen
-    order / postings."""
+    order / postings.  With `elide_singletons` (cosine-only use) entries of k-mers that occur in a
+    single sequence get colidx 0xFFFFFFFF and no posting (see include/snekmer_hip.h)."""
     nnz = csr.nnz
     b = out or Basis()
     cap = max(nnz, 1)
@@ -171,7 +172,7 @@ def build_basis(ctx, csr: CountsCSR, nsym: int, k: int, stats: bool = False, fir
         b.post = need(b.post, cap, np.uint64)
     ncols = _i64(0)
     ctx.call(
-        "skm_basis_build", csr.code_bits, key_bits(nsym, k), _i64(csr.n), _i64(nnz), _ptr(csr.rowptr), _ptr(csr.codes),
+        "skm_basis_build", csr.code_bits, key_bits(nsym, k), 1 if elide_singletons else 0, _i64(csr.n), _i64(nnz), _ptr(csr.rowptr), _ptr(csr.codes),
         _ptr(csr.counts), _ptr(csr.firstpos if first_seen else None), C.byref(ncols), _ptr(b.codes), _ptr(csr.colidx),
         _ptr(b.df if stats else None), _ptr(b.total if stats else None), _ptr(b.firstkey if first_seen else None),
         _ptr(b.fs_order if first_seen else None), _ptr(b.colptr if postings else None),
@@ -291,7 +292,7 @@ class Pipeline:
 
     def vectorize(self, batch: SeqBatch) -> CountsCSR:
         self.csr = count_csr(self.ctx, batch, self.lut, self.k, out=self.csr)
-        self.basis = build_basis(self.ctx, self.csr, self.lut.nsym, self.k, out=self.basis)
+        self.basis = build_basis(self.ctx, self.csr, self.lut.nsym, self.k, out=self.basis, elide_singletons=True)
         self.rnorm = row_norms(self.ctx, self.csr.n, self.csr.rowptr, self.csr.counts, out=self.rnorm)
         return self.csr
 
