@@ -530,3 +530,39 @@ def test_row_top2_ties_and_edges(ctx):
     assert (idx == order).all() and (val == np.take_along_axis(S[:, :m], order, axis=1)).all()
     idx1, val1 = skm_apply.row_top2(ctx, d, n, 1, ld)
     assert (idx1[:, 0] == 0).all() and (idx1[:, 1] == 0xFFFFFFFF).all() and (val1[:, 1] == 0).all()
+
+
+# ------------------------------------------------------------------ degenerate inputs
+def test_degenerate_batches(ctx):
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.kmerize import vectorize_records
+    from snekmer_amd.score import cosine_similarity
+
+    lut = A.build_lut("hydro")
+    # no valid k-mer anywhere: nnz == 0, the matrix is all zeros (sklearn: zero norm -> 1)
+    batch = engine.SeqBatch.from_strings(ctx, ["MKV", "", "XXXXXXXXXXXXXXXXXXXXXXXX", "*"])
+    pipe = engine.Pipeline(ctx, lut, 14)
+    out = pipe.step(batch)
+    assert pipe.csr.nnz == 0 and pipe.basis.ncols == 0
+    assert (out.download().reshape(out.shape)[:4, :4] == 0).all()
+    # one sequence; output width not a multiple of 4
+    one = engine.SeqBatch.from_strings(ctx, ["MKVLAAGIWSTCDEFHNPQRYMKVLAAGIWST"])
+    o1 = engine.Pipeline(ctx, lut, 5).step(one)
+    assert abs(float(o1.download().ravel()[0]) - 1.0) < 1e-6
+    three = engine.SeqBatch.from_strings(ctx, ["MKVLAAGIWSTCDEFHNPQRY", "MKVLAAGIWSTCDEFHNPQRW", "GGGGGGGGGGGGG"])
+    o3 = engine.Pipeline(ctx, lut, 5).step(three)
+    S = o3.download().reshape(o3.shape)[:3, :3]
+    assert np.allclose(np.diag(S), 1.0, atol=1e-6) and abs(S[0, 1] - S[1, 0]) < 1e-7 and S[0, 2] == S[2, 0]
+    # empty record list through the rule-body counterpart
+    out = vectorize_records([], "hydro", 14, ctx=ctx)
+    assert out["vecs"].shape == (0, 0) and len(out["kmerlist"]) == 0 and len(out["ids"]) == 0
+    out = vectorize_records([("a", "MKV"), ("b", "")], "hydro", 14, ctx=ctx)
+    assert out["vecs"].shape == (2, 0) and list(out["seqs"]) == ["VSV", ""] and list(out["lengths"]) == [3, 0]
+    # rectangular cosine with a zero row and a 1-row Y
+    X = np.array([[1, 0, 2, 0, 0], [0, 0, 0, 0, 0], [3, 1, 0, 0, 2]])
+    Y = np.array([[1, 1, 1, 0, 0]])
+    R = cosine_similarity(X, Y, ctx=ctx)
+    from oracle import ref_path
+
+    assert np.abs(R - ref_path.cosine_similarity(X, Y)).max() <= COS_TOL and R.shape == (3, 1)
