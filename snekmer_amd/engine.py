@@ -220,11 +220,12 @@ def csr_to_dense(ctx, n: int, rowptr, colidx, counts, ncols_out: int, colmap=Non
     return out
 
 
-def count_dense(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int, dtype=np.uint16) -> _hip.DeviceArray:
+def count_dense(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int, dtype=np.uint16, out=None) -> _hip.DeviceArray:
     """North-star dense count matrix [n x |S|^k] by atomic scatter (small bases only)."""
     space = lut.nsym**k
     ld = space + (space & 1)
-    out = ctx.empty((max(batch.n, 1), ld), dtype)
+    if out is None or out.shape != (max(batch.n, 1), ld) or out.dtype != np.dtype(dtype):
+        out = ctx.empty((max(batch.n, 1), ld), dtype)
     code = {np.dtype(np.uint16): 0, np.dtype(np.uint32): 1}[np.dtype(dtype)]
     ctx.call("skm_count_dense", _ptr(lut.rank), lut.nsym, k, _ptr(batch.d_seq), _ptr(batch.d_off), _i64(batch.n), code,
              _ptr(out), _i64(ld))
