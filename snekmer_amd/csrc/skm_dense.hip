@@ -14,6 +14,7 @@
 //   k_cosine_dense_i8   128x128 output tile per workgroup, K-step 64, int8 operands staged in LDS,
 //                       v_mfma_i32_32x32x32_i8 with int32 accumulation (exact), float32 epilogue
 //                       acc * rnorm_x[i] * rnorm_y[j].
+#include <cstdlib>
 #include <cstring>
 
 #include "skm_common.h"
@@ -163,6 +164,113 @@ __global__ __launch_bounds__(256) void k_cosine_dense_i8(int64_t n, int64_t m, i
     }
 }
 
+
+// ------------------------------------------------------------------------------- i8 MFMA cosine, v2
+// Same 128 x 128 tile and 32x32x32 MFMA, but the operands go global -> LDS directly
+// (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPR staging), two LDS stages so the
+// loads of K-step s+1 are in flight while step s is multiplied (counted vmcnt + raw s_barrier:
+// __syncthreads() would drain the DMA), K-step 128, and an XOR swizzle of the 16-byte chunk index
+// (chunk ^ ((row >> 1) & 7)) applied to the SOURCE address and to the fragment reads, which makes
+// the ds_read_b128 fragment reads bank-conflict free on 128-byte rows.
+constexpr int BK2 = 128;
+constexpr int STAGE_BYTES = (BM + BN) * BK2;  // 32 KiB
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cosine_dense_i8_v2(int64_t n, int64_t m, int64_t kdim,
+                                                            const int8_t *__restrict__ X,
+                                                            const int8_t *__restrict__ Y,
+                                                            const float *__restrict__ xr,
+                                                            const float *__restrict__ yr, float *__restrict__ out,
+                                                            int64_t ld)
+{
+    __shared__ __attribute__((aligned(16))) int8_t s_t[2 * STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int64_t row0 = (int64_t)blockIdx.y * BM, col0 = (int64_t)blockIdx.x * BN;
+
+    i32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[a][b][r] = 0;
+
+    // staging: wave w copies rows [32w, 32w+32) of both operands, 8 rows (1 KiB) per instruction;
+    // lane l lands at (row l/8, chunk l%8) and therefore fetches source chunk (l%8) ^ ((row>>1)&7)
+    const int srow = lane >> 3, schunk = lane & 7;
+    auto stage = [&](int buf, int64_t k0) {
+        int8_t *sa = s_t + buf * STAGE_BYTES, *sb = sa + BM * BK2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = wid * 32 + q * 8 + srow;
+            const int src_chunk = schunk ^ ((r >> 1) & 7);
+            const int64_t gi = min(row0 + r, n - 1), gj = min(col0 + r, m - 1);  // clamp: masked in the epilogue
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(X + gi * kdim + k0 + src_chunk * 16),
+                                             (__attribute__((address_space(3))) void *)(sa + (wid * 32 + q * 8) * BK2), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Y + gj * kdim + k0 + src_chunk * 16),
+                                             (__attribute__((address_space(3))) void *)(sb + (wid * 32 + q * 8) * BK2), 16, 0, 0);
+        }
+    };
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int64_t nsteps = kdim / BK2;
+    stage(0, 0);
+    for (int64_t s = 0; s < nsteps; ++s) {
+        const int buf = (int)(s & 1);
+        // everyone has finished reading buf^1 (step s-1) before it is overwritten
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < nsteps) {
+            stage(buf ^ 1, (s + 1) * BK2);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // step s landed; step s+1 (8 loads) in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const int8_t *sa = s_t + buf * STAGE_BYTES, *sb = sa + BM * BK2;
+#pragma unroll
+        for (int ks = 0; ks < BK2 / 32; ++ks) {
+            i32x4 fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ra = wr * 64 + t * 32 + fr, rb = wc * 64 + t * 32 + fr;
+                const int ca = (ks * 2 + fh) ^ ((ra >> 1) & 7), cb = (ks * 2 + fh) ^ ((rb >> 1) & 7);
+                fa[t] = *reinterpret_cast<const i32x4 *>(sa + ra * BK2 + ca * 16);
+                fb[t] = *reinterpret_cast<const i32x4 *>(sb + rb * BK2 + cb * 16);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    const int ccol = lane & 31, chalf = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int64_t j = col0 + wc * 64 + b * 32 + ccol;
+            const float rj = j < m ? yr[j] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t i = row0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+                if (i < n && j < m) {
+                    float o = (float)acc[a][b][r] * xr[i] * rj;
+                    if (MODE == 1) {
+                        o = fminf(fmaxf(1.0f - o, 0.0f), 2.0f);
+                        if (i == j)
+                            o = 0.0f;
+                    }
+                    out[i * ld + j] = o;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int skm_count_dense(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, const uint8_t *d_seq,
@@ -226,10 +334,19 @@ extern "C" int skm_cosine_dense_i8(skm_ctx *ctx, int64_t n, int64_t m, int64_t k
     SKM_REQUIRE((((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0, SKM_E_BADARG, "skm_cosine_dense_i8: operands must be 16-byte aligned");
     SKM_HIP(hipSetDevice(ctx->device));
     dim3 grid((unsigned)skm_ceil_div(m, BN), (unsigned)skm_ceil_div(n, BM));
+    const char *v_env = getenv("SKM_DENSE_VARIANT");  // 1 forces the register-staged kernel
+    const bool v2 = kdim % BK2 == 0 && !(v_env && atoi(v_env) == 1);
     SKM_PROF(ctx, "k_cosine_dense_i8");
-    if (mode == 0)
-        k_cosine_dense_i8<0><<<grid, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
-    else
-        k_cosine_dense_i8<1><<<grid, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+    if (v2) {
+        if (mode == 0)
+            k_cosine_dense_i8_v2<0><<<grid, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+        else
+            k_cosine_dense_i8_v2<1><<<grid, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+    } else {
+        if (mode == 0)
+            k_cosine_dense_i8<0><<<grid, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+        else
+            k_cosine_dense_i8<1><<<grid, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+    }
     return skm_check_launch("k_cosine_dense_i8");
 }

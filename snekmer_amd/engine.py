@@ -261,7 +261,7 @@ class DensePipeline:
             raise ValueError(f"dense path needs |S|^k <= 2^26 (got {lut.nsym}^{k})")
         self.ctx, self.lut, self.k = ctx, lut, k
         self.space = space
-        self.kdim = (space + 63) // 64 * 64
+        self.kdim = (space + 127) // 128 * 128  # K-step of the LDS-DMA MFMA kernel
         self.csr = self.rnorm = self.dense = self.out = None
 
     def step(self, batch: SeqBatch, mode: int = 0):

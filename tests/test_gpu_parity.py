@@ -358,7 +358,15 @@ def test_cosine_dense_i8_mfma_exact_gram_and_scaling(ctx):
     from snekmer_amd import engine
 
     rng = np.random.default_rng(0)
-    n, m, kdim = 200, 333, 192
+    for kdim in (192, 384):  # 192: register-staged kernel (kdim % 128 != 0); 384: LDS-DMA kernel
+        _check_dense_gram(ctx, rng, 200, 333, kdim)
+    _check_dense_gram(ctx, rng, 129, 1, 128)
+    _check_dense_gram(ctx, rng, 5, 300, 1024)
+
+
+def _check_dense_gram(ctx, rng, n, m, kdim):
+    from snekmer_amd import engine
+
     X = rng.integers(-128, 128, size=(n, kdim)).astype(np.int8)
     Y = rng.integers(-128, 128, size=(m, kdim)).astype(np.int8)
     ones_n = ctx.to_device(np.ones(n + 4, dtype=np.float32))
