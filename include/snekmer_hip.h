@@ -152,6 +152,12 @@ int skm_csr_to_dense(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const uin
                      const uint32_t *d_counts, const uint32_t *d_colmap, int64_t ncols_out,
                      int mode, int dtype, void *d_out, int64_t ld);
 
+/* Column re-indexing of a dense row-major matrix, the data movement of KmerBasis.transform
+ * (snekmer/vectorize.py:107-119): out[i, p] = in[i, d_src[p]], or 0 where d_src[p] == 0xFFFFFFFF.
+ * elem_bytes is 1, 2, 4 or 8; d_in is [rows x ld_in], d_out [rows x ncols_out] (tight). */
+int skm_gather_columns(skm_ctx *ctx, int64_t rows, int64_t ncols_out, int elem_bytes, const void *d_in, int64_t ld_in,
+                       const uint32_t *d_src, void *d_out);
+
 /* Largest count in a CSR (host-synchronous): the int8 dense path needs it to be <= 127. */
 int skm_csr_max_count(skm_ctx *ctx, int64_t nnz, const uint32_t *d_counts, uint32_t *h_max);
 

@@ -212,6 +212,18 @@ __global__ void k_hamming_from_gram(int64_t n, int64_t m, float inv_cols, const 
     }
 }
 
+template <typename T>
+__global__ void k_gather_columns(int64_t rows, int64_t ncols_out, const T *__restrict__ in, int64_t ld_in,
+                                 const uint32_t *__restrict__ src, T *__restrict__ out)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= ncols_out)
+        return;
+    const uint32_t c = src[p];
+    for (int64_t i = blockIdx.y; i < rows; i += gridDim.y)
+        out[i * ncols_out + p] = c == 0xFFFFFFFFu ? T(0) : in[i * ld_in + c];
+}
+
 __global__ void k_max_u32(int64_t n, const uint32_t *__restrict__ v, unsigned int *out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -655,6 +667,29 @@ extern "C" int skm_hamming_similarity_from_gram(skm_ctx *ctx, int64_t n, int64_t
     SKM_PROF(ctx, "k_hamming_from_gram");
     k_hamming_from_gram<<<grid, BLK, 0, ctx->stream>>>(n, m, 1.0f / (float)ncols, d_xcount, d_ycount, d_out, ld);
     return skm_check_launch("k_hamming_from_gram");
+}
+
+extern "C" int skm_gather_columns(skm_ctx *ctx, int64_t rows, int64_t ncols_out, int elem_bytes, const void *d_in,
+                                  int64_t ld_in, const uint32_t *d_src, void *d_out)
+{
+    SKM_REQUIRE(ctx && rows >= 0 && ncols_out >= 0 && ld_in >= 0, SKM_E_BADARG, "skm_gather_columns: bad argument");
+    SKM_REQUIRE(elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4 || elem_bytes == 8, SKM_E_BADARG,
+                "skm_gather_columns: elem_bytes must be 1, 2, 4 or 8");
+    if (rows == 0 || ncols_out == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_src && d_out && (ld_in == 0 || d_in), SKM_E_BADARG, "skm_gather_columns: null array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    dim3 grid((unsigned)skm_ceil_div(ncols_out, BLK), (unsigned)(rows < 4096 ? rows : 4096));
+    SKM_PROF(ctx, "k_gather_columns");
+    if (elem_bytes == 8)
+        k_gather_columns<uint64_t><<<grid, BLK, 0, ctx->stream>>>(rows, ncols_out, (const uint64_t *)d_in, ld_in, d_src, (uint64_t *)d_out);
+    else if (elem_bytes == 4)
+        k_gather_columns<uint32_t><<<grid, BLK, 0, ctx->stream>>>(rows, ncols_out, (const uint32_t *)d_in, ld_in, d_src, (uint32_t *)d_out);
+    else if (elem_bytes == 2)
+        k_gather_columns<uint16_t><<<grid, BLK, 0, ctx->stream>>>(rows, ncols_out, (const uint16_t *)d_in, ld_in, d_src, (uint16_t *)d_out);
+    else
+        k_gather_columns<uint8_t><<<grid, BLK, 0, ctx->stream>>>(rows, ncols_out, (const uint8_t *)d_in, ld_in, d_src, (uint8_t *)d_out);
+    return skm_check_launch("k_gather_columns");
 }
 
 extern "C" int skm_csr_max_count(skm_ctx *ctx, int64_t nnz, const uint32_t *d_counts, uint32_t *h_max)

@@ -61,10 +61,32 @@ class KmerBasis:
             )
         where = {k: i for i, k in enumerate(vector_basis)}
         n_in = vector.shape[1]  # IndexError for 1-D input, as upstream
-        source = np.fromiter((where.get(self.basis_order[i], n_in) for i in range(len(self.basis))),
-                             dtype=np.int64, count=len(self.basis))
-        padded = np.concatenate([vector, np.zeros((vector.shape[0], 1), dtype=vector.dtype)], axis=1)
-        return padded[:, source]
+        none = 0xFFFFFFFF
+        source = np.fromiter((where.get(self.basis_order[i], none) for i in range(len(self.basis))),
+                             dtype=np.uint32, count=len(self.basis))
+        return _gather_columns(vector, source)
+
+
+def _gather_columns(matrix: np.ndarray, source: np.ndarray) -> np.ndarray:
+    """out[:, p] = matrix[:, source[p]] (zero column where source[p] == 0xFFFFFFFF), moved on the
+    device by skm_gather_columns.  Element types of 1/2/4/8 bytes are moved as raw words."""
+    import ctypes as C
+
+    rows, n_in = matrix.shape
+    p_out = int(source.size)
+    if matrix.dtype.itemsize not in (1, 2, 4, 8) or matrix.dtype.hasobject:
+        raise NotImplementedError(f"KmerBasis.transform: unsupported element type {matrix.dtype}")
+    out = np.zeros((rows, p_out), dtype=matrix.dtype)
+    if rows == 0 or p_out == 0:
+        return out
+    ctx = _ctx()
+    src = np.ascontiguousarray(matrix)
+    d_in = ctx.to_device(src.view(np.uint8).reshape(-1)) if src.size else ctx.zeros(1, np.uint8)
+    d_src = ctx.to_device(source)
+    d_out = ctx.empty(out.nbytes, np.uint8)
+    ctx.call("skm_gather_columns", C.c_int64(rows), C.c_int64(p_out), matrix.dtype.itemsize, C.c_void_p(d_in.ptr),
+             C.c_int64(n_in), C.c_void_p(d_src.ptr), C.c_void_p(d_out.ptr))
+    return d_out.download().view(matrix.dtype).reshape(rows, p_out)
 
 
 def _generate(alphabet: Set[str], k: int):

@@ -540,6 +540,31 @@ def test_row_top2_ties_and_edges(ctx):
     assert (idx1[:, 0] == 0).all() and (idx1[:, 1] == 0xFFFFFFFF).all() and (val1[:, 1] == 0).all()
 
 
+# ------------------------------------------------------------------ a9 KmerBasis.transform
+def test_kmerbasis_transform_and_harmonize_match_reference_fixture(ctx):
+    import snekmer_amd as skm
+
+    g6 = gjson("g6_basis.json")
+    kb = skm.vectorize.KmerBasis()
+    kb.set_basis(g6["basis"])
+    out = kb.transform(np.asarray(g6["matrix"]), g6["vector_basis"])
+    assert out.dtype == np.float64 and out.tolist() == g6["out"]
+    kv = skm.vectorize.KmerVec("hydro", 3)
+    kv.set_kmer_set(["SSS", "SSV", "VVV"])
+    assert kv.harmonize(np.array([[1.0, 2.0], [3.0, 4.0]]), ["VVV", "SVS"]).tolist() == g6["harmonize"]
+    # other element widths, and the cluster use: harmonize a binary matrix into a larger union basis
+    rng = np.random.default_rng(2)
+    vb = [f"K{i:03d}" for i in range(300)]
+    union = sorted(set(vb[::2]) | {f"Z{i:03d}" for i in range(77)})
+    kb.set_basis(union)
+    for dt in (np.float32, np.int64, np.uint8, np.int16):
+        M = rng.integers(0, 3, size=(41, 300)).astype(dt)
+        got = kb.transform(M, vb)
+        where = {k: i for i, k in enumerate(vb)}
+        ref = np.stack([M[:, where[k]] if k in where else np.zeros(41, dt) for k in union], axis=1)
+        assert got.dtype == dt and (got == ref).all()
+
+
 # ------------------------------------------------------------------ degenerate inputs
 def test_degenerate_batches(ctx):
     from snekmer_amd import alphabet as A
