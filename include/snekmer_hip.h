@@ -158,6 +158,10 @@ int skm_csr_to_dense(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const uin
 int skm_gather_columns(skm_ctx *ctx, int64_t rows, int64_t ncols_out, int elem_bytes, const void *d_in, int64_t ld_in,
                        const uint32_t *d_src, void *d_out);
 
+/* d_out[i] = (uint32) d_in[i] for non-negative int8 counts (lets the CSR norm kernel serve dense
+ * int8 operands). */
+int skm_widen_i8_u32(skm_ctx *ctx, int64_t count, const int8_t *d_in, uint32_t *d_out);
+
 /* Largest count in a CSR (host-synchronous): the int8 dense path needs it to be <= 127. */
 int skm_csr_max_count(skm_ctx *ctx, int64_t nnz, const uint32_t *d_counts, uint32_t *h_max);
 

@@ -224,6 +224,14 @@ __global__ void k_gather_columns(int64_t rows, int64_t ncols_out, const T *__res
         out[i * ncols_out + p] = c == 0xFFFFFFFFu ? T(0) : in[i * ld_in + c];
 }
 
+__global__ void k_widen_i8_u32(int64_t n, const int8_t *__restrict__ in, uint32_t *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        out[i] = (uint32_t)(uint8_t)in[i];
+}
+
 __global__ void k_max_u32(int64_t n, const uint32_t *__restrict__ v, unsigned int *out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -690,6 +698,17 @@ extern "C" int skm_gather_columns(skm_ctx *ctx, int64_t rows, int64_t ncols_out,
     else
         k_gather_columns<uint8_t><<<grid, BLK, 0, ctx->stream>>>(rows, ncols_out, (const uint8_t *)d_in, ld_in, d_src, (uint8_t *)d_out);
     return skm_check_launch("k_gather_columns");
+}
+
+extern "C" int skm_widen_i8_u32(skm_ctx *ctx, int64_t count, const int8_t *d_in, uint32_t *d_out)
+{
+    SKM_REQUIRE(ctx && count >= 0, SKM_E_BADARG, "skm_widen_i8_u32: bad argument");
+    if (count == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_in && d_out, SKM_E_BADARG, "skm_widen_i8_u32: null array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    k_widen_i8_u32<<<skm_grid_cap(ctx, skm_ceil_div(count, BLK), 16), BLK, 0, ctx->stream>>>(count, d_in, d_out);
+    return skm_check_launch("k_widen_i8_u32");
 }
 
 extern "C" int skm_csr_max_count(skm_ctx *ctx, int64_t nnz, const uint32_t *d_counts, uint32_t *h_max)

@@ -271,6 +271,122 @@ __global__ __launch_bounds__(256) void k_cosine_dense_i8_v2(int64_t n, int64_t m
     }
 }
 
+
+// ------------------------------------------------------------------------------- i8 MFMA cosine, v3
+// 256 x 256 output tile, 8 waves (2 x 4, 128 x 64 per wave = 4 x 2 MFMA tiles), otherwise the v2
+// structure (LDS-DMA, 2 stages of 64 KiB, swizzled 128-byte rows).  A 128 x 128 tile moves
+// 32 KiB through L2 per 4.2 Mop, which at the i8 MFMA rate is ~39 TB/s chip-wide, above what L2
+// delivers; the 256 x 256 tile halves that and is the shape that can approach the matrix-core rate.
+constexpr int BM3 = 256, BN3 = 256;
+constexpr int STAGE3_BYTES = (BM3 + BN3) * BK2;  // 64 KiB
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_cosine_dense_i8_v3(int64_t n, int64_t m, int64_t kdim,
+                                                            const int8_t *__restrict__ X,
+                                                            const int8_t *__restrict__ Y,
+                                                            const float *__restrict__ xr,
+                                                            const float *__restrict__ yr, float *__restrict__ out,
+                                                            int64_t ld)
+{
+    __shared__ __attribute__((aligned(16))) int8_t s_t[2 * STAGE3_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 2, wc = wid & 3;
+    // XCD-aware tile order (speed only).  Workgroups b, b+8, ... share an XCD and its L2; give each
+    // XCD a contiguous run of tiles ordered by 4 x 8 "supertiles", so that the ~32 workgroups
+    // resident on an XCD stream the same 4 row panels and 8 column panels in K lock-step.
+    const int64_t nty = (n + BM3 - 1) / BM3, ntx = (m + BN3 - 1) / BN3;
+    const int64_t nsx = (ntx + 7) / 8;
+    const int64_t nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+    const int64_t seq = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+    const int64_t st = seq / 32, within = seq % 32;
+    const int64_t ty = (st / nsx) * 4 + within / 8, tx = (st % nsx) * 8 + within % 8;
+    if (ty >= nty || tx >= ntx)
+        return;
+    const int64_t row0 = ty * BM3, col0 = tx * BN3;
+
+    i32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[a][b][r] = 0;
+
+    const int srow = lane >> 3, schunk = lane & 7;
+    auto stage = [&](int buf, int64_t k0) {
+        int8_t *sa = s_t + buf * STAGE3_BYTES, *sb = sa + BM3 * BK2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = wid * 32 + q * 8 + srow;
+            const int src_chunk = schunk ^ ((r >> 1) & 7);
+            const int64_t gi = min(row0 + r, n - 1), gj = min(col0 + r, m - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(X + gi * kdim + k0 + src_chunk * 16),
+                                             (__attribute__((address_space(3))) void *)(sa + (wid * 32 + q * 8) * BK2), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Y + gj * kdim + k0 + src_chunk * 16),
+                                             (__attribute__((address_space(3))) void *)(sb + (wid * 32 + q * 8) * BK2), 16, 0, 0);
+        }
+    };
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int64_t nsteps = kdim / BK2;
+    stage(0, 0);
+    for (int64_t s = 0; s < nsteps; ++s) {
+        const int buf = (int)(s & 1);
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < nsteps) {
+            stage(buf ^ 1, (s + 1) * BK2);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const int8_t *sa = s_t + buf * STAGE3_BYTES, *sb = sa + BM3 * BK2;
+#pragma unroll
+        for (int ks = 0; ks < BK2 / 32; ++ks) {
+            i32x4 fa[4], fb[2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ra = wr * 128 + t * 32 + fr;
+                fa[t] = *reinterpret_cast<const i32x4 *>(sa + ra * BK2 + (((ks * 2 + fh) ^ ((ra >> 1) & 7)) * 16));
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int rb = wc * 64 + t * 32 + fr;
+                fb[t] = *reinterpret_cast<const i32x4 *>(sb + rb * BK2 + (((ks * 2 + fh) ^ ((rb >> 1) & 7)) * 16));
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    const int ccol = lane & 31, chalf = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int64_t j = col0 + wc * 64 + b * 32 + ccol;
+            const float rj = j < m ? yr[j] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t i = row0 + wr * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
+                if (i < n && j < m) {
+                    float o = (float)acc[a][b][r] * xr[i] * rj;
+                    if (MODE == 1) {
+                        o = fminf(fmaxf(1.0f - o, 0.0f), 2.0f);
+                        if (i == j)
+                            o = 0.0f;
+                    }
+                    out[i * ld + j] = o;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int skm_count_dense(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, const uint8_t *d_seq,
@@ -334,10 +450,21 @@ extern "C" int skm_cosine_dense_i8(skm_ctx *ctx, int64_t n, int64_t m, int64_t k
     SKM_REQUIRE((((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0, SKM_E_BADARG, "skm_cosine_dense_i8: operands must be 16-byte aligned");
     SKM_HIP(hipSetDevice(ctx->device));
     dim3 grid((unsigned)skm_ceil_div(m, BN), (unsigned)skm_ceil_div(n, BM));
-    const char *v_env = getenv("SKM_DENSE_VARIANT");  // 1 forces the register-staged kernel
-    const bool v2 = kdim % BK2 == 0 && !(v_env && atoi(v_env) == 1);
+    const char *v_env = getenv("SKM_DENSE_VARIANT");  // 1: register-staged kernel, 2: 128x128 LDS-DMA kernel
+    const int forced = v_env ? atoi(v_env) : 0;
+    const bool v2 = kdim % BK2 == 0 && forced != 1;
+    const bool v3 = v2 && forced != 2 && n >= 1024 && m >= 1024;
     SKM_PROF(ctx, "k_cosine_dense_i8");
-    if (v2) {
+    if (v3) {
+        // padded to whole 4 x 8 supertiles; workgroups that fall outside the matrix exit at once
+        const int64_t nsy3 = skm_ceil_div(skm_ceil_div(n, BM3), 4), nsx3 = skm_ceil_div(skm_ceil_div(m, BN3), 8);
+        SKM_REQUIRE(nsy3 * nsx3 * 32 < ((int64_t)1 << 31), SKM_E_OVERFLOW, "skm_cosine_dense_i8: too many tiles");
+        dim3 grid3((unsigned)(nsy3 * nsx3 * 32));
+        if (mode == 0)
+            k_cosine_dense_i8_v3<0><<<grid3, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+        else
+            k_cosine_dense_i8_v3<1><<<grid3, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+    } else if (v2) {
         if (mode == 0)
             k_cosine_dense_i8_v2<0><<<grid, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
         else

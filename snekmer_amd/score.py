@@ -48,12 +48,79 @@ def _as_count_csr(ctx, X):
     return csr, int(shape[1])
 
 
-def cosine_similarity(X, Y=None, mode: int = 0, ctx=None) -> np.ndarray:
+DENSE_MAX_COLS = 1 << 17
+DENSE_MIN_DENSITY = 0.005
+
+
+def _try_dense_i8(ctx, X, Y, mode, force=False):
+    """Dense ndarray inputs over a small basis with counts <= 127 go to the i8 MFMA kernel
+    (a true dense GEMM); everything else (sparse inputs, huge bases, large counts) returns None
+    and takes the sparse path, which is exact for any count."""
+    mats = [X] if Y is None else [X, Y]
+    if not all(isinstance(M, np.ndarray) and M.ndim == 2 for M in mats):
+        return None
+    if Y is not None and X.shape[1] != Y.shape[1]:
+        raise ValueError(
+            f"Incompatible dimension for X and Y matrices: X.shape[1] == {X.shape[1]} while Y.shape[1] == {Y.shape[1]}"
+        )
+    k = X.shape[1]
+    if k == 0 or (k > DENSE_MAX_COLS and not force) or min(M.shape[0] for M in mats) == 0:
+        return None
+    for M in mats:
+        if M.dtype == bool:
+            continue
+        if np.any(M < 0) or np.any(M > 127) or (M.dtype.kind == "f" and np.any(M != np.floor(M))):
+            return None
+    if not force and sum(np.count_nonzero(M) for M in mats) < DENSE_MIN_DENSITY * sum(M.size for M in mats):
+        return None
+    kdim = (k + 127) // 128 * 128
+
+    def upload(M):
+        P = np.zeros((M.shape[0], kdim), dtype=np.int8)
+        P[:, :k] = M
+        return ctx.to_device(P), None
+
+    dx, _ = upload(X)
+    n = X.shape[0]
+    xr = _dense_row_norms(ctx, dx, n, kdim)
+    if Y is None:
+        dy, yr, m = dx, xr, n
+    else:
+        dy, _ = upload(Y)
+        m = Y.shape[0]
+        yr = _dense_row_norms(ctx, dy, m, kdim)
+    ld = (m + 3) // 4 * 4
+    out = engine.cosine_dense_i8(ctx, n, m, kdim, dx, dy, xr, yr, mode=mode, ld=ld)
+    return out.download().reshape(max(n, 1), max(ld, 1))[:n, :m]
+
+
+def _dense_row_norms(ctx, d_mat, n, kdim):
+    """1/||row|| of an int8 matrix: the Gram kernel itself gives the exact squared norms on its
+    diagonal blocks, but a CSR view is cheaper: reuse skm_row_norms_csr on a one-entry-per-cell CSR."""
+    import ctypes as C
+
+    rowptr = ctx.to_device(np.arange(n + 1, dtype=np.int64) * kdim)
+    counts = ctx.empty(max(n * kdim, 1), np.uint32)
+    ctx.call("skm_widen_i8_u32", C.c_int64(n * kdim), C.c_void_p(d_mat.ptr), C.c_void_p(counts.ptr))
+    return engine.row_norms(ctx, n, rowptr, counts)
+
+
+def cosine_similarity(X, Y=None, mode: int = 0, ctx=None, path: str = "auto") -> np.ndarray:
     """Cosine similarity between the rows of X and the rows of Y (Y=None: X with itself).
-    float32 result [n_x, n_y]; exact integer dot products scaled in float32 (|err| <= ~3e-7)."""
+    float32 result [n_x, n_y]; exact integer dot products scaled in float32 (|err| <= ~3e-7).
+    `path`: "auto" picks the i8 MFMA GEMM for dense ndarrays over a small basis with counts <= 127
+    and the sparse kernels otherwise; "sparse" / "dense" force one."""
     from . import _hip
 
     ctx = ctx or _hip.default_context()
+    if path not in ("auto", "sparse", "dense"):
+        raise ValueError("path must be 'auto', 'sparse' or 'dense'")
+    if path != "sparse":
+        dense = _try_dense_i8(ctx, X, Y, mode, force=path == "dense")
+        if dense is not None:
+            return dense
+        if path == "dense":
+            raise ValueError("dense i8 path needs dense ndarray inputs with integer values in [0, 127]")
     x, kx = _as_count_csr(ctx, X)
     if Y is None:
         y, ky = x, kx

@@ -213,9 +213,13 @@ def test_cosine_matches_sklearn_goldens(ctx, tag):
     g = gnpz(f"g3_demo_{tag}.npz")
     ncols = len(g["kmerlist"])
     counts = csr_to_dense(g["counts_rowptr"], g["counts_col"], g["counts_val"], ncols)
-    S = cosine_similarity(counts, ctx=ctx)
-    assert S.dtype == np.float32 and S.shape == g["cosine"].shape
-    assert np.abs(S - g["cosine"]).max() <= COS_TOL
+    for path in ("auto", "sparse", "dense"):
+        S = cosine_similarity(counts, ctx=ctx, path=path)
+        assert S.dtype == np.float32 and S.shape == g["cosine"].shape
+        assert np.abs(S - g["cosine"]).max() <= COS_TOL, path
+    Rd = cosine_similarity(g["totals"], counts, ctx=ctx, path="dense").T if g["totals"].max() <= 127 else None
+    if Rd is not None:
+        assert np.abs(Rd - g["cosine_rect"]).max() <= COS_TOL
     # sparse input, rectangular family-totals x sequences, transposed as the rule does
     R = cosine_similarity(g["totals"], sp.csr_matrix(counts), ctx=ctx).T
     assert np.abs(R - g["cosine_rect"]).max() <= COS_TOL
@@ -362,6 +366,7 @@ def test_cosine_dense_i8_mfma_exact_gram_and_scaling(ctx):
         _check_dense_gram(ctx, rng, 200, 333, kdim)
     _check_dense_gram(ctx, rng, 129, 1, 128)
     _check_dense_gram(ctx, rng, 5, 300, 1024)
+    _check_dense_gram(ctx, rng, 1100, 1029, 256)  # 256 x 256 tile kernel incl. ragged edges
 
 
 def _check_dense_gram(ctx, rng, n, m, kdim):
