@@ -61,6 +61,20 @@ def cpu_baseline(alphabet_name, k, seed, n_sample):
     }
 
 
+class stdout_to_stderr:
+    """gloo and RCCL print connection banners on stdout; stdout is reserved for the one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def load_pmc_traffic():
     """Per-launch HBM bytes of the dominant kernel from the committed PMC summary, if any."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -109,7 +123,8 @@ def main():
         import torch
         import torch.distributed as dist
 
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        with stdout_to_stderr():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     ctx = _hip.Context(local_rank)
     lut = alphabet.build_lut(args.alphabet)
@@ -126,9 +141,11 @@ def main():
     else:
         from snekmer_amd.dist import RcclExchange, ShardedPipeline, shard_bounds
 
-        uid = [RcclExchange.new_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ex = RcclExchange(ctx, world, rank, uid[0])
+        with stdout_to_stderr():
+            uid = [RcclExchange.new_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ex = RcclExchange(ctx, world, rank, uid[0])
+            ex.allgather_i64(rank)  # first collective: connection set-up (and any lazy banner) happens here
         bounds = shard_bounds(n_total, world)
         lo, hi = bounds[rank]
         shard = engine.SeqBatch(ctx, res[off[lo] : off[hi]], off[lo : hi + 1] - off[lo])
@@ -217,8 +234,9 @@ def main():
         print(json.dumps(line), flush=True)
 
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        with stdout_to_stderr():
+            dist.barrier()
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
