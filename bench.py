@@ -145,7 +145,7 @@ def main():
             uid = [RcclExchange.new_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             ex = RcclExchange(ctx, world, rank, uid[0])
-            ex.allgather_i64(rank)  # first collective: connection set-up (and any lazy banner) happens here
+            ex.allgather_i64([rank])  # first collective: connection set-up (and any lazy banner) happens here
         bounds = shard_bounds(n_total, world)
         lo, hi = bounds[rank]
         shard = engine.SeqBatch(ctx, res[off[lo] : off[hi]], off[lo : hi + 1] - off[lo])

@@ -158,6 +158,11 @@ int skm_csr_to_dense(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const uin
 int skm_gather_columns(skm_ctx *ctx, int64_t rows, int64_t ncols_out, int elem_bytes, const void *d_in, int64_t ld_in,
                        const uint32_t *d_src, void *d_out);
 
+/* Counts travel as bytes in the multi-GPU exchange when every count fits (skm_csr_max_count <= 255):
+ * d_out[i] = (uint8) d_in[i] and back. */
+int skm_narrow_u32_u8(skm_ctx *ctx, int64_t count, const uint32_t *d_in, uint8_t *d_out);
+int skm_widen_u8_u32(skm_ctx *ctx, int64_t count, const uint8_t *d_in, uint32_t *d_out);
+
 /* d_out[i] = (uint32) d_in[i] for non-negative int8 counts (lets the CSR norm kernel serve dense
  * int8 operands). */
 int skm_widen_i8_u32(skm_ctx *ctx, int64_t count, const int8_t *d_in, uint32_t *d_out);

@@ -67,6 +67,8 @@ _SIGNATURES = {
     "skm_csr_concat_rowptr": (C.c_int, [_p, C.c_int, _p, _p, _p, _p]),
     "skm_csr_to_dense": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, C.c_int, C.c_int, _p, _i64]),
     "skm_gather_columns": (C.c_int, [_p, _i64, _i64, C.c_int, _p, _i64, _p, _p]),
+    "skm_narrow_u32_u8": (C.c_int, [_p, _i64, _p, _p]),
+    "skm_widen_u8_u32": (C.c_int, [_p, _i64, _p, _p]),
     "skm_widen_i8_u32": (C.c_int, [_p, _i64, _p, _p]),
     "skm_csr_max_count": (C.c_int, [_p, _i64, _p, C.POINTER(C.c_uint32)]),
     "skm_row_norms_csr": (C.c_int, [_p, _i64, _p, _p, _p, _p]),

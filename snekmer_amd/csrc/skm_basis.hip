@@ -232,6 +232,14 @@ __global__ void k_widen_i8_u32(int64_t n, const int8_t *__restrict__ in, uint32_
         out[i] = (uint32_t)(uint8_t)in[i];
 }
 
+__global__ void k_narrow_u32_u8(int64_t n, const uint32_t *__restrict__ in, uint8_t *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        out[i] = (uint8_t)in[i];
+}
+
 __global__ void k_max_u32(int64_t n, const uint32_t *__restrict__ v, unsigned int *out)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -709,6 +717,22 @@ extern "C" int skm_widen_i8_u32(skm_ctx *ctx, int64_t count, const int8_t *d_in,
     SKM_HIP(hipSetDevice(ctx->device));
     k_widen_i8_u32<<<skm_grid_cap(ctx, skm_ceil_div(count, BLK), 16), BLK, 0, ctx->stream>>>(count, d_in, d_out);
     return skm_check_launch("k_widen_i8_u32");
+}
+
+extern "C" int skm_narrow_u32_u8(skm_ctx *ctx, int64_t count, const uint32_t *d_in, uint8_t *d_out)
+{
+    SKM_REQUIRE(ctx && count >= 0, SKM_E_BADARG, "skm_narrow_u32_u8: bad argument");
+    if (count == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_in && d_out, SKM_E_BADARG, "skm_narrow_u32_u8: null array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    k_narrow_u32_u8<<<skm_grid_cap(ctx, skm_ceil_div(count, BLK), 16), BLK, 0, ctx->stream>>>(count, d_in, d_out);
+    return skm_check_launch("k_narrow_u32_u8");
+}
+
+extern "C" int skm_widen_u8_u32(skm_ctx *ctx, int64_t count, const uint8_t *d_in, uint32_t *d_out)
+{
+    return skm_widen_i8_u32(ctx, count, (const int8_t *)d_in, d_out);
 }
 
 extern "C" int skm_csr_max_count(skm_ctx *ctx, int64_t nnz, const uint32_t *d_counts, uint32_t *h_max)

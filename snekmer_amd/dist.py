@@ -42,11 +42,13 @@ def shard_bounds_by_residues(offsets: np.ndarray, world: int) -> List[Tuple[int,
     return [(int(cuts[r]), int(cuts[r + 1])) for r in range(world)]
 
 
-def plan_allgather(nnz_per_rank: Sequence[int], rows_per_rank: Sequence[int], code_bytes: int):
-    """Byte counts of the three all-gathers (codes, counts, local rowptr) per rank."""
+def plan_allgather(nnz_per_rank: Sequence[int], rows_per_rank: Sequence[int], code_bytes: int, count_bytes: int = 4):
+    """Byte counts of the three all-gathers (codes, counts, local rowptr) per rank.  Counts travel
+    as single bytes (count_bytes=1) when every rank's largest count is <= 255, which is the rule
+    for k-mer counts; 4 otherwise."""
     return {
         "codes": [int(z) * code_bytes for z in nnz_per_rank],
-        "counts": [int(z) * 4 for z in nnz_per_rank],
+        "counts": [int(z) * count_bytes for z in nnz_per_rank],
         "rowptr": [(int(r) + 1) * 8 for r in rows_per_rank],
     }
 
@@ -80,11 +82,16 @@ class RcclExchange:
         _hip._check(lib, lib.skm_comm_unique_id(buf.ctypes.data_as(_p)))
         return buf.tobytes()
 
-    def allgather_i64(self, value: int) -> np.ndarray:
-        self._mine.upload(np.asarray([value], dtype=np.int64))
-        sizes = np.full(self.world, 8, dtype=np.int64)
+    def allgather_i64(self, values) -> np.ndarray:
+        """Gather a small fixed-length int64 vector from every rank -> [world, len]."""
+        vals = np.atleast_1d(np.asarray(values, dtype=np.int64))
+        if self._mine.size != vals.size:
+            self._mine = self.ctx.empty(vals.size, np.int64)
+            self._sizes = self.ctx.empty(self.world * vals.size, np.int64)
+        self._mine.upload(vals)
+        sizes = np.full(self.world, 8 * vals.size, dtype=np.int64)
         self.ctx.call("skm_allgatherv", _p(self._mine.ptr), sizes.ctypes.data_as(_p), _p(self._sizes.ptr))
-        return self._sizes.download(self.world)
+        return self._sizes.download(self.world * vals.size).reshape(self.world, vals.size)
 
     def allgatherv(self, d_send, nbytes_per_rank: Sequence[int], d_recv):
         sizes = np.asarray(nbytes_per_rank, dtype=np.int64)
@@ -107,6 +114,8 @@ class ShardedPipeline:
         self.code_dtype = np.uint32 if bits == 32 else np.uint64
         cap = total_residues + 1
         self.local = None
+        self.bytes_local = ctx.empty(cap, np.uint8)   # counts of the local shard, one byte each
+        self.bytes_full = ctx.empty(cap, np.uint8)
         self.g_rowptr_local = ctx.empty(self.n_total + len(self.bounds), np.int64)
         full = engine.CountsCSR(ctx, self.n_total, 0, bits, ctx.empty(self.n_total + 1, np.int64),
                                 ctx.empty(cap, self.code_dtype), ctx.empty(cap, np.uint32), None)
@@ -118,10 +127,17 @@ class ShardedPipeline:
     def step(self, shard_batch):
         e, ctx = self.engine, self.ctx
         self.local = e.count_csr(ctx, shard_batch, self.lut, self.k, out=self.local)
-        nnz = self.ex.allgather_i64(self.local.nnz)
-        plan = plan_allgather(nnz, self.rows, np.dtype(self.code_dtype).itemsize)
+        meta = self.ex.allgather_i64([self.local.nnz, e.csr_max_count(ctx, self.local)])
+        nnz = meta[:, 0]
+        narrow = int(meta[:, 1].max()) <= 255
+        plan = plan_allgather(nnz, self.rows, np.dtype(self.code_dtype).itemsize, 1 if narrow else 4)
         self.ex.allgatherv(self.local.codes, plan["codes"], self.full.codes)
-        self.ex.allgatherv(self.local.counts, plan["counts"], self.full.counts)
+        if narrow:
+            ctx.call("skm_narrow_u32_u8", _i64(self.local.nnz), _p(self.local.counts.ptr), _p(self.bytes_local.ptr))
+            self.ex.allgatherv(self.bytes_local, plan["counts"], self.bytes_full)
+            ctx.call("skm_widen_u8_u32", _i64(int(nnz.sum())), _p(self.bytes_full.ptr), _p(self.full.counts.ptr))
+        else:
+            self.ex.allgatherv(self.local.counts, plan["counts"], self.full.counts)
         self.ex.allgatherv(self.local.rowptr, plan["rowptr"], self.g_rowptr_local)
         h_rows = np.asarray(self.rows, dtype=np.int64)
         h_nnz = np.asarray(nnz, dtype=np.int64)

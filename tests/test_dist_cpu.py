@@ -63,10 +63,13 @@ def _worker(rank, world, port, outdir):
             return np.concatenate([o.numpy()[: nbytes[r]] for r, o in enumerate(outs)])
 
         nnz = allgather_i64(len(loc_codes))
+        maxc = allgather_i64(int(loc_counts.max()) if len(loc_counts) else 0)
         rows = [b - a for a, b in bounds]
-        plan = plan_allgather(nnz, rows, 4)
+        narrow = max(maxc) <= 255  # counts travel as bytes, as ShardedPipeline does
+        plan = plan_allgather(nnz, rows, 4, 1 if narrow else 4)
         codes = allgatherv(loc_codes.astype(np.uint32), plan["codes"]).view(np.uint32)
-        counts = allgatherv(loc_counts.astype(np.uint32), plan["counts"]).view(np.uint32)
+        cdt = np.uint8 if narrow else np.uint32
+        counts = allgatherv(loc_counts.astype(cdt), plan["counts"]).view(cdt).astype(np.uint32)
         rp_all = allgatherv(loc_rp.astype(np.int64), plan["rowptr"]).view(np.int64)
         pieces, pos = [], 0
         for r in rows:
@@ -114,5 +117,6 @@ def test_shard_bounds_cover_and_balance():
     assert max(res) - min(res) <= 2 * 1000  # within two of the longest sequences
     plan = plan_allgather([10, 0, 5], [3, 2, 4], 8)
     assert plan == {"codes": [80, 0, 40], "counts": [40, 0, 20], "rowptr": [32, 24, 40]}
+    assert plan_allgather([10, 0, 5], [3, 2, 4], 4, 1)["counts"] == [10, 0, 5]
     rp = concat_rowptr_host([np.array([0, 2, 5]), np.array([0]), np.array([0, 1, 1, 4])])
     assert rp.tolist() == [0, 2, 5, 6, 6, 9]
