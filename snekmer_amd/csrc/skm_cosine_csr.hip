@@ -248,7 +248,8 @@ __global__ __launch_bounds__(WCH / 4) void k_cosine_write(const uint64_t *__rest
                                                      const float *__restrict__ xrnorm,
                                                      const float *__restrict__ yrnorm, int64_t m, int64_t row0,
                                                      int64_t row1, float *__restrict__ out, int64_t ld,
-                                                     uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_count)
+                                                     uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_count,
+                                                     uint32_t *__restrict__ fb_flag)
 {
     constexpr int R = WR, CH = WCH, TB = WCH / 4, NW = TB / 64;
     constexpr int RPW = (R + NW - 1) / NW;  // rows fed by each wave
@@ -283,10 +284,14 @@ __global__ __launch_bounds__(WCH / 4) void k_cosine_write(const uint64_t *__rest
     __syncthreads();
     if (s_skip) {
         // some row of this strip exceeded the sparse kernel's capacities: leave it to the cursor kernel
-        // (cursor strips are 8 rows; a strip listed twice is merely computed twice)
+        // (cursor strips are 8 rows; fb_flag makes sure a strip is listed once, since the cursor
+        // kernel's grid is sized by the number of strips)
         constexpr int CURSOR_R = 8;
-        if (tid < (R + CURSOR_R - 1) / CURSOR_R)
-            fb_list[atomicAdd(fb_count, 1u)] = (uint32_t)((i0 - row0) / CURSOR_R) + tid;
+        if (tid < (R + CURSOR_R - 1) / CURSOR_R) {
+            const uint32_t strip = (uint32_t)((i0 - row0) / CURSOR_R) + tid;
+            if (atomicExch(&fb_flag[strip], 1u) == 0u)
+                fb_list[atomicAdd(fb_count, 1u)] = strip;
+        }
         return;
     }
 
@@ -449,10 +454,14 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     uint64_t *g_start = (uint64_t *)p;
     SKM_TRY(skm_ws(ctx, WS_C, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
     uint32_t *g_len = (uint32_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)(2 * strips + 8 * MAXB), &p));
+    // one entry per writer workgroup at most (the writer may run one row per workgroup)
+    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)(nrows + 8 * MAXB + 8), &p));
     uint32_t *fb_list = (uint32_t *)p;
     SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
     uint32_t *over_list = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_F, sizeof(uint32_t) * (size_t)(strips + MAXB + 8), &p));
+    uint32_t *fb_flag = (uint32_t *)p;
+    SKM_HIP(hipMemsetAsync(fb_flag, 0, sizeof(uint32_t) * (size_t)(strips + MAXB + 8), st));
     SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
     unsigned long long *g_counter = (unsigned long long *)((uint8_t *)p + 2048);
     uint32_t *fb_counts = (uint32_t *)((uint8_t *)p + 2048 + 8);            // [MAXB]
@@ -485,7 +494,7 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         uint64_t *gs = g_start + rel;
         uint32_t *gl = g_len + rel;
         uint32_t *ol = over_list + rel, *oc = over_counts + b;
-        uint32_t *fl = fb_list + 2 * (rel / R) + 8 * b, *fc = fb_counts + b;
+        uint32_t *fl = fb_list + rel + 8 * b, *fc = fb_counts + b, *ff = fb_flag + rel / R + b;
         float *outb = d_out + rel * ld;
         {
             SKM_PROF_ON(ctx, "k_gram_sparse", sg);
@@ -520,17 +529,25 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         }
         {
             SKM_PROF(ctx, "k_cosine_write");
-#define SKM_LAUNCH_WV(MODE, VEC, WR)                                                                                    \
-    k_cosine_write<MODE, VEC, WR, CH><<<(unsigned)skm_ceil_div(rows_b, WR), CH / 4, 0, st>>>(                             \
-        g_ent, gs, gl, d_xrnorm, d_yrnorm, m, r0, r1, outb, ld, fl, fc)
+#define SKM_LAUNCH_WV(MODE, VEC, WR, WCH)                                                                               \
+    k_cosine_write<MODE, VEC, WR, WCH><<<(unsigned)skm_ceil_div(rows_b, WR), WCH / 4, 0, st>>>(                           \
+        g_ent, gs, gl, d_xrnorm, d_yrnorm, m, r0, r1, outb, ld, fl, fc, ff)
 #define SKM_LAUNCH_W(MODE, VEC)                                                                                         \
     do {                                                                                                                \
         if (wv == 1)                                                                                                    \
-            SKM_LAUNCH_WV(MODE, VEC, 8);                                                                                \
+            SKM_LAUNCH_WV(MODE, VEC, 8, 1024);                                                                          \
         else if (wv == 2)                                                                                               \
-            SKM_LAUNCH_WV(MODE, VEC, 16);                                                                               \
-        else                                                                                                            \
-            SKM_LAUNCH_WV(MODE, VEC, 4);                                                                                \
+            SKM_LAUNCH_WV(MODE, VEC, 16, 1024);                                                                         \
+        else if (wv == 4)                                                                                               \
+            SKM_LAUNCH_WV(MODE, VEC, 2, 2048);                                                                          \
+        else if (wv == 5)                                                                                               \
+            SKM_LAUNCH_WV(MODE, VEC, 2, 4096);                                                                          \
+        else if (wv == 6)                                                                                               \
+            SKM_LAUNCH_WV(MODE, VEC, 1, 2048);                                                                          \
+        else if (wv == 7)                                                                                               \
+            SKM_LAUNCH_WV(MODE, VEC, 4, 1024);                                                                          \
+        else /* default: one row per workgroup, 16 KiB per row and step (measured best) */                              \
+            SKM_LAUNCH_WV(MODE, VEC, 1, 4096);                                                                          \
     } while (0)
             if (mode == 0) {
                 if (vec)

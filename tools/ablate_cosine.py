@@ -22,7 +22,9 @@ ctx.sync()
 ctx.profile_enable(True)
 gres = {}
 for rnd in range(3):
-    for name, env in (("full", {}), ("w4", {"SKM_WRITE_VARIANT": "1"}), ("w16", {"SKM_WRITE_VARIANT": "2"}), ("no_pairs", {"SKM_GRAM_ABLATE": "1"}), ("no_emit", {"SKM_GRAM_ABLATE": "2"}),
+    for name, env in (("full", {}), ("w8x1024", {"SKM_WRITE_VARIANT": "1"}), ("w16x1024", {"SKM_WRITE_VARIANT": "2"}),
+                      ("w1x4096", {"SKM_WRITE_VARIANT": "3"}), ("w2x2048", {"SKM_WRITE_VARIANT": "4"}),
+                      ("w2x4096", {"SKM_WRITE_VARIANT": "5"}), ("w1x2048", {"SKM_WRITE_VARIANT": "6"}), ("no_pairs", {"SKM_GRAM_ABLATE": "1"}), ("no_emit", {"SKM_GRAM_ABLATE": "2"}),
                       ("v1", {"SKM_GRAM_VARIANT": "1"}), ("v2", {"SKM_GRAM_VARIANT": "2"}), ("v3", {"SKM_GRAM_VARIANT": "3"}),
                       ("v4", {"SKM_GRAM_VARIANT": "4"}), ("v5", {"SKM_GRAM_VARIANT": "5"}), ("v6", {"SKM_GRAM_VARIANT": "6"})):
         for k in ("SKM_GRAM_ABLATE", "SKM_GRAM_VARIANT", "SKM_WRITE_VARIANT"):
