@@ -6,35 +6,33 @@
 //                                                        snekmer/rules/evaluate.smk:434-436
 //   pairwise_distances(X, metric="cosine")               snekmer/score.py:169-171
 //
-// Why not a dense GEMM here: at k = 12 the observed basis has ~200 columns per sequence
-// (SURVEY.md D2/H1); the dense N x B operand would be terabytes and >99.9 % of the N x N Gram
+// Why not a dense GEMM here: at k = 12 the observed basis has >100 columns per sequence
+// (SURVEY.md D2/H1); the dense N x B operand would be terabytes and >99.6 % of the N x N Gram
 // entries are zero.  The output matrix itself (N*M float32) is the irreducible traffic, so the
-// kernel is organised as a streaming writer that is bound by HBM write bandwidth:
+// stage is organised around a streaming writer bound by HBM write bandwidth:
 //
-//   - a workgroup owns a strip of R = 8 output rows and walks the M output columns in chunks of
-//     CH = 1024; the chunk's exact integer dot products are accumulated in LDS (int32, 32 KiB);
-//   - every non-zero (row i, column c, count v) of the strip is a "task" holding a cursor into
-//     the posting list of c (rows of Y containing c, ascending).  Because posting lists are
-//     sorted, a task contributes to chunk [j0, j1) exactly the entries its cursor passes while
-//     the posting's row is < j1: LDS atomic add of v * v', cursor state in registers;
-//   - the epilogue converts the chunk to float32, scales by 1/|x_i| * 1/|y_j| and streams it out
-//     with 16-byte stores (each wave store instruction writes 1 KiB of one output row).
+//   k_gram_sparse      (skm_gram_kernel.h) workgroup per row: every (non-zero, posting) pair of the
+//                      row is read once with independent loads and accumulated in an LDS hash
+//                      table keyed by the neighbour row; the row's (j, exact int32 dot) entries
+//                      are appended to a global neighbour list grouped by 1024-column chunk.
+//   k_gram_sparse_big  the same with an 8192-slot table and room for 4096 non-zeros, for the rows
+//                      the first pass flags (more than 1024 neighbours or 512 distinct k-mers).
+//   k_cosine_write     workgroup per output row, pure streaming writer: per 4096-column step it
+//                      drops the step's neighbour entries into a zeroed LDS tile, scales to float32
+//                      (mode 1: cosine distance) and stores 16 B per lane.  Dominant kernel.
+//   k_cosine_strip     exact for ANY density, the fallback for strips the kernels above cannot
+//                      hold (> 4096 neighbours or distinct k-mers in a row, > 2^20 output columns):
+//                      a workgroup owns 8 output rows and walks the columns in chunks of 1024 with
+//                      dense int32 LDS accumulators; every non-zero holds a cursor into its
+//                      (sorted) posting list and adds v*v' for the postings that fall into the
+//                      chunk.  One dependent memory round trip per posting: slow, but general.
 //
-// That cursor kernel (k_cosine_strip) is correct for any density but pays one dependent memory
-// round trip per posting consumed, so it is now the FALLBACK.  The fast path splits the work:
+// Environment knobs (diagnostics / tuning only): SKM_COSINE_PATH=cursor forces the fallback
+// everywhere; SKM_GRAM_VARIANT / SKM_WRITE_VARIANT select other (equally exact) kernel shapes;
+// SKM_COSINE_OVERLAP=1 runs Gram and writer on two streams; SKM_COSINE_ABLATE / SKM_GRAM_ABLATE
+// build timing-only variants whose RESULTS ARE INVALID (tools/ablate_cosine.py).
 //
-//   k_gram_sparse   workgroup = 2 rows.  All (task, posting) pairs of the strip are flattened
-//                   (LDS prefix sum of posting-list lengths, binary search per pair), so every
-//                   posting is read exactly once with independent, coalesced loads; products go
-//                   into per-row LDS hash tables (4096 slots) keyed by the neighbour row j.  Each
-//                   row's entries are appended to a global neighbour list (j, exact int32 dot)
-//                   grouped by 1024-column output chunk (LDS counting sort).  Rows with > 2048
-//                   neighbours or strips with > 768 non-zeros are flagged for the cursor kernel.
-//   k_cosine_write  workgroup = 8 rows, pure streaming writer: per 1024-column chunk it drops the
-//                   few neighbour entries of the chunk into a zeroed LDS tile, scales to float32
-//                   and stores 16 B per lane (1 KiB per wave instruction).  Bound by HBM writes.
-//
-// The dense small-basis case (a true dense GEMM) is served by the i8 MFMA kernel in
+// The dense small-basis case (a true dense GEMM) is served by the i8 MFMA kernels in
 // skm_dense.hip instead.
 #include <cstdlib>
 #include <cstring>
@@ -517,9 +515,9 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         }
         SKM_TRY(skm_check_launch("k_gram_sparse"));
         {
-            // rows with more neighbours than the small tables hold: 16384-slot table, one row per workgroup
+            // rows the small tables cannot hold: 8192-slot table and up to 4096 non-zeros, one row per workgroup
             SKM_PROF_ON(ctx, "k_gram_sparse_big", sg);
-            k_gram_sparse_big<16384, 512, 2, 4><<<skm_grid_cap(ctx, rows_b, 1), 512, 0, sg>>>(
+            k_gram_sparse_big<8192, 512, 8, 4><<<skm_grid_cap(ctx, rows_b, 1), 512, 0, sg>>>(
                 d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, r0, r1, nchunk, g_ent, cap_ent, g_counter, gs, gl, ol, oc);
         }
         SKM_TRY(skm_check_launch("k_gram_sparse_big"));
