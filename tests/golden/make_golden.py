@@ -337,6 +337,33 @@ def main(ref_root):
             lengths=out["lengths"],
         )
 
+    # ---- G10: a real proteome from the reference's CI data (.test/input_learnapp, config k=8 alphabet=2)
+    prot = os.path.join(ref_root, ".test", "input_learnapp", "UP000322080_2603819.fasta")
+    shutil.copyfile(prot, os.path.join(HERE, "data", "UP000322080_2603819.fasta"))
+    os.chmod(os.path.join(HERE, "data", "UP000322080_2603819.fasta"), 0o644)
+    precs = read_fasta(prot)
+    out = run_rule(V, A, precs, 2, 8)
+    counts = run_counts(out["seqs"], out["kmerlist"])
+    assert ((counts > 0) == (out["vecs"] > 0)).all()
+    sample = np.sort(np.random.default_rng(10).choice(len(precs), size=24, replace=False))
+    cos_rows = cosine_similarity(counts[sample], counts)
+    np.savez_compressed(
+        os.path.join(HERE, "g10_proteome_solvacc_k8.npz"),
+        kmerlist=out["kmerlist"],
+        ids=out["ids"],
+        lengths=out["lengths"],
+        reduced_lengths=np.asarray([len(x) for x in out["seqs"]]),
+        row_count_sums=counts.sum(axis=1),
+        row_presence_sums=out["vecs"].sum(axis=1).astype(np.int64),
+        col_totals=counts.sum(axis=0),
+        col_df=(counts > 0).sum(axis=0),
+        nnz=np.asarray([(counts > 0).sum()]),
+        max_count=np.asarray([counts.max()]),
+        sample_rows=sample,
+        cosine_rows=cos_rows,
+        sample_counts=counts[sample[:4]],
+    )
+
     # ---- G9: score.connection_matrix_from_features / utils.to_feature_matrix ---------
     X = rng.integers(0, 4, size=(9, 23)).astype(float)
     X[3] = 0

@@ -604,3 +604,64 @@ def test_degenerate_batches(ctx):
     from oracle import ref_path
 
     assert np.abs(R - ref_path.cosine_similarity(X, Y)).max() <= COS_TOL and R.shape == (3, 1)
+
+
+# ------------------------------------------------------------------ real proteome (reference CI data)
+def test_real_proteome_rule_outputs_and_cosine(ctx):
+    """UP000322080 (3 383 proteins, up to 2 478 aa) at the reference's CI config k=8, alphabet 2:
+    rule outputs against the reference-generated fixture; cosine through the sparse kernels (every
+    row has thousands of neighbours -> large-table pass) and through the i8 MFMA GEMM."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.io import read_fasta
+    from snekmer_amd.kmerize import vectorize_records
+    from snekmer_amd.utils import pack_sequences
+
+    g = gnpz("g10_proteome_solvacc_k8.npz")
+    recs = read_fasta(os.path.join(GOLDEN, "data", "UP000322080_2603819.fasta"))
+    out = vectorize_records(recs, 2, 8, ctx=ctx)
+    assert list(out["kmerlist"]) == list(g["kmerlist"]) and list(out["ids"]) == list(g["ids"])
+    assert list(out["lengths"]) == list(g["lengths"])
+    assert [len(s) for s in out["seqs"]] == list(g["reduced_lengths"])
+    assert (out["vecs"].sum(axis=1).astype(np.int64) == g["row_presence_sums"]).all()
+    n = len(recs)
+    dense_counts = csr_to_dense(out["counts_rowptr"], out["counts_col"], out["counts_val"], len(g["kmerlist"]))
+    assert (dense_counts.sum(axis=1) == g["row_count_sums"]).all()
+    assert (dense_counts.sum(axis=0) == g["col_totals"]).all() and ((dense_counts > 0).sum(axis=0) == g["col_df"]).all()
+    assert (dense_counts[g["sample_rows"][:4]] == g["sample_counts"]).all()
+    assert int(dense_counts.max()) == int(g["max_count"][0])
+
+    lut = A.build_lut(2)
+    res, off = pack_sequences([s for _, s in recs])
+    batch = engine.SeqBatch(ctx, res, off)
+    for pipe in (engine.Pipeline(ctx, lut, 8), engine.DensePipeline(ctx, lut, 8)):
+        o = pipe.step(batch)
+        ld = o.shape[1]
+        got = np.stack([o.download(n, offset=int(r) * ld) for r in g["sample_rows"]])
+        assert np.abs(got - g["cosine_rows"]).max() <= COS_TOL, type(pipe).__name__
+
+
+def test_real_proteome_sparse_regime_standard_k12(ctx):
+    """Same proteome in the k=12 regime the reference cannot reach (its dense float64 matrix
+    would need tens of GB): uint64 codes, sequences up to 2 467 windows (LDS-block size classes),
+    checked against the pinned C oracle."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.io import read_fasta
+    from snekmer_amd.utils import pack_sequences
+
+    orc = _oracle()
+    recs = read_fasta(os.path.join(GOLDEN, "data", "UP000322080_2603819.fasta"))
+    lut = A.build_lut("standard")
+    res, off = pack_sequences([s for _, s in recs])
+    batch = engine.SeqBatch(ctx, res, off)
+    pipe = engine.Pipeline(ctx, lut, 12)
+    out = pipe.step(batch)
+    n = batch.n
+    rowptr, codes, counts, _ = pipe.csr.host()
+    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, 12, res, off)
+    assert (rowptr == o_rowptr).all() and (codes == o_codes).all() and (counts == o_counts).all()
+    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
+    ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), np.arange(n))
+    S = out.download().reshape(out.shape)[:n, :n]
+    assert np.abs(S - ref).max() <= COS_TOL

@@ -159,3 +159,22 @@ def test_g9_connection_matrix():
     g = gnpz("g9_connection.npz")
     np.testing.assert_allclose(ref_path.cosine_distances(g["X"]), g["cosine"], atol=1e-13)
     np.testing.assert_allclose(ref_path.hamming_similarity(g["X"] > 0), g["jaccard"], atol=1e-13)
+
+
+def test_g10_real_proteome_oracle():
+    """The reference's own CI proteome (.test/input_learnapp, k=8, alphabet 2 = solvacc)."""
+    g = gnpz("g10_proteome_solvacc_k8.npz")
+    recs = ref_path.read_fasta(os.path.join(GOLDEN, "data", "UP000322080_2603819.fasta"))
+    assert [r[0] for r in recs] == list(g["ids"]) and [len(r[1]) for r in recs] == list(g["lengths"])
+    lut = A.build_lut(2)
+    seq, off = pack_sequences([s for _, s in recs])
+    rowptr, codes, cnt, first = c_oracle.count_csr(lut.rank, lut.nsym, 8, seq, off)
+    basis, df, tot, fk, col = c_oracle.basis(rowptr, codes, cnt, first)
+    order = np.argsort(fk, kind="stable")
+    assert list(lut.decode(basis[order], 8)) == list(g["kmerlist"])
+    assert (tot[order] == g["col_totals"]).all() and (df[order] == g["col_df"]).all()
+    assert len(codes) == int(g["nnz"][0]) and int(cnt.max()) == int(g["max_count"][0])
+    assert (np.add.reduceat(np.r_[cnt, 0].astype(np.int64), rowptr[:-1]) * (np.diff(rowptr) > 0) == g["row_count_sums"]).all()
+    assert (np.diff(rowptr) == g["row_presence_sums"]).all()
+    S = c_oracle.cosine_rows(rowptr, col, cnt, len(basis), g["sample_rows"])
+    np.testing.assert_allclose(S, g["cosine_rows"], atol=1e-12)
