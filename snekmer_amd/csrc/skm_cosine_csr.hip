@@ -503,6 +503,15 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
                 SKM_LAUNCH_G(1, 1, 2048, 256, 2, 4);
             else if (gabl == 2)
                 SKM_LAUNCH_G(2, 1, 2048, 256, 2, 4);
+            else if (gabl == 4)
+                SKM_LAUNCH_G(4, 1, 2048, 256, 2, 4);
+            else if (gabl == 5)
+                SKM_LAUNCH_G(5, 1, 2048, 256, 2, 4);
+            else if (gabl == 3) {  // phase stamps (exact results, slower): read with skm_debug_gram_phases
+                unsigned long long zeros[8] = {};
+                SKM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gram_phase_ticks), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice, sg));
+                SKM_LAUNCH_G(3, 1, 2048, 256, 2, 4);
+            }
             else if (gvar == 1)
                 SKM_LAUNCH_G(0, 1, 4096, 256, 2, 4);
             else if (gvar == 2)
@@ -585,4 +594,14 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     }
 #undef SKM_LAUNCH_A
     return skm_check_launch("k_cosine_strip");
+}
+
+// Diagnostic: per-phase shader-clock ticks summed over the workgroups of the last k_gram_sparse
+// launch made with SKM_GRAM_ABLATE=3 (tools/ablate_cosine.py).  Not part of the public header.
+extern "C" int skm_debug_gram_phases(skm_ctx *ctx, unsigned long long *h_ticks8)
+{
+    SKM_REQUIRE(ctx && h_ticks8, SKM_E_BADARG, "skm_debug_gram_phases: bad argument");
+    SKM_HIP(hipStreamSynchronize(ctx->stream));
+    SKM_HIP(hipMemcpyFromSymbol(h_ticks8, HIP_SYMBOL(g_gram_phase_ticks), 8 * sizeof(unsigned long long)));
+    return SKM_OK;
 }

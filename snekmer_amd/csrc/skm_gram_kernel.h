@@ -10,6 +10,9 @@
 #pragma once
 
 constexpr int GNB = 1024;  // output chunks (of CH columns) a neighbour list can be grouped by
+// diagnostic only (GABL == 3): summed shader-clock ticks per phase over all workgroups
+__device__ unsigned long long g_gram_phase_ticks[8];
+
 constexpr uint32_t G_OVERFLOW = 0xFFFFFFFFu;
 constexpr uint32_t G_SINGLETON = 0xFFFFFFFFu;  // colidx of a k-mer that occurs in one row only
 
@@ -44,6 +47,16 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     uint32_t *hist = s_u;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int rows = (int)min((int64_t)GR, row1 - i0);
+    unsigned long long stamp = 0;
+    auto phase = [&](int idx) {
+        if (GABL == 3 && tid == 0) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (idx >= 0)
+                atomicAdd(&g_gram_phase_ticks[idx], now - stamp);
+            stamp = now;
+        }
+    };
+    phase(-1);
     // rows this kernel cannot hold are flagged (and listed for the large-table pass)
     auto flag_rows = [&]() {
         if (tid < rows) {
@@ -64,6 +77,7 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
         (&hvals[0][0])[z] = 0;
     }
     __syncthreads();
+    phase(0);  // table zeroing + row pointers
     const int64_t e0 = s_rp[0];
     const int64_t ntasks64 = s_rp[GR] - e0;
     if (ntasks64 > GTCAP) {
@@ -125,6 +139,7 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     if (tid == 0)
         t_scan[ntasks] = total;
     __syncthreads();
+    phase(1);  // task loads + prefix sum
 
     // every (task, posting) pair once.  A thread takes SL consecutive pairs per step: one
     // branch-free binary search locates the first pair's task, the rest walk forward; all posting
@@ -152,7 +167,8 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
                     jj[u] = (uint32_t)(i0 + (lv[u] >> 28));
                     ww[u] = lv[u] & 0x0FFFFFFFu;
                 } else {
-                    const uint64_t pw = ypost[t_start[t] + (g - t_scan[t])];
+                    const uint64_t pw = GABL == 5 ? (uint64_t)((g * 2654435761u) % 100000u) | (1ull << 32)  // diagnostic: no load
+                                                  : ypost[t_start[t] + (g - t_scan[t])];
                     jj[u] = (uint32_t)pw;
                     ww[u] = (uint32_t)(pw >> 32);
                 }
@@ -160,7 +176,9 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
         }
 #pragma unroll
         for (int u = 0; u < SL; ++u) {
-            if (g0 + u < total) {
+            if (GABL == 4) {  // diagnostic: loads only, no hash insert
+                asm volatile("" ::"v"(jj[u]), "v"(ww[u]), "v"(lv[u]));
+            } else if (g0 + u < total) {
                 const uint32_t j = jj[u];
                 const int prod = (int)(lv[u] & 0x0FFFFFFFu) * (int)ww[u];
                 const int li = (int)(lv[u] >> 28);
@@ -188,6 +206,7 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
         }
     }
     __syncthreads();
+    phase(2);  // pair loop
     if (s_over) {
         flag_rows();
         return;
@@ -233,6 +252,7 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
         }
     }
     __syncthreads();
+    phase(3);  // chunk histogram + scan
     bool fits[GR];
 #pragma unroll
     for (int r = 0; r < GR; ++r)
@@ -249,6 +269,7 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
         g_start[i0 - row0 + tid] = s_off[tid];
         g_len[i0 - row0 + tid] = fits[tid] ? s_distinct[tid] : G_OVERFLOW;
     }
+    phase(4);  // emit
 }
 
 // One strip of GR consecutive rows per workgroup.

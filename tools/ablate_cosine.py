@@ -24,7 +24,7 @@ gres = {}
 for rnd in range(3):
     for name, env in (("full", {}), ("w8x1024", {"SKM_WRITE_VARIANT": "1"}), ("w16x1024", {"SKM_WRITE_VARIANT": "2"}),
                       ("w1x4096", {"SKM_WRITE_VARIANT": "3"}), ("w2x2048", {"SKM_WRITE_VARIANT": "4"}),
-                      ("w2x4096", {"SKM_WRITE_VARIANT": "5"}), ("w1x2048", {"SKM_WRITE_VARIANT": "6"}), ("no_pairs", {"SKM_GRAM_ABLATE": "1"}), ("no_emit", {"SKM_GRAM_ABLATE": "2"}),
+                      ("w2x4096", {"SKM_WRITE_VARIANT": "5"}), ("w1x2048", {"SKM_WRITE_VARIANT": "6"}), ("no_pairs", {"SKM_GRAM_ABLATE": "1"}), ("no_emit", {"SKM_GRAM_ABLATE": "2"}), ("no_insert", {"SKM_GRAM_ABLATE": "4"}), ("no_load", {"SKM_GRAM_ABLATE": "5"}),
                       ("v1", {"SKM_GRAM_VARIANT": "1"}), ("v2", {"SKM_GRAM_VARIANT": "2"}), ("v3", {"SKM_GRAM_VARIANT": "3"}),
                       ("v4", {"SKM_GRAM_VARIANT": "4"}), ("v5", {"SKM_GRAM_VARIANT": "5"}), ("v6", {"SKM_GRAM_VARIANT": "6"})):
         for k in ("SKM_GRAM_ABLATE", "SKM_GRAM_VARIANT", "SKM_WRITE_VARIANT"):
@@ -48,3 +48,15 @@ for rnd in range(0):
 os.environ["SKM_COSINE_ABLATE"] = "0"
 for abl, v in results.items():
     print(f"ABL={abl}: min {min(v):.3f} ms  median {sorted(v)[len(v)//2]:.3f} ms  all {['%.2f' % x for x in v]}")
+
+# phase stamps of the Gram kernel (diagnostic build, exact results)
+import ctypes as C
+os.environ["SKM_GRAM_ABLATE"] = "3"
+pipe.cosine()
+ticks = (C.c_ulonglong * 8)()
+ctx.lib.skm_debug_gram_phases.argtypes = [C.c_void_p, C.c_void_p]
+ctx.lib.skm_debug_gram_phases(ctx.handle, ticks)
+os.environ.pop("SKM_GRAM_ABLATE")
+names = ["zero+rowptr", "tasks+scan", "pair loop", "hist+scan", "emit"]
+tot = sum(ticks[:5]) or 1
+print("gram phases (ticks per row, share): " + ", ".join(f"{n} {ticks[i]/pipe.csr.n:.0f} ({100*ticks[i]/tot:.0f}%)" for i, n in enumerate(names)))
