@@ -213,6 +213,26 @@ int skm_csr_group_sum(skm_ctx *ctx, int64_t n, int64_t nnz, const int64_t *d_row
                       const uint32_t *d_counts, const uint32_t *d_group, int64_t ngroups, int64_t *d_out_rowptr,
                       uint32_t *d_out_col, uint32_t *d_out_val, int64_t *h_out_nnz);
 
+/* Exact sparse Gram rows ("neighbour lists"): for rows [row0,row1) of X, every row j of Y sharing at
+ * least one column, with the exact int32 dot product.  This is the reduced output for problem sizes
+ * whose dense N x M matrix cannot be stored (BASELINE configs[3], 1M x 1M).
+ *   d_start[row1-row0], d_len[row1-row0]: position and length of each row's list in d_ent;
+ *   d_ent[cap_ent]: entries (j << 32 | dot), order within a row unspecified;
+ *   d_len == 0xFFFFFFFF marks a row the kernels could not hold (> 8192 neighbours or > 4096
+ *   distinct k-mers, or cap_ent exhausted); *h_overflow_rows counts them, *h_total_entries is the
+ *   number of entries written (both host-synchronous). */
+int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
+                       const uint32_t *d_xcounts, int64_t m, int64_t ncols, const uint32_t *d_ycolptr,
+                       const uint64_t *d_ypost, int64_t row0, int64_t row1, int64_t cap_ent, uint64_t *d_start,
+                       uint32_t *d_len, uint64_t *d_ent, int64_t *h_total_entries, int64_t *h_overflow_rows);
+
+/* k best cosine neighbours per row from the lists of skm_gram_neighbors: score = dot * xrnorm[row0+r]
+ * * yrnorm[j], descending, ties towards the lower j; exclude_self drops j == row0 + r.
+ * d_idx / d_val are [nrows x k]; missing slots hold 0xFFFFFFFF / 0. */
+int skm_neighbors_topk(skm_ctx *ctx, int64_t nrows, int64_t row0, const uint64_t *d_start, const uint32_t *d_len,
+                       const uint64_t *d_ent, const float *d_xrnorm, const float *d_yrnorm, int k, int exclude_self,
+                       uint32_t *d_idx, float *d_val);
+
 /* Exact sum over columns of df*(df) pairs the sparse kernel will visit (cost model input). */
 int skm_pair_work(skm_ctx *ctx, int64_t ncols, const uint32_t *d_colptr, uint64_t *h_pairs);
 

@@ -372,6 +372,152 @@ __global__ __launch_bounds__(WCH / 4) void k_cosine_write(const uint64_t *__rest
     }
 }
 
+// wave per row: k rounds of "largest entry below the previous pick" in (score desc, j asc) order
+__global__ __launch_bounds__(256) void k_neighbors_topk(int64_t nrows, int64_t row0, const uint64_t *__restrict__ g_start,
+                                                        const uint32_t *__restrict__ g_len,
+                                                        const uint64_t *__restrict__ g_ent,
+                                                        const float *__restrict__ xr, const float *__restrict__ yr, int k,
+                                                        int exclude_self, uint32_t *__restrict__ idx,
+                                                        float *__restrict__ val)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < nrows; r += nwaves) {
+        const uint32_t len = g_len[r] == G_OVERFLOW ? 0u : g_len[r];
+        const uint64_t st = g_start[r];
+        const float ri = xr[row0 + r];
+        const uint32_t self = (uint32_t)(row0 + r);
+        float pv = INFINITY;  // previous pick
+        uint32_t pj = 0;
+        bool first = true;
+        for (int t = 0; t < k; ++t) {
+            float bv = -INFINITY;
+            uint32_t bj = 0xFFFFFFFFu;
+            for (uint32_t e = lane; e < len; e += 64) {
+                const uint64_t w = g_ent[st + e];
+                const uint32_t j = (uint32_t)(w >> 32);
+                if (exclude_self && j == self)
+                    continue;
+                const float v = (float)(int)(uint32_t)w * ri * yr[j];
+                const bool below = first || v < pv || (v == pv && j > pj);
+                if (below && (v > bv || (v == bv && j < bj))) {
+                    bv = v;
+                    bj = j;
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o);
+                const uint32_t oj = __shfl_xor(bj, o);
+                if (ov > bv || (ov == bv && oj < bj)) {
+                    bv = ov;
+                    bj = oj;
+                }
+            }
+            if (lane == 0) {
+                idx[r * k + t] = bj;
+                val[r * k + t] = bj == 0xFFFFFFFFu ? 0.0f : bv;
+            }
+            if (bj == 0xFFFFFFFFu) {
+                for (int u = t + 1 + lane; u < k; u += 64) {
+                    idx[r * k + u] = 0xFFFFFFFFu;
+                    val[r * k + u] = 0.0f;
+                }
+                break;
+            }
+            pv = bv;
+            pj = bj;
+            first = false;
+        }
+    }
+}
+
+__global__ void k_count_overflow(int64_t nrows, const uint32_t *__restrict__ g_len, unsigned int *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ov = i < nrows && g_len[i] == G_OVERFLOW;
+    const unsigned long long bal = __ballot(ov);
+    if ((threadIdx.x & 63) == 0 && bal)
+        atomicAdd(out, (unsigned int)__popcll(bal));
+}
+
+}  // namespace
+
+extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
+                                  const uint32_t *d_xcounts, int64_t m, int64_t ncols, const uint32_t *d_ycolptr,
+                                  const uint64_t *d_ypost, int64_t row0, int64_t row1, int64_t cap_ent,
+                                  uint64_t *d_start, uint32_t *d_len, uint64_t *d_ent, int64_t *h_total_entries,
+                                  int64_t *h_overflow_rows)
+{
+    SKM_REQUIRE(ctx && n >= 0 && m >= 0 && ncols >= 0 && cap_ent >= 0 && h_total_entries && h_overflow_rows, SKM_E_BADARG,
+                "skm_gram_neighbors: bad argument");
+    SKM_REQUIRE(row0 >= 0 && row0 <= row1 && row1 <= n, SKM_E_BADARG, "skm_gram_neighbors: bad row range");
+    SKM_REQUIRE(m < ((int64_t)1 << 32) - 1, SKM_E_OVERFLOW, "skm_gram_neighbors: m >= 2^32");
+    *h_total_entries = 0;
+    *h_overflow_rows = 0;
+    const int64_t nrows = row1 - row0;
+    if (nrows == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_xrowptr && d_ycolptr && d_start && d_len && (cap_ent == 0 || d_ent), SKM_E_BADARG,
+                "skm_gram_neighbors: null array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
+    uint32_t *list1 = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_F, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
+    uint32_t *list2 = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
+    unsigned long long *g_counter = (unsigned long long *)((uint8_t *)p + 2048);
+    uint32_t *cnt1 = (uint32_t *)((uint8_t *)p + 2048 + 8), *cnt2 = cnt1 + 1, *novf = cnt1 + 2;
+    SKM_HIP(hipMemsetAsync(g_counter, 0, 8 + 16, st));
+    const int nchunk = (int)min((int64_t)GNB, skm_ceil_div(m, CH));
+    const unsigned long long cap = (unsigned long long)cap_ent;
+    {
+        SKM_PROF(ctx, "k_gram_sparse");
+        k_gram_sparse<0, 1, 2048, 256, 2, 4><<<(unsigned)nrows, 256, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr,
+                                                                              d_ypost, row0, row1, nchunk, d_ent, cap,
+                                                                              g_counter, d_start, d_len, list1, cnt1);
+    }
+    SKM_TRY(skm_check_launch("k_gram_sparse"));
+    {
+        SKM_PROF(ctx, "k_gram_sparse_big");
+        k_gram_sparse_big<8192, 512, 8, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
+            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, nchunk, d_ent, cap, g_counter, d_start, d_len,
+            list1, cnt1, list2, cnt2);
+        // last resort inside LDS: 16384 slots (8192 neighbours), up to 1024 distinct k-mers
+        k_gram_sparse_big<16384, 512, 2, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
+            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, nchunk, d_ent, cap, g_counter, d_start, d_len,
+            list2, cnt2, nullptr, nullptr);
+    }
+    SKM_TRY(skm_check_launch("k_gram_sparse_big"));
+    k_count_overflow<<<(unsigned)skm_ceil_div(nrows, 256), 256, 0, st>>>(nrows, d_len, novf);
+    SKM_TRY(skm_check_launch("k_count_overflow"));
+    unsigned long long *h = (unsigned long long *)ctx->h_pinned;
+    SKM_HIP(hipMemcpyAsync(h, g_counter, 8, hipMemcpyDeviceToHost, st));
+    SKM_HIP(hipMemcpyAsync(h + 1, novf, 4, hipMemcpyDeviceToHost, st));
+    SKM_HIP(hipStreamSynchronize(st));
+    *h_total_entries = (int64_t)(h[0] < cap ? h[0] : cap);
+    *h_overflow_rows = (int64_t)*(uint32_t *)(h + 1);
+    return SKM_OK;
+}
+
+extern "C" int skm_neighbors_topk(skm_ctx *ctx, int64_t nrows, int64_t row0, const uint64_t *d_start, const uint32_t *d_len,
+                                  const uint64_t *d_ent, const float *d_xrnorm, const float *d_yrnorm, int k,
+                                  int exclude_self, uint32_t *d_idx, float *d_val)
+{
+    SKM_REQUIRE(ctx && nrows >= 0 && row0 >= 0 && k >= 1 && k <= 1024, SKM_E_BADARG, "skm_neighbors_topk: bad argument");
+    if (nrows == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_start && d_len && d_xrnorm && d_yrnorm && d_idx && d_val, SKM_E_BADARG, "skm_neighbors_topk: null array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    SKM_PROF(ctx, "k_neighbors_topk");
+    k_neighbors_topk<<<skm_grid_cap(ctx, skm_ceil_div(nrows, 4), 16), 256, 0, ctx->stream>>>(
+        nrows, row0, d_start, d_len, d_ent, d_xrnorm, d_yrnorm, k, exclude_self, d_idx, d_val);
+    return skm_check_launch("k_neighbors_topk");
+}
+
+namespace {
 }  // namespace
 
 extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
@@ -527,7 +673,8 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
             // rows the small tables cannot hold: 8192-slot table and up to 4096 non-zeros, one row per workgroup
             SKM_PROF_ON(ctx, "k_gram_sparse_big", sg);
             k_gram_sparse_big<8192, 512, 8, 4><<<skm_grid_cap(ctx, rows_b, 1), 512, 0, sg>>>(
-                d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, r0, r1, nchunk, g_ent, cap_ent, g_counter, gs, gl, ol, oc);
+                d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, r0, r1, nchunk, g_ent, cap_ent, g_counter, gs, gl, ol, oc,
+                nullptr, nullptr);
         }
         SKM_TRY(skm_check_launch("k_gram_sparse_big"));
         if (overlap) {

@@ -231,7 +231,7 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     for (int z = tid; z < GR * GH; z += GT) {
         const uint32_t key = (&hkeys[0][0])[z];
         if (key)
-            atomicAdd(&hist[(z / GH) * GNB + ((key - 1u) / CH)], 1u);
+            atomicAdd(&hist[(z / GH) * GNB + min((int)((key - 1u) / CH), nchunk - 1)], 1u);
     }
     __syncthreads();
     if (wid < GR) {  // exclusive scan of row wid's chunk counters by one wave
@@ -261,7 +261,7 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
         const uint32_t key = (&hkeys[0][0])[z];
         const int r = z / GH;
         if (key && fits[r]) {
-            const uint32_t pos = atomicAdd(&hist[r * GNB + ((key - 1u) / CH)], 1u);
+            const uint32_t pos = atomicAdd(&hist[r * GNB + min((int)((key - 1u) / CH), nchunk - 1)], 1u);
             g_ent[s_off[r] + pos] = ((uint64_t)(key - 1u) << 32) | (uint32_t)(&hvals[0][0])[z];
         }
     }
@@ -301,14 +301,16 @@ __global__ __launch_bounds__(GT) void k_gram_sparse_big(const int64_t *__restric
                                                         unsigned long long *__restrict__ g_counter,
                                                         uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len,
                                                         const uint32_t *__restrict__ row_list,
-                                                        const uint32_t *__restrict__ row_count)
+                                                        const uint32_t *__restrict__ row_count,
+                                                        uint32_t *__restrict__ over_list,
+                                                        uint32_t *__restrict__ over_count)
 {
     const uint32_t cnt = *row_count;
     for (uint32_t idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
         const int64_t i0 = row0 + row_list[idx];
         // a one-row strip: clamp row1 so that the strip never spills into the next row
         gram_strip<0, 1, GH, GT, GQ, SL>(i0, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0, i0 + 1, nchunk, g_ent, cap_ent,
-                                         g_counter, g_start, g_len, nullptr, nullptr);
+                                         g_counter, g_start, g_len, over_list, over_count);
         __syncthreads();
     }
 }

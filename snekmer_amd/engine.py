@@ -249,6 +249,49 @@ def cosine_dense_i8(ctx, n: int, m: int, kdim: int, x_i8, y_i8, x_rnorm, y_rnorm
     return out
 
 
+class NeighborLists:
+    """Exact sparse Gram rows of a row block: per row the rows j sharing a k-mer and the int32 dot."""
+
+    def __init__(self, ctx, row0, row1, start, length, ent, total, overflow_rows):
+        self.ctx, self.row0, self.row1 = ctx, row0, row1
+        self.start, self.length, self.ent = start, length, ent
+        self.total, self.overflow_rows = total, overflow_rows
+
+    def host(self):
+        """(start uint64[nrows], len uint32[nrows] (0xFFFFFFFF = not held), j uint32[total], dot int32[total])."""
+        nrows = self.row1 - self.row0
+        ent = self.ent.download(self.total)
+        return (self.start.download(nrows), self.length.download(nrows), (ent >> np.uint64(32)).astype(np.uint32),
+                (ent & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32))
+
+
+def gram_neighbors(ctx, x: CountsCSR, m: int, ncols: int, colptr, post, row0: int = 0, row1: Optional[int] = None,
+                   cap_entries: Optional[int] = None) -> NeighborLists:
+    """Neighbour lists (exact sparse Gram rows) for rows [row0,row1) of `x` against the postings of an
+    m-row matrix: the reduced output when the dense matrix cannot be stored (skm_gram_neighbors)."""
+    row1 = x.n if row1 is None else row1
+    nrows = row1 - row0
+    cap = int(cap_entries if cap_entries is not None else 16 * max(x.nnz, 1) + (1 << 20))
+    start = ctx.empty(max(nrows, 1), np.uint64)
+    length = ctx.empty(max(nrows, 1), np.uint32)
+    ent = ctx.empty(max(cap, 1), np.uint64)
+    total, ovf = _i64(0), _i64(0)
+    ctx.call("skm_gram_neighbors", _i64(x.n), _ptr(x.rowptr), _ptr(x.colidx), _ptr(x.counts), _i64(m), _i64(ncols),
+             _ptr(colptr), _ptr(post), _i64(row0), _i64(row1), _i64(cap), _ptr(start), _ptr(length), _ptr(ent),
+             C.byref(total), C.byref(ovf))
+    return NeighborLists(ctx, row0, row1, start, length, ent, int(total.value), int(ovf.value))
+
+
+def neighbors_topk(ctx, nb: NeighborLists, x_rnorm, y_rnorm, k: int, exclude_self: bool = True):
+    """(idx uint32[nrows,k], score float32[nrows,k]): the k best cosine neighbours of every row."""
+    nrows = nb.row1 - nb.row0
+    idx = ctx.empty(max(nrows * k, 1), np.uint32)
+    val = ctx.empty(max(nrows * k, 1), np.float32)
+    ctx.call("skm_neighbors_topk", _i64(nrows), _i64(nb.row0), _ptr(nb.start), _ptr(nb.length), _ptr(nb.ent),
+             _ptr(x_rnorm), _ptr(y_rnorm), k, 1 if exclude_self else 0, _ptr(idx), _ptr(val))
+    return idx.download(nrows * k).reshape(nrows, k), val.download(nrows * k).reshape(nrows, k)
+
+
 class DensePipeline:
     """Small-basis variant of Pipeline: the full |S|^k basis as dense int8 counts, cosine by MFMA.
 

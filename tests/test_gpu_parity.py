@@ -665,3 +665,54 @@ def test_real_proteome_sparse_regime_standard_k12(ctx):
     ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), np.arange(n))
     S = out.download().reshape(out.shape)[:n, :n]
     assert np.abs(S - ref).max() <= COS_TOL
+
+
+# ------------------------------------------------------------------ neighbour lists / top-k (config 4 output)
+def test_gram_neighbors_and_topk_vs_oracle(ctx):
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+
+    orc = _oracle()
+    lut = A.build_lut("red6")
+    k = 12
+    seqs, (res, off) = _mixed_batch(seed=9, n=1200)
+    batch = engine.SeqBatch(ctx, res, off)
+    pipe = engine.Pipeline(ctx, lut, k)
+    pipe.vectorize(batch)
+    n = batch.n
+    b = pipe.basis
+    lo, hi = 100, 1100
+    nb = engine.gram_neighbors(ctx, pipe.csr, n, b.ncols, b.colptr, b.post, row0=lo, row1=hi)
+    start, length, jj, dot = nb.host()
+    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
+    ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), np.arange(lo, hi))  # float64 cosine rows
+    nsq = np.array([float((o_counts[o_rowptr[i]:o_rowptr[i + 1]].astype(np.float64) ** 2).sum()) for i in range(n)])
+    norms = np.sqrt(np.where(nsq > 0, nsq, 1.0))
+    held = 0
+    for r in range(hi - lo):
+        if length[r] == 0xFFFFFFFF:
+            continue
+        held += 1
+        js = jj[int(start[r]) : int(start[r]) + int(length[r])]
+        ds = dot[int(start[r]) : int(start[r]) + int(length[r])]
+        assert len(set(js.tolist())) == len(js)
+        exp_nz = np.nonzero(ref[r] > 0)[0]
+        assert sorted(js.tolist()) == exp_nz.tolist()
+        gram = ref[r, js] * norms[lo + r] * norms[js]
+        assert np.abs(ds - np.rint(gram)).max() == 0
+    assert held >= (hi - lo) - nb.overflow_rows and nb.overflow_rows <= 4  # only the 9k/20k-window monsters may overflow
+    kk = 7
+    idx, val = engine.neighbors_topk(ctx, nb, pipe.rnorm, pipe.rnorm, kk, exclude_self=True)
+    for r in range(0, hi - lo, 13):
+        if length[r] == 0xFFFFFFFF:
+            continue
+        row = ref[r].copy()
+        row[lo + r] = -1.0  # self excluded
+        cand = np.nonzero(row > 0)[0]
+        order = cand[np.lexsort((cand, -np.round(row[cand], 12)))][:kk]
+        got = idx[r][idx[r] != 0xFFFFFFFF]
+        # float32 scores can swap near-ties relative to float64: compare as score lists and as sets of clear winners
+        assert len(got) == min(kk, len(cand))
+        assert np.abs(val[r][: len(got)] - row[got]).max() <= COS_TOL
+        assert np.abs(np.sort(row[got])[::-1] - row[order][: len(got)]).max() <= COS_TOL
