@@ -218,8 +218,8 @@ int skm_csr_group_sum(skm_ctx *ctx, int64_t n, int64_t nnz, const int64_t *d_row
  * whose dense N x M matrix cannot be stored (BASELINE configs[3], 1M x 1M).
  *   d_start[row1-row0], d_len[row1-row0]: position and length of each row's list in d_ent;
  *   d_ent[cap_ent]: entries (j << 32 | dot), order within a row unspecified;
- *   d_len == 0xFFFFFFFF marks a row the kernels could not hold (> 8192 neighbours or > 4096
- *   distinct k-mers, or cap_ent exhausted); *h_overflow_rows counts them, *h_total_entries is the
+ *   d_len == 0xFFFFFFFF marks a row the kernels could not hold (> 65536 neighbours, or cap_ent
+ *   exhausted); *h_overflow_rows counts them, *h_total_entries is the
  *   number of entries written (both host-synchronous). */
 int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
                        const uint32_t *d_xcounts, int64_t m, int64_t ncols, const uint32_t *d_ycolptr,

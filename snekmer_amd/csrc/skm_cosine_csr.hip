@@ -432,6 +432,116 @@ __global__ __launch_bounds__(256) void k_neighbors_topk(int64_t nrows, int64_t r
     }
 }
 
+// Last pass of skm_gram_neighbors: rows with more neighbours (or distinct k-mers) than the LDS
+// tables hold.  One row at a time per workgroup, hash table (HS slots) in a per-workgroup slice of
+// global scratch; a wave walks one posting list at a time.  Few rows take this path (3 % at
+// N = 1 M), so it is written for capacity, not speed.  Entries are NOT grouped by chunk.
+constexpr int HS_BITS = 17;
+constexpr int HS = 1 << HS_BITS;  // 131072 slots -> up to 65536 neighbours per row
+
+__global__ __launch_bounds__(1024) void k_gram_sparse_huge(const int64_t *__restrict__ xrowptr,
+                                                           const uint32_t *__restrict__ xcolidx,
+                                                           const uint32_t *__restrict__ xcounts,
+                                                           const uint32_t *__restrict__ ycolptr,
+                                                           const uint64_t *__restrict__ ypost, int64_t row0,
+                                                           uint64_t *__restrict__ g_ent, unsigned long long cap_ent,
+                                                           unsigned long long *__restrict__ g_counter,
+                                                           uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len,
+                                                           const uint32_t *__restrict__ row_list,
+                                                           const uint32_t *__restrict__ row_count,
+                                                           uint32_t *__restrict__ scratch)
+{
+    __shared__ unsigned int s_distinct, s_fill;
+    __shared__ unsigned long long s_off;
+    __shared__ int s_over;
+    uint32_t *hkeys = scratch + (size_t)blockIdx.x * 2 * HS;
+    int *hvals = reinterpret_cast<int *>(hkeys + HS);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+    const uint32_t cnt = *row_count;
+    for (uint32_t idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
+        const int64_t orow = row_list[idx];
+        const int64_t i = row0 + orow;
+        for (int z = tid; z < 2 * HS; z += blockDim.x)
+            hkeys[z] = 0u;  // keys and values are adjacent
+        if (tid == 0) {
+            s_distinct = 0;
+            s_fill = 0;
+            s_over = 0;
+        }
+        __syncthreads();
+        const int64_t b = xrowptr[i], e = xrowptr[i + 1];
+        for (int64_t t = b + wid; t < e; t += nw) {
+            const uint32_t c = xcolidx[t];
+            const int v = (int)xcounts[t];
+            uint32_t pb = 0, pe = 1;
+            const bool single = c == 0xFFFFFFFFu;  // k-mer of this row only
+            if (!single) {
+                pb = ycolptr[c];
+                pe = ycolptr[c + 1];
+            }
+            for (uint32_t p = pb + lane; p < pe; p += 64) {
+                uint32_t j;
+                int prod;
+                if (single) {
+                    j = (uint32_t)i;
+                    prod = v * v;
+                } else {
+                    const uint64_t pw = ypost[p];
+                    j = (uint32_t)pw;
+                    prod = v * (int)(uint32_t)(pw >> 32);
+                }
+                const uint32_t key = j + 1u;
+                uint32_t h = (j * 2654435761u) >> (32 - HS_BITS);
+                for (int probe = 0; probe < HS; ++probe) {
+                    uint32_t seen = __hip_atomic_load(&hkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seen == 0u) {
+                        seen = atomicCAS(&hkeys[h], 0u, key);
+                        if (seen == 0u) {
+                            seen = key;
+                            if (atomicAdd(&s_distinct, 1u) >= (unsigned)(HS / 2))
+                                s_over = 1;
+                        }
+                    }
+                    if (seen == key) {
+                        atomicAdd(&hvals[h], prod);
+                        break;
+                    }
+                    h = (h + 1) & (HS - 1);
+                }
+            }
+            if (s_over)
+                break;
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long off = 0;
+            if (!s_over) {
+                off = atomicAdd(g_counter, (unsigned long long)s_distinct);
+                if (off + s_distinct > cap_ent)
+                    s_over = 1;
+            }
+            s_off = off;
+        }
+        __syncthreads();
+        if (!s_over) {
+            for (int z = tid; z < HS; z += blockDim.x) {
+                const uint32_t key = hkeys[z];
+                if (key) {
+                    const unsigned int pos = atomicAdd(&s_fill, 1u);
+                    g_ent[s_off + pos] = ((uint64_t)(key - 1u) << 32) | (uint32_t)hvals[z];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            g_start[orow] = s_off;
+            g_len[orow] = s_over ? G_OVERFLOW : s_distinct;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void k_count_overflow(int64_t nrows, const uint32_t *__restrict__ g_len, unsigned int *out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -485,12 +595,22 @@ extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrow
         k_gram_sparse_big<8192, 512, 8, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
             d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, nchunk, d_ent, cap, g_counter, d_start, d_len,
             list1, cnt1, list2, cnt2);
-        // last resort inside LDS: 16384 slots (8192 neighbours), up to 1024 distinct k-mers
+        // largest table that fits LDS: 16384 slots (8192 neighbours), up to 1024 distinct k-mers
+        SKM_HIP(hipMemsetAsync(cnt1, 0, 4, st));
         k_gram_sparse_big<16384, 512, 2, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
             d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, nchunk, d_ent, cap, g_counter, d_start, d_len,
-            list2, cnt2, nullptr, nullptr);
+            list2, cnt2, list1, cnt1);
     }
     SKM_TRY(skm_check_launch("k_gram_sparse_big"));
+    {
+        // what is left: table of 131072 slots per workgroup in global scratch
+        const int huge_grid = ctx->num_cus > 0 ? ctx->num_cus : 256;
+        SKM_TRY(skm_ws(ctx, WS_G, sizeof(uint32_t) * 2 * (size_t)HS * (size_t)huge_grid, &p));
+        SKM_PROF(ctx, "k_gram_sparse_huge");
+        k_gram_sparse_huge<<<huge_grid, 1024, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, d_ent, cap,
+                                                       g_counter, d_start, d_len, list1, cnt1, (uint32_t *)p);
+    }
+    SKM_TRY(skm_check_launch("k_gram_sparse_huge"));
     k_count_overflow<<<(unsigned)skm_ceil_div(nrows, 256), 256, 0, st>>>(nrows, d_len, novf);
     SKM_TRY(skm_check_launch("k_count_overflow"));
     unsigned long long *h = (unsigned long long *)ctx->h_pinned;

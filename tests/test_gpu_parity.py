@@ -701,7 +701,7 @@ def test_gram_neighbors_and_topk_vs_oracle(ctx):
         assert sorted(js.tolist()) == exp_nz.tolist()
         gram = ref[r, js] * norms[lo + r] * norms[js]
         assert np.abs(ds - np.rint(gram)).max() == 0
-    assert held >= (hi - lo) - nb.overflow_rows and nb.overflow_rows <= 4  # only the 9k/20k-window monsters may overflow
+    assert nb.overflow_rows == 0 and held == hi - lo  # incl. the 9k/20k-window sequences (global-table pass)
     kk = 7
     idx, val = engine.neighbors_topk(ctx, nb, pipe.rnorm, pipe.rnorm, kk, exclude_self=True)
     for r in range(0, hi - lo, 13):
