@@ -198,6 +198,12 @@ int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint
 int skm_hamming_similarity_from_gram(skm_ctx *ctx, int64_t n, int64_t m, int64_t ncols, const float *d_xcount,
                                      const float *d_ycount, float *d_out, int64_t ld);
 
+/* Jaccard distance on binary rows as scipy's pdist(X, "jaccard") + squareform gives it
+ * (snekmer/scripts/cluster_cluster.py:189-190, the non-BSF branch): (|a|+|b|-2|a&b|) / (|a|+|b|-|a&b|),
+ * 0 when both rows are empty.  Same in-place convention as skm_hamming_similarity_from_gram. */
+int skm_jaccard_distance_from_gram(skm_ctx *ctx, int64_t n, int64_t m, const float *d_xcount, const float *d_ycount,
+                                   float *d_out, int64_t ld);
+
 /* Apply epilogue (snekmer/rules/apply.smk:312-328, rules/learn.smk:831-849): for every row of a
  * score matrix the two largest entries and their columns, i.e. np.argsort(-S, axis=1)[:, :2] with
  * ties broken towards the lower column.  d_idx[2*i+{0,1}], d_val[2*i+{0,1}]; with m == 1 the

@@ -199,8 +199,10 @@ __global__ void k_group_emit(int64_t nnz, const uint64_t *__restrict__ skeys, co
     }
 }
 
-__global__ void k_hamming_from_gram(int64_t n, int64_t m, float inv_cols, const float *__restrict__ xc,
-                                    const float *__restrict__ yc, float *__restrict__ out, int64_t ld)
+// KIND 0: 1 - hamming distance; KIND 1: Jaccard distance.  In place over the intersection sizes.
+template <int KIND>
+__global__ void k_setsim_from_gram(int64_t n, int64_t m, float inv_cols, const float *__restrict__ xc,
+                                   const float *__restrict__ yc, float *__restrict__ out, int64_t ld)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m)
@@ -208,7 +210,13 @@ __global__ void k_hamming_from_gram(int64_t n, int64_t m, float inv_cols, const 
     const float cj = yc[j];
     for (int64_t i = blockIdx.y; i < n; i += gridDim.y) {
         const float g = out[i * ld + j];
-        out[i * ld + j] = 1.0f - (xc[i] + cj - 2.0f * g) * inv_cols;
+        const float sym = xc[i] + cj - 2.0f * g;  // |a xor b|
+        if (KIND == 0) {
+            out[i * ld + j] = 1.0f - sym * inv_cols;
+        } else {
+            const float uni = xc[i] + cj - g;
+            out[i * ld + j] = uni > 0.0f ? sym / uni : 0.0f;
+        }
     }
 }
 
@@ -680,9 +688,23 @@ extern "C" int skm_hamming_similarity_from_gram(skm_ctx *ctx, int64_t n, int64_t
     SKM_REQUIRE(d_xcount && d_ycount && d_out, SKM_E_BADARG, "skm_hamming_similarity_from_gram: null array");
     SKM_HIP(hipSetDevice(ctx->device));
     dim3 grid((unsigned)skm_ceil_div(m, BLK), (unsigned)(n < 1024 ? n : 1024));
-    SKM_PROF(ctx, "k_hamming_from_gram");
-    k_hamming_from_gram<<<grid, BLK, 0, ctx->stream>>>(n, m, 1.0f / (float)ncols, d_xcount, d_ycount, d_out, ld);
-    return skm_check_launch("k_hamming_from_gram");
+    SKM_PROF(ctx, "k_setsim_from_gram");
+    k_setsim_from_gram<0><<<grid, BLK, 0, ctx->stream>>>(n, m, 1.0f / (float)ncols, d_xcount, d_ycount, d_out, ld);
+    return skm_check_launch("k_setsim_from_gram");
+}
+
+extern "C" int skm_jaccard_distance_from_gram(skm_ctx *ctx, int64_t n, int64_t m, const float *d_xcount,
+                                              const float *d_ycount, float *d_out, int64_t ld)
+{
+    SKM_REQUIRE(ctx && n >= 0 && m >= 0 && ld >= m, SKM_E_BADARG, "skm_jaccard_distance_from_gram: bad argument");
+    if (n == 0 || m == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_xcount && d_ycount && d_out, SKM_E_BADARG, "skm_jaccard_distance_from_gram: null array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    dim3 grid((unsigned)skm_ceil_div(m, BLK), (unsigned)(n < 1024 ? n : 1024));
+    SKM_PROF(ctx, "k_setsim_from_gram");
+    k_setsim_from_gram<1><<<grid, BLK, 0, ctx->stream>>>(n, m, 0.0f, d_xcount, d_ycount, d_out, ld);
+    return skm_check_launch("k_setsim_from_gram");
 }
 
 extern "C" int skm_gather_columns(skm_ctx *ctx, int64_t rows, int64_t ncols_out, int elem_bytes, const void *d_in,

@@ -152,11 +152,22 @@ def connection_matrix_from_features(feature_matrix, metric="jaccard"):
     )
 
 
+def jaccard_distance(feature_matrix, ctx=None) -> np.ndarray:
+    """Square Jaccard distance matrix of a binary feature matrix, what
+    ``squareform(pdist(X, "jaccard"))`` gives in snekmer/scripts/cluster_cluster.py:189-190 (the
+    branch used when the optional BSF package is absent)."""
+    return _set_measure(feature_matrix, "jaccard", ctx)
+
+
 def hamming_similarity(feature_matrix, ctx=None) -> np.ndarray:
     """What the reference's metric="jaccard" branch really computes (snekmer/score.py:166-168):
     ``1 - pairwise_distances(X, metric="hamming")`` = fraction of columns on which two rows agree.
     Implemented for the binary presence matrices that branch is used with (``vecs``); the exact
     intersection sizes come from the sparse Gram kernels with unit norms."""
+    return _set_measure(feature_matrix, "hamming", ctx)
+
+
+def _set_measure(feature_matrix, kind: str, ctx=None) -> np.ndarray:
     import ctypes as C
 
     from . import _hip
@@ -166,7 +177,7 @@ def hamming_similarity(feature_matrix, ctx=None) -> np.ndarray:
     if A.ndim != 2:
         raise ValueError("expected a 2-D feature matrix")
     if A.dtype != bool and np.any((A != 0) & (A != 1)):
-        raise NotImplementedError("metric='jaccard' is implemented for binary (0/1 or bool) matrices only")
+        raise NotImplementedError(f"the {kind} measure is implemented for binary (0/1 or bool) matrices only")
     Ab = (A != 0).astype(np.uint8)
     n, ncols = Ab.shape
     if ncols == 0:
@@ -175,8 +186,12 @@ def hamming_similarity(feature_matrix, ctx=None) -> np.ndarray:
     ones = ctx.to_device(np.ones(n + 4, dtype=np.float32))
     colptr, post = engine.transpose(ctx, n, x.nnz, ncols, x.rowptr, x.colidx, x.counts)
     ld = (n + 3) // 4 * 4
-    out = engine.cosine_matrix(ctx, x, ones, n, ncols, colptr, post, ones, mode=0, ld=ld)
+    out = engine.cosine_matrix(ctx, x, ones, n, ncols, colptr, post, ones, mode=0, ld=ld)  # exact |a & b|
     sizes = ctx.to_device(np.concatenate([Ab.sum(axis=1), np.zeros(4)]).astype(np.float32))
-    ctx.call("skm_hamming_similarity_from_gram", C.c_int64(n), C.c_int64(n), C.c_int64(ncols), C.c_void_p(sizes.ptr),
-             C.c_void_p(sizes.ptr), C.c_void_p(out.ptr), C.c_int64(ld))
+    if kind == "hamming":
+        ctx.call("skm_hamming_similarity_from_gram", C.c_int64(n), C.c_int64(n), C.c_int64(ncols), C.c_void_p(sizes.ptr),
+                 C.c_void_p(sizes.ptr), C.c_void_p(out.ptr), C.c_int64(ld))
+    else:
+        ctx.call("skm_jaccard_distance_from_gram", C.c_int64(n), C.c_int64(n), C.c_void_p(sizes.ptr), C.c_void_p(sizes.ptr),
+                 C.c_void_p(out.ptr), C.c_int64(ld))
     return out.download().reshape(max(n, 1), max(ld, 1))[:n, :n]

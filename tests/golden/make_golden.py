@@ -364,6 +364,15 @@ def main(ref_root):
         sample_counts=counts[sample[:4]],
     )
 
+    # ---- G11: Jaccard distance as scripts/cluster_cluster.py:189-190 computes it without BSF
+    from scipy.spatial.distance import pdist, squareform
+
+    demo = run_rule(V, A, records, "hydro", 14)
+    np.savez_compressed(
+        os.path.join(HERE, "g11_jaccard_demo_hydro_k14.npz"),
+        jaccard_distance=squareform(pdist(demo["vecs"], "jaccard")),
+    )
+
     # ---- G9: score.connection_matrix_from_features / utils.to_feature_matrix ---------
     X = rng.integers(0, 4, size=(9, 23)).astype(float)
     X[3] = 0

@@ -716,3 +716,16 @@ def test_gram_neighbors_and_topk_vs_oracle(ctx):
         assert len(got) == min(kk, len(cand))
         assert np.abs(val[r][: len(got)] - row[got]).max() <= COS_TOL
         assert np.abs(np.sort(row[got])[::-1] - row[order][: len(got)]).max() <= COS_TOL
+
+
+def test_jaccard_distance_matches_scipy_golden(ctx):
+    """cluster's distance matrix (scripts/cluster_cluster.py:189-190, non-BSF branch)."""
+    import snekmer_amd as skm
+
+    g3 = gnpz("g3_demo_hydro_k14_mf0.npz")
+    vecs = np.unpackbits(g3["vecs_bits"], axis=1)[:, : g3["vecs_shape"][1]]
+    D = skm.score.jaccard_distance(vecs)
+    ref = gnpz("g11_jaccard_demo_hydro_k14.npz")["jaccard_distance"]
+    assert D.shape == ref.shape and np.abs(D - ref).max() <= 1e-6 and (np.diag(D) == 0).all()
+    E = skm.score.jaccard_distance(np.zeros((3, 5)))
+    assert (E == 0).all()

@@ -178,3 +178,14 @@ def test_g10_real_proteome_oracle():
     assert (np.diff(rowptr) == g["row_presence_sums"]).all()
     S = c_oracle.cosine_rows(rowptr, col, cnt, len(basis), g["sample_rows"])
     np.testing.assert_allclose(S, g["cosine_rows"], atol=1e-12)
+
+
+def test_g11_jaccard_distance_formula():
+    """The set formula the device epilogue uses equals scipy's pdist(X, 'jaccard') on the fixture."""
+    g3 = gnpz("g3_demo_hydro_k14_mf0.npz")
+    vecs = np.unpackbits(g3["vecs_bits"], axis=1)[:, : g3["vecs_shape"][1]].astype(np.int64)
+    inter = vecs @ vecs.T
+    sizes = vecs.sum(axis=1)
+    uni = sizes[:, None] + sizes[None, :] - inter
+    D = np.where(uni > 0, (uni - inter) / np.maximum(uni, 1), 0.0)
+    np.testing.assert_allclose(D, gnpz("g11_jaccard_demo_hydro_k14.npz")["jaccard_distance"], atol=1e-12)
