@@ -46,7 +46,6 @@ extern "C" int skm_create(int device_id, skm_ctx **out_ctx)
     SKM_HIP(hipGetDeviceProperties(&prop, device_id));
     ctx->num_cus = prop.multiProcessorCount;
     SKM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    SKM_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     SKM_HIP(hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocDefault));
     *out_ctx = ctx;
     return SKM_OK;
@@ -70,12 +69,6 @@ extern "C" int skm_destroy(skm_ctx *ctx)
             hipFree(ctx->ws[i]);
     if (ctx->h_pinned)
         hipHostFree(ctx->h_pinned);
-    for (auto e : ctx->sync_events)
-        hipEventDestroy(e);
-    if (ctx->aux_stream) {
-        hipStreamSynchronize(ctx->aux_stream);
-        hipStreamDestroy(ctx->aux_stream);
-    }
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return SKM_OK;
@@ -84,7 +77,6 @@ extern "C" int skm_destroy(skm_ctx *ctx)
 extern "C" int skm_sync(skm_ctx *ctx)
 {
     SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
-    SKM_HIP(hipStreamSynchronize(ctx->aux_stream));
     SKM_HIP(hipStreamSynchronize(ctx->stream));
     return SKM_OK;
 }

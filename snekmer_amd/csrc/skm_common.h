@@ -51,8 +51,6 @@ struct skm_prof_entry {
 struct skm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t aux_stream = nullptr;  // producer side of the gram/writer overlap (skm_cosine_csr)
-    std::vector<hipEvent_t> sync_events;
     int num_cus = 0;
     void *ws[WS_COUNT] = {};
     size_t ws_bytes[WS_COUNT] = {};

@@ -27,10 +27,9 @@
 //                      (sorted) posting list and adds v*v' for the postings that fall into the
 //                      chunk.  One dependent memory round trip per posting: slow, but general.
 //
-// Environment knobs (diagnostics / tuning only): SKM_COSINE_PATH=cursor forces the fallback
-// everywhere; SKM_GRAM_VARIANT / SKM_WRITE_VARIANT select other (equally exact) kernel shapes;
-// SKM_COSINE_OVERLAP=1 runs Gram and writer on two streams; SKM_COSINE_ABLATE / SKM_GRAM_ABLATE
-// build timing-only variants whose RESULTS ARE INVALID (tools/ablate_cosine.py).
+// Environment knobs (diagnostics only): SKM_COSINE_PATH=cursor forces the fallback everywhere;
+// SKM_COSINE_ABLATE / SKM_GRAM_ABLATE select timing-only builds whose RESULTS ARE INVALID
+// (tools/ablate_cosine.py).  Shapes that were measured and rejected are listed in DESIGN.md.
 //
 // The dense small-basis case (a true dense GEMM) is served by the i8 MFMA kernels in
 // skm_dense.hip instead.
@@ -661,56 +660,57 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     const bool vec = (ld % 4 == 0) && (((uintptr_t)d_out & 15) == 0) && (((uintptr_t)d_yrnorm & 15) == 0);
     hipStream_t st = ctx->stream;
 
-#define SKM_LAUNCH_A(MODE, VEC, ABL, GRID, LIST, COUNT)                                                             \
-    k_cosine_strip<MODE, VEC, ABL><<<(unsigned)(GRID), TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m,   \
-                                                                     d_ycolptr, d_ypost, d_yrnorm, row0,            \
-                                                                     row1, d_out, ld, LIST, COUNT)
+// expands CALL(MODE, VEC) for the runtime (mode, vec) pair
+#define SKM_BY_MODE_VEC(CALL)  \
+    do {                       \
+        if (mode == 0) {       \
+            if (vec)           \
+                CALL(0, true); \
+            else               \
+                CALL(0, false); \
+        } else {               \
+            if (vec)           \
+                CALL(1, true); \
+            else               \
+                CALL(1, false); \
+        }                      \
+    } while (0)
+#define SKM_CURSOR(MODE, VEC)                                                                                        \
+    k_cosine_strip<MODE, VEC, 0><<<(unsigned)strips, TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, \
+                                                                   d_ypost, d_yrnorm, row0, row1, d_out, ld, fb_list, fb_count)
+
     // Diagnostic builds of the cursor kernel (tools/ablate_cosine.py): results are NOT valid.
     const char *abl_env = getenv("SKM_COSINE_ABLATE");
     const int abl = abl_env ? atoi(abl_env) : 0;
+    uint32_t *fb_list = nullptr, *fb_count = nullptr;
     if (abl >= 1 && abl <= 3 && mode == 0 && vec) {
         SKM_PROF(ctx, "k_cosine_strip");
+#define SKM_CURSOR_ABL(ABL)                                                                                          \
+    k_cosine_strip<0, true, ABL><<<(unsigned)strips, TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, \
+                                                                   d_ypost, d_yrnorm, row0, row1, d_out, ld, nullptr, nullptr)
         if (abl == 1)
-            SKM_LAUNCH_A(0, true, 1, strips, nullptr, nullptr);
+            SKM_CURSOR_ABL(1);
         else if (abl == 2)
-            SKM_LAUNCH_A(0, true, 2, strips, nullptr, nullptr);
+            SKM_CURSOR_ABL(2);
         else
-            SKM_LAUNCH_A(0, true, 3, strips, nullptr, nullptr);
+            SKM_CURSOR_ABL(3);
+#undef SKM_CURSOR_ABL
         return skm_check_launch("k_cosine_strip");
     }
     const char *path_env = getenv("SKM_COSINE_PATH");  // "cursor" forces the fallback kernel everywhere
-    const bool cursor_only = (path_env && strcmp(path_env, "cursor") == 0) || skm_ceil_div(m, CH) > GNB;
-    if (cursor_only) {
+    if ((path_env && strcmp(path_env, "cursor") == 0) || skm_ceil_div(m, CH) > GNB) {
         SKM_PROF(ctx, "k_cosine_strip");
-        if (mode == 0) {
-            if (vec)
-                SKM_LAUNCH_A(0, true, 0, strips, nullptr, nullptr);
-            else
-                SKM_LAUNCH_A(0, false, 0, strips, nullptr, nullptr);
-        } else {
-            if (vec)
-                SKM_LAUNCH_A(1, true, 0, strips, nullptr, nullptr);
-            else
-                SKM_LAUNCH_A(1, false, 0, strips, nullptr, nullptr);
-        }
+        SKM_BY_MODE_VEC(SKM_CURSOR);
         return skm_check_launch("k_cosine_strip");
     }
 
-    // ---- fast path: sparse Gram -> streaming writer -> cursor kernel for flagged strips.
-    // Optional (SKM_COSINE_OVERLAP=1): cut the rows into blocks and produce block b's neighbour
-    // lists on the auxiliary stream while block b-1 is written on the main stream.  Measured on
-    // MI355X this LOSES (14.1 vs 13.1 ms/step at config 3): the Gram workgroups fill the CUs' LDS
-    // and wave slots and starve the writer, so the default is one block on one stream.
+    // ---- fast path: sparse Gram (+ large-table pass) -> streaming writer -> cursor kernel for what is left
     int64_t *h_rp = (int64_t *)ctx->h_pinned;
     SKM_HIP(hipMemcpyAsync(h_rp, d_xrowptr + row0, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     SKM_HIP(hipMemcpyAsync(h_rp + 1, d_xrowptr + row1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     SKM_HIP(hipStreamSynchronize(st));
     const int64_t xnnz = h_rp[1] - h_rp[0];
     const unsigned long long cap_ent = (unsigned long long)(8 * xnnz + (1 << 20));
-    const char *ov_env = getenv("SKM_COSINE_OVERLAP");
-    const bool overlap = ov_env && atoi(ov_env) == 1 && nrows >= 4096;
-    constexpr int MAXB = 16;
-    const int nblk = overlap ? 8 : 1;
     void *p;
     SKM_TRY(skm_ws(ctx, WS_A, sizeof(uint64_t) * (size_t)cap_ent, &p));
     uint64_t *g_ent = (uint64_t *)p;
@@ -718,148 +718,70 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     uint64_t *g_start = (uint64_t *)p;
     SKM_TRY(skm_ws(ctx, WS_C, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
     uint32_t *g_len = (uint32_t *)p;
-    // one entry per writer workgroup at most (the writer may run one row per workgroup)
-    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)(nrows + 8 * MAXB + 8), &p));
-    uint32_t *fb_list = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)(strips + 8), &p));  // each strip is listed at most once
+    fb_list = (uint32_t *)p;
     SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
     uint32_t *over_list = (uint32_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_F, sizeof(uint32_t) * (size_t)(strips + MAXB + 8), &p));
+    SKM_TRY(skm_ws(ctx, WS_F, sizeof(uint32_t) * (size_t)(strips + 8), &p));
     uint32_t *fb_flag = (uint32_t *)p;
-    SKM_HIP(hipMemsetAsync(fb_flag, 0, sizeof(uint32_t) * (size_t)(strips + MAXB + 8), st));
+    SKM_HIP(hipMemsetAsync(fb_flag, 0, sizeof(uint32_t) * (size_t)(strips + 8), st));
     SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
     unsigned long long *g_counter = (unsigned long long *)((uint8_t *)p + 2048);
-    uint32_t *fb_counts = (uint32_t *)((uint8_t *)p + 2048 + 8);            // [MAXB]
-    uint32_t *over_counts = (uint32_t *)((uint8_t *)p + 2048 + 8 + 4 * MAXB);  // [MAXB]
-    SKM_HIP(hipMemsetAsync(g_counter, 0, 8 + 8 * MAXB, st));
-    hipStream_t sg = overlap ? ctx->aux_stream : st;
-    while ((int)ctx->sync_events.size() < MAXB + 1) {
-        hipEvent_t ev;
-        SKM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        ctx->sync_events.push_back(ev);
-    }
-    if (overlap) {  // the producer stream starts after everything already queued on the main stream
-        SKM_HIP(hipEventRecord(ctx->sync_events[MAXB], st));
-        SKM_HIP(hipStreamWaitEvent(sg, ctx->sync_events[MAXB], 0));
-    }
-    const char *gabl_env = getenv("SKM_GRAM_ABLATE");  // diagnostic only: results NOT valid
-    const int gabl = gabl_env ? atoi(gabl_env) : 0;
-    const char *gvar_env = getenv("SKM_GRAM_VARIANT");  // tuning aids; every variant is exact
-    const int gvar = gvar_env ? atoi(gvar_env) : 0;
-    const char *wv_env = getenv("SKM_WRITE_VARIANT");
-    const int wv = wv_env ? atoi(wv_env) : 0;
+    fb_count = (uint32_t *)((uint8_t *)p + 2048 + 8);
+    uint32_t *over_count = fb_count + 1;
+    SKM_HIP(hipMemsetAsync(g_counter, 0, 16, st));
     const int nchunk = (int)skm_ceil_div(m, CH);
-    // block boundaries on multiples of 16 rows (writer strips are 4, 8 or 16 rows; cursor strips 8)
-    const int64_t per = (skm_ceil_div(nrows, nblk) + 15) / 16 * 16;
-    for (int b = 0; b < nblk; ++b) {
-        const int64_t r0 = row0 + (int64_t)b * per, r1 = min(row1, r0 + per);
-        if (r0 >= r1)
-            break;
-        const int64_t rows_b = r1 - r0, rel = r0 - row0;
-        uint64_t *gs = g_start + rel;
-        uint32_t *gl = g_len + rel;
-        uint32_t *ol = over_list + rel, *oc = over_counts + b;
-        uint32_t *fl = fb_list + rel + 8 * b, *fc = fb_counts + b, *ff = fb_flag + rel / R + b;
-        float *outb = d_out + rel * ld;
-        {
-            SKM_PROF_ON(ctx, "k_gram_sparse", sg);
-#define SKM_LAUNCH_G(GABL, GR, GH, GT, GQ, SL)                                                                        \
-    k_gram_sparse<GABL, GR, GH, GT, GQ, SL><<<(unsigned)skm_ceil_div(rows_b, GR), GT, 0, sg>>>(                         \
-        d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, r0, r1, nchunk, g_ent, cap_ent, g_counter, gs, gl, ol, oc)
-            if (gabl == 1)
-                SKM_LAUNCH_G(1, 1, 2048, 256, 2, 4);
-            else if (gabl == 2)
-                SKM_LAUNCH_G(2, 1, 2048, 256, 2, 4);
-            else if (gabl == 4)
-                SKM_LAUNCH_G(4, 1, 2048, 256, 2, 4);
-            else if (gabl == 5)
-                SKM_LAUNCH_G(5, 1, 2048, 256, 2, 4);
-            else if (gabl == 3) {  // phase stamps (exact results, slower): read with skm_debug_gram_phases
-                unsigned long long zeros[8] = {};
-                SKM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gram_phase_ticks), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice, sg));
-                SKM_LAUNCH_G(3, 1, 2048, 256, 2, 4);
-            }
-            else if (gvar == 1)
-                SKM_LAUNCH_G(0, 1, 4096, 256, 2, 4);
-            else if (gvar == 2)
-                SKM_LAUNCH_G(0, 2, 2048, 512, 2, 4);
-            else if (gvar == 7)
-                SKM_LAUNCH_G(0, 2, 4096, 512, 2, 4);
-            else  // default: one row per workgroup, 2048 slots (22 KB of LDS -> 7 workgroups per CU)
-                SKM_LAUNCH_G(0, 1, 2048, 256, 2, 4);
-#undef SKM_LAUNCH_G
-        }
-        SKM_TRY(skm_check_launch("k_gram_sparse"));
-        {
-            // rows the small tables cannot hold: 8192-slot table and up to 4096 non-zeros, one row per workgroup
-            SKM_PROF_ON(ctx, "k_gram_sparse_big", sg);
-            k_gram_sparse_big<8192, 512, 8, 4><<<skm_grid_cap(ctx, rows_b, 1), 512, 0, sg>>>(
-                d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, r0, r1, nchunk, g_ent, cap_ent, g_counter, gs, gl, ol, oc,
-                nullptr, nullptr);
-        }
-        SKM_TRY(skm_check_launch("k_gram_sparse_big"));
-        if (overlap) {
-            SKM_HIP(hipEventRecord(ctx->sync_events[b], sg));
-            SKM_HIP(hipStreamWaitEvent(st, ctx->sync_events[b], 0));
-        }
-        {
-            SKM_PROF(ctx, "k_cosine_write");
-#define SKM_LAUNCH_WV(MODE, VEC, WR, WCH)                                                                               \
-    k_cosine_write<MODE, VEC, WR, WCH><<<(unsigned)skm_ceil_div(rows_b, WR), WCH / 4, 0, st>>>(                           \
-        g_ent, gs, gl, d_xrnorm, d_yrnorm, m, r0, r1, outb, ld, fl, fc, ff)
-#define SKM_LAUNCH_W(MODE, VEC)                                                                                         \
-    do {                                                                                                                \
-        if (wv == 1)                                                                                                    \
-            SKM_LAUNCH_WV(MODE, VEC, 8, 1024);                                                                          \
-        else if (wv == 2)                                                                                               \
-            SKM_LAUNCH_WV(MODE, VEC, 16, 1024);                                                                         \
-        else if (wv == 4)                                                                                               \
-            SKM_LAUNCH_WV(MODE, VEC, 2, 2048);                                                                          \
-        else if (wv == 5)                                                                                               \
-            SKM_LAUNCH_WV(MODE, VEC, 2, 4096);                                                                          \
-        else if (wv == 6)                                                                                               \
-            SKM_LAUNCH_WV(MODE, VEC, 1, 2048);                                                                          \
-        else if (wv == 7)                                                                                               \
-            SKM_LAUNCH_WV(MODE, VEC, 4, 1024);                                                                          \
-        else /* default: one row per workgroup, 16 KiB per row and step (measured best) */                              \
-            SKM_LAUNCH_WV(MODE, VEC, 1, 4096);                                                                          \
-    } while (0)
-            if (mode == 0) {
-                if (vec)
-                    SKM_LAUNCH_W(0, true);
-                else
-                    SKM_LAUNCH_W(0, false);
-            } else {
-                if (vec)
-                    SKM_LAUNCH_W(1, true);
-                else
-                    SKM_LAUNCH_W(1, false);
-            }
-#undef SKM_LAUNCH_W
-#undef SKM_LAUNCH_WV
-        }
-        SKM_TRY(skm_check_launch("k_cosine_write"));
-        {
-            // strips flagged by the kernels above; worst-case grid, surplus workgroups exit at once
-            SKM_PROF(ctx, "k_cosine_strip");
-            const int64_t strips_b = skm_ceil_div(rows_b, R);
-#define SKM_LAUNCH_C(MODE, VEC)                                                                                       \
-    k_cosine_strip<MODE, VEC, 0><<<(unsigned)strips_b, TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m,      \
-                                                                     d_ycolptr, d_ypost, d_yrnorm, r0, r1, outb, ld, fl, fc)
-            if (mode == 0) {
-                if (vec)
-                    SKM_LAUNCH_C(0, true);
-                else
-                    SKM_LAUNCH_C(0, false);
-            } else {
-                if (vec)
-                    SKM_LAUNCH_C(1, true);
-                else
-                    SKM_LAUNCH_C(1, false);
-            }
-#undef SKM_LAUNCH_C
-        }
+    const char *gabl_env = getenv("SKM_GRAM_ABLATE");  // diagnostic builds of k_gram_sparse (1, 2, 4, 5: results NOT valid)
+    const int gabl = gabl_env ? atoi(gabl_env) : 0;
+    {
+        // one row per workgroup, 2048 slots: 22 KB of LDS -> 7 workgroups per CU (measured best shape)
+        SKM_PROF(ctx, "k_gram_sparse");
+#define SKM_GRAM(GABL)                                                                                               \
+    k_gram_sparse<GABL, 1, 2048, 256, 2, 4><<<(unsigned)nrows, 256, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr,  \
+                                                                             d_ypost, row0, row1, nchunk, g_ent, cap_ent, \
+                                                                             g_counter, g_start, g_len, over_list, over_count)
+        if (gabl == 1)
+            SKM_GRAM(1);
+        else if (gabl == 2)
+            SKM_GRAM(2);
+        else if (gabl == 4)
+            SKM_GRAM(4);
+        else if (gabl == 5)
+            SKM_GRAM(5);
+        else if (gabl == 3) {  // phase stamps (exact results, slower): read with skm_debug_gram_phases
+            unsigned long long zeros[8] = {};
+            SKM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gram_phase_ticks), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice, st));
+            SKM_GRAM(3);
+        } else
+            SKM_GRAM(0);
+#undef SKM_GRAM
     }
-#undef SKM_LAUNCH_A
+    SKM_TRY(skm_check_launch("k_gram_sparse"));
+    {
+        // rows the small tables cannot hold: 8192 slots and up to 4096 non-zeros, one row per workgroup
+        SKM_PROF(ctx, "k_gram_sparse_big");
+        k_gram_sparse_big<8192, 512, 8, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
+            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, nchunk, g_ent, cap_ent, g_counter, g_start, g_len,
+            over_list, over_count, nullptr, nullptr);
+    }
+    SKM_TRY(skm_check_launch("k_gram_sparse_big"));
+    {
+        // one row per workgroup, 16 KiB per row and step (measured best shape)
+        SKM_PROF(ctx, "k_cosine_write");
+#define SKM_WRITE(MODE, VEC)                                                                                         \
+    k_cosine_write<MODE, VEC, 1, 4096><<<(unsigned)nrows, 1024, 0, st>>>(g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, \
+                                                                          row1, d_out, ld, fb_list, fb_count, fb_flag)
+        SKM_BY_MODE_VEC(SKM_WRITE);
+#undef SKM_WRITE
+    }
+    SKM_TRY(skm_check_launch("k_cosine_write"));
+    {
+        // strips with a row still flagged; worst-case grid, surplus workgroups exit at once
+        SKM_PROF(ctx, "k_cosine_strip");
+        SKM_BY_MODE_VEC(SKM_CURSOR);
+    }
+#undef SKM_CURSOR
+#undef SKM_BY_MODE_VEC
     return skm_check_launch("k_cosine_strip");
 }
 
