@@ -229,6 +229,23 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
+        if world == 1 and not sharded and args.alphabet == "red6":
+            # red6 is a benchmark alphabet; the nearest reference alphabet (`standard`,
+            # 7^12 needs uint64 codes) is timed next to it on the same sequences, outside the timed region
+            lut7 = alphabet.build_lut("standard")
+            pipe7 = engine.Pipeline(ctx, lut7, args.k)
+            pipe7.out = pipe.out  # share the 40 GB result buffer
+            pipe7.step(batch)
+            ctx.sync()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                pipe7.step(batch)
+            ctx.sync()
+            dt7 = (time.perf_counter() - t1) / 3
+            line["reference_alphabet_check"] = {
+                "alphabet": "standard", "k": args.k, "code_bits": 64, "ms_per_step": dt7 * 1e3,
+                "sequences_per_s": n_total / dt7, "nnz": pipe7.csr.nnz, "basis_columns": pipe7.basis.ncols,
+            }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.alphabet, args.k, seed, args.cpu_sample)
         print(json.dumps(line), flush=True)
