@@ -729,3 +729,54 @@ def test_jaccard_distance_matches_scipy_golden(ctx):
     assert D.shape == ref.shape and np.abs(D - ref).max() <= 1e-6 and (np.diag(D) == 0).all()
     E = skm.score.jaccard_distance(np.zeros((3, 5)))
     assert (E == 0).all()
+
+
+# ------------------------------------------------------------------ seeded fuzz
+def test_fuzz_small_batches_all_alphabets(ctx):
+    """Many small random batches: ragged lengths (0..700), invalid characters, trailing '*', low
+    complexity, every alphabet and assorted k; CSR, basis, first-seen order and cosine against the
+    oracle each time."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.utils import pack_sequences
+
+    orc = _oracle()
+    rng = np.random.default_rng(2026)
+    pool = np.frombuffer(b"ARNDCQEGHILKMFPSTWYVXBZ*-acgt ", dtype=np.uint8)
+    weights = np.r_[np.full(20, 1.0), np.full(10, 0.02)]
+    weights /= weights.sum()
+    names = ["hydro", "standard", "solvacc", "hydrocharge", "hydrostruct", "miqs", "ptm", None, "red6"]
+    for trial in range(40):
+        name = names[trial % len(names)]
+        lut = A.build_lut(name)
+        kmax = min(24, int(np.floor(63 / np.log2(lut.nsym))))
+        k = int(rng.integers(1, kmax + 1))
+        n = int(rng.integers(1, 40))
+        seqs = []
+        for _ in range(n):
+            L = int(rng.choice([0, 1, k - 1 if k > 1 else 0, k, k + 1, int(rng.integers(0, 700))]))
+            if rng.random() < 0.2:  # low complexity
+                body = np.repeat(pool[rng.integers(0, 20, size=max(1, L // 7 + 1))], 7)[:L]
+            else:
+                body = pool[rng.choice(len(pool), size=L, p=weights)]
+            s = body.tobytes().decode("latin-1") + "*" * int(rng.integers(0, 3) if rng.random() < 0.3 else 0)
+            seqs.append(s)
+        res, off = pack_sequences(seqs)
+        batch = engine.SeqBatch(ctx, res, off)
+        csr = engine.count_csr(ctx, batch, lut, k, with_firstpos=True)
+        rowptr, codes, counts, first = csr.host()
+        o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+        assert (rowptr == o_rowptr).all() and (codes.astype(np.uint64) == o_codes).all(), (trial, name, k)
+        assert (counts == o_counts).all() and (first == o_first).all(), (trial, name, k)
+        if csr.nnz == 0:
+            continue
+        b = engine.build_basis(ctx, csr, lut.nsym, k, stats=True, first_seen=True, postings=True)
+        ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
+        assert b.ncols == len(ob) and (b.codes.download(b.ncols).astype(np.uint64) == ob).all()
+        assert (b.fs_order.download(b.ncols) == np.argsort(ofk, kind="stable")).all()
+        assert (csr.colidx.download(csr.nnz) == ocol).all()
+        rn = engine.row_norms(ctx, n, csr.rowptr, csr.counts)
+        out = engine.cosine_matrix(ctx, csr, rn, n, b.ncols, b.colptr, b.post, rn, ld=(n + 3) // 4 * 4)
+        S = out.download().reshape(out.shape)[:n, :n]
+        ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), np.arange(n))
+        assert np.abs(S - ref).max() <= COS_TOL, (trial, name, k)
