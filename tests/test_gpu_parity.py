@@ -780,3 +780,39 @@ def test_fuzz_small_batches_all_alphabets(ctx):
         S = out.download().reshape(out.shape)[:n, :n]
         ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), np.arange(n))
         assert np.abs(S - ref).max() <= COS_TOL, (trial, name, k)
+
+
+# ------------------------------------------------------------------ C-ABI error conventions
+def test_c_abi_error_codes_and_messages(ctx):
+    import ctypes as C
+
+    from snekmer_amd import _hip
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+
+    lib = ctx.lib
+    lut = A.build_lut("hydro")
+    batch = engine.SeqBatch.from_strings(ctx, ["MKVLAAGIW"])
+    rowptr = ctx.empty(2, np.int64)
+    codes = ctx.empty(16, np.uint32)
+    counts = ctx.empty(16, np.uint32)
+    nnz = C.c_int64(0)
+    p = lambda a: C.c_void_p(a.ptr)  # noqa: E731
+    rank = lut.rank.ctypes.data_as(C.c_void_p)
+
+    def count(nsym, k, bits, cap):
+        return lib.skm_count_csr(ctx.handle, rank, nsym, k, bits, p(batch.d_seq), p(batch.d_off), C.c_int64(1),
+                                 C.c_int64(batch.total), C.c_int64(cap), p(rowptr), p(codes), p(counts), None, C.byref(nnz))
+
+    assert count(2, 4, 32, 16) == 0 and nnz.value > 0
+    assert count(2, 4, 16, 16) == -1 and b"code width" in lib.skm_last_error()          # SKM_E_BADARG
+    assert count(2, 40, 32, 16) == -5 and b"does not fit" in lib.skm_last_error()       # SKM_E_UNSUPPORTED
+    assert count(2, 4, 32, 3) == -1 and b"cap_entries" in lib.skm_last_error()          # capacity too small
+    assert lib.skm_cosine_dense_i8(ctx.handle, C.c_int64(4), C.c_int64(4), C.c_int64(100), None, None, None, None, 0, None,
+                                   C.c_int64(4)) == -1
+    with pytest.raises(_hip.HipError) as e:
+        ctx.call("skm_cosine_csr", C.c_int64(4), None, None, None, None, C.c_int64(4), C.c_int64(1), None, None, None,
+                 C.c_int64(3), C.c_int64(2), 0, None, C.c_int64(4))
+    assert e.value.code == -1 and "row range" in str(e.value)
+    out = C.c_void_p()
+    assert lib.skm_create(99, C.byref(out)) == -1 and b"out of range" in lib.skm_last_error()
