@@ -61,18 +61,14 @@ def cpu_baseline(alphabet_name, k, seed, n_sample):
     }
 
 
-class stdout_to_stderr:
-    """gloo and RCCL print connection banners on stdout; stdout is reserved for the one JSON line."""
-
-    def __enter__(self):
-        sys.stdout.flush()
-        self.saved = os.dup(1)
-        os.dup2(2, 1)
-
-    def __exit__(self, *exc):
-        sys.stdout.flush()
-        os.dup2(self.saved, 1)
-        os.close(self.saved)
+def reserve_stdout() -> int:
+    """gloo and RCCL print banners on stdout (RCCL through C stdio, flushed as late as process
+    exit); stdout is reserved for the one JSON line.  Point fd 1 at stderr for the whole run and
+    return a private descriptor of the real stdout for that line."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return real
 
 
 def load_pmc_traffic():
@@ -98,6 +94,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    real_stdout = reserve_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -123,8 +120,7 @@ def main():
         import torch
         import torch.distributed as dist
 
-        with stdout_to_stderr():
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     ctx = _hip.Context(local_rank)
     lut = alphabet.build_lut(args.alphabet)
@@ -141,11 +137,10 @@ def main():
     else:
         from snekmer_amd.dist import RcclExchange, ShardedPipeline, shard_bounds
 
-        with stdout_to_stderr():
-            uid = [RcclExchange.new_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            ex = RcclExchange(ctx, world, rank, uid[0])
-            ex.allgather_i64([rank])  # first collective: connection set-up (and any lazy banner) happens here
+        uid = [RcclExchange.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ex = RcclExchange(ctx, world, rank, uid[0])
+        ex.allgather_i64([rank])  # first collective: connection set-up happens here, outside the timed region
         bounds = shard_bounds(n_total, world)
         lo, hi = bounds[rank]
         shard = engine.SeqBatch(ctx, res[off[lo] : off[hi]], off[lo : hi + 1] - off[lo])
@@ -248,12 +243,11 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.alphabet, args.k, seed, args.cpu_sample)
-        print(json.dumps(line), flush=True)
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
     if dist is not None:
-        with stdout_to_stderr():
-            dist.barrier()
-            dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -42,7 +42,7 @@ int load_rccl()
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *lib = nullptr;
     for (const char *nm : names) {
-        lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);  // LOCAL: the host process may carry its own RCCL (PyTorch does)
         if (lib)
             break;
     }

@@ -237,8 +237,11 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
 #include "skm_gram_kernel.h"
 
 // ------------------------------------------------------------------------------- streaming writer
-// WR rows per workgroup, WCH columns per chunk, WCH/4 threads (4 columns per thread and chunk).
-template <int MODE, bool VEC, int WR, int WCH>
+// One output row per workgroup, WCH columns per step, WCH/4 threads (4 columns per thread and step).
+// The row's neighbour list (any order) is held in registers, WREG entries per thread; per step
+// a thread drops its entries that fall into the step's column range into the LDS tile.  Longer
+// lists re-read the tail from global memory (L2) on every step.
+template <int MODE, bool VEC, int WCH>
 __global__ __launch_bounds__(WCH / 4) void k_cosine_write(const uint64_t *__restrict__ g_ent,
                                                      const uint64_t *__restrict__ g_start,
                                                      const uint32_t *__restrict__ g_len,
@@ -248,83 +251,46 @@ __global__ __launch_bounds__(WCH / 4) void k_cosine_write(const uint64_t *__rest
                                                      uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_count,
                                                      uint32_t *__restrict__ fb_flag)
 {
-    constexpr int R = WR, CH = WCH, TB = WCH / 4, NW = TB / 64;
-    constexpr int RPW = (R + NW - 1) / NW;  // rows fed by each wave
-    __shared__ __attribute__((aligned(16))) int s_acc[R][CH];
-    __shared__ uint64_t s_start[R];
-    __shared__ uint32_t s_len[R];
-    __shared__ float s_rni[R];
-    __shared__ int s_skip;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int64_t i0 = row0 + (int64_t)blockIdx.x * R;
-    const int rows = (int)min((int64_t)R, row1 - i0);
-    if (tid == 0)
-        s_skip = 0;
-    __syncthreads();
-    if (tid < R) {
-        uint32_t len = 0;
-        uint64_t st = 0;
-        float rn = 0.0f;
-        if (tid < rows) {
-            len = g_len[i0 - row0 + tid];
-            st = g_start[i0 - row0 + tid];
-            rn = xrnorm[i0 + tid];
-            if (len == G_OVERFLOW)
-                s_skip = 1;
-        }
-        s_len[tid] = len;
-        s_start[tid] = st;
-        s_rni[tid] = rn;
-    }
-    for (int z = tid; z < R * CH / 4; z += TB)
-        reinterpret_cast<int4 *>(&s_acc[0][0])[z] = make_int4(0, 0, 0, 0);
-    __syncthreads();
-    if (s_skip) {
-        // some row of this strip exceeded the sparse kernel's capacities: leave it to the cursor kernel
+    constexpr int CH = WCH, TB = WCH / 4, WREG = 2;
+    __shared__ __attribute__((aligned(16))) int s_acc[CH];
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;  // row of the block
+    const int64_t i = row0 + r;
+    const uint32_t len = g_len[r];
+    if (len == G_OVERFLOW) {
+        // the row exceeded the sparse kernels' capacities: leave its strip to the cursor kernel
         // (cursor strips are 8 rows; fb_flag makes sure a strip is listed once, since the cursor
         // kernel's grid is sized by the number of strips)
         constexpr int CURSOR_R = 8;
-        if (tid < (R + CURSOR_R - 1) / CURSOR_R) {
-            const uint32_t strip = (uint32_t)((i0 - row0) / CURSOR_R) + tid;
+        if (tid == 0) {
+            const uint32_t strip = (uint32_t)(r / CURSOR_R);
             if (atomicExch(&fb_flag[strip], 1u) == 0u)
                 fb_list[atomicAdd(fb_count, 1u)] = strip;
         }
         return;
     }
-
-    // each wave feeds two rows; it keeps a 64-entry window of the row's sorted neighbour list in
-    // registers and reloads only when the window is used up
-    int lrow[RPW];
-    uint32_t wbase[RPW];
-    uint64_t went[RPW];
+    const uint64_t *ent = g_ent + g_start[r];
+    uint64_t w[WREG];
 #pragma unroll
-    for (int u = 0; u < RPW; ++u) {
-        lrow[u] = wid + u * NW;
-        wbase[u] = 0;
-        went[u] = ~0ull;
-        if (lrow[u] < R && (uint32_t)lane < s_len[lrow[u]])
-            went[u] = g_ent[s_start[lrow[u]] + lane];
-    }
+    for (int u = 0; u < WREG; ++u)
+        w[u] = (uint32_t)(tid + u * TB) < len ? ent[tid + u * TB] : ~0ull;  // column 0xFFFFFFFF never matches
+    const float ri = xrnorm[i];
+    reinterpret_cast<int4 *>(s_acc)[tid] = make_int4(0, 0, 0, 0);
+    __syncthreads();
 
     for (int64_t j0 = 0; j0 < m; j0 += CH) {
-        const int64_t j1 = min(j0 + (int64_t)CH, m);
-        const uint32_t j1u = (uint32_t)j1, j0u = (uint32_t)j0;
+        const uint32_t j0u = (uint32_t)j0;
 #pragma unroll
-        for (int u = 0; u < RPW; ++u) {
-            const int li = lrow[u];
-            while (li < R) {
-                const uint32_t j = (uint32_t)(went[u] >> 32);
-                const bool take = went[u] != ~0ull && j >= j0u && j < j1u;
-                if (take)
-                    s_acc[li][j - j0u] = (int)(uint32_t)went[u];
-                // window exhausted within this chunk -> load the next 64 entries and continue
-                const bool last_taken = __shfl((int)take, 63) != 0;
-                if (!last_taken || wbase[u] + 64 >= s_len[li])
-                    break;
-                wbase[u] += 64;
-                const uint32_t e = wbase[u] + lane;
-                went[u] = e < s_len[li] ? g_ent[s_start[li] + e] : ~0ull;
-            }
+        for (int u = 0; u < WREG; ++u) {
+            const uint32_t dj = (uint32_t)(w[u] >> 32) - j0u;
+            if (dj < (uint32_t)CH)
+                s_acc[dj] = (int)(uint32_t)w[u];
+        }
+        for (uint32_t e = (uint32_t)tid + WREG * TB; e < len; e += TB) {
+            const uint64_t x = ent[e];
+            const uint32_t dj = (uint32_t)(x >> 32) - j0u;
+            if (dj < (uint32_t)CH)
+                s_acc[dj] = (int)(uint32_t)x;
         }
         __syncthreads();
         const int64_t jc = j0 + 4 * tid;
@@ -338,34 +304,26 @@ __global__ __launch_bounds__(WCH / 4) void k_cosine_write(const uint64_t *__rest
                 if (jc + u < m)
                     rj[u] = yrnorm[jc + u];
         }
+        const int4 a = reinterpret_cast<int4 *>(s_acc)[tid];
+        reinterpret_cast<int4 *>(s_acc)[tid] = make_int4(0, 0, 0, 0);
+        float o[4] = {(float)a.x * ri * rj[0], (float)a.y * ri * rj[1], (float)a.z * ri * rj[2], (float)a.w * ri * rj[3]};
+        if (MODE == 1) {
 #pragma unroll
-        for (int li = 0; li < R; ++li) {
-            int4 a = *reinterpret_cast<int4 *>(&s_acc[li][4 * tid]);
-            *reinterpret_cast<int4 *>(&s_acc[li][4 * tid]) = make_int4(0, 0, 0, 0);
-            if (li < rows) {
-                const float ri = s_rni[li];
-                float o[4] = {(float)a.x * ri * rj[0], (float)a.y * ri * rj[1], (float)a.z * ri * rj[2],
-                              (float)a.w * ri * rj[3]};
-                const int64_t i = i0 + li;
-                if (MODE == 1) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        float d = 1.0f - o[u];
-                        d = fminf(fmaxf(d, 0.0f), 2.0f);
-                        o[u] = (jc + u == i) ? 0.0f : d;
-                    }
-                }
-                float *dst = out + (i - row0) * ld + jc;
-                if (VEC && jc + 3 < m) {
-                    f32x4 pack = {o[0], o[1], o[2], o[3]};
-                    __builtin_nontemporal_store(pack, reinterpret_cast<f32x4 *>(dst));
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (jc + u < m)
-                            dst[u] = o[u];
-                }
+            for (int u = 0; u < 4; ++u) {
+                float d = 1.0f - o[u];
+                d = fminf(fmaxf(d, 0.0f), 2.0f);
+                o[u] = (jc + u == i) ? 0.0f : d;
             }
+        }
+        float *dst = out + r * ld + jc;
+        if (VEC && jc + 3 < m) {
+            f32x4 pack = {o[0], o[1], o[2], o[3]};
+            __builtin_nontemporal_store(pack, reinterpret_cast<f32x4 *>(dst));
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (jc + u < m)
+                    dst[u] = o[u];
         }
         __syncthreads();
     }
@@ -541,6 +499,11 @@ __global__ __launch_bounds__(1024) void k_gram_sparse_huge(const int64_t *__rest
     }
 }
 
+__global__ void k_set_u64(unsigned long long *dst, unsigned long long v)
+{
+    *dst = v;
+}
+
 __global__ void k_count_overflow(int64_t nrows, const uint32_t *__restrict__ g_len, unsigned int *out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -580,24 +543,23 @@ extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrow
     unsigned long long *g_counter = (unsigned long long *)((uint8_t *)p + 2048);
     uint32_t *cnt1 = (uint32_t *)((uint8_t *)p + 2048 + 8), *cnt2 = cnt1 + 1, *novf = cnt1 + 2;
     SKM_HIP(hipMemsetAsync(g_counter, 0, 8 + 16, st));
-    const int nchunk = (int)min((int64_t)GNB, skm_ceil_div(m, CH));
     const unsigned long long cap = (unsigned long long)cap_ent;
     {
         SKM_PROF(ctx, "k_gram_sparse");
         k_gram_sparse<0, 1, 2048, 256, 2, 4><<<(unsigned)nrows, 256, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr,
-                                                                              d_ypost, row0, row1, nchunk, d_ent, cap,
+                                                                              d_ypost, row0, row1, 0ull, d_ent, cap,
                                                                               g_counter, d_start, d_len, list1, cnt1);
     }
     SKM_TRY(skm_check_launch("k_gram_sparse"));
     {
         SKM_PROF(ctx, "k_gram_sparse_big");
         k_gram_sparse_big<8192, 512, 8, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
-            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, nchunk, d_ent, cap, g_counter, d_start, d_len,
+            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, d_ent, cap, g_counter, d_start, d_len,
             list1, cnt1, list2, cnt2);
         // largest table that fits LDS: 16384 slots (8192 neighbours), up to 1024 distinct k-mers
         SKM_HIP(hipMemsetAsync(cnt1, 0, 4, st));
         k_gram_sparse_big<16384, 512, 2, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
-            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, nchunk, d_ent, cap, g_counter, d_start, d_len,
+            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, d_ent, cap, g_counter, d_start, d_len,
             list2, cnt2, list1, cnt1);
     }
     SKM_TRY(skm_check_launch("k_gram_sparse_big"));
@@ -698,19 +660,18 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         return skm_check_launch("k_cosine_strip");
     }
     const char *path_env = getenv("SKM_COSINE_PATH");  // "cursor" forces the fallback kernel everywhere
-    if ((path_env && strcmp(path_env, "cursor") == 0) || skm_ceil_div(m, CH) > GNB) {
+    if (path_env && strcmp(path_env, "cursor") == 0) {
         SKM_PROF(ctx, "k_cosine_strip");
         SKM_BY_MODE_VEC(SKM_CURSOR);
         return skm_check_launch("k_cosine_strip");
     }
 
     // ---- fast path: sparse Gram (+ large-table pass) -> streaming writer -> cursor kernel for what is left
-    int64_t *h_rp = (int64_t *)ctx->h_pinned;
-    SKM_HIP(hipMemcpyAsync(h_rp, d_xrowptr + row0, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    SKM_HIP(hipMemcpyAsync(h_rp + 1, d_xrowptr + row1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    SKM_HIP(hipStreamSynchronize(st));
-    const int64_t xnnz = h_rp[1] - h_rp[0];
-    const unsigned long long cap_ent = (unsigned long long)(8 * xnnz + (1 << 20));
+    // neighbour lists: row r of the block owns SLOT entries at g_ent[r * SLOT] (all the first pass
+    // can produce); the lists of the large-table pass are allocated behind that region
+    constexpr unsigned long long SLOT = 1024;
+    const unsigned long long fixed_ent = (unsigned long long)nrows * SLOT;
+    const unsigned long long cap_ent = fixed_ent + (unsigned long long)max((int64_t)(1 << 20), nrows * 256);
     void *p;
     SKM_TRY(skm_ws(ctx, WS_A, sizeof(uint64_t) * (size_t)cap_ent, &p));
     uint64_t *g_ent = (uint64_t *)p;
@@ -730,7 +691,7 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     fb_count = (uint32_t *)((uint8_t *)p + 2048 + 8);
     uint32_t *over_count = fb_count + 1;
     SKM_HIP(hipMemsetAsync(g_counter, 0, 16, st));
-    const int nchunk = (int)skm_ceil_div(m, CH);
+    k_set_u64<<<1, 1, 0, st>>>(g_counter, fixed_ent);
     const char *gabl_env = getenv("SKM_GRAM_ABLATE");  // diagnostic builds of k_gram_sparse (1, 2, 4, 5: results NOT valid)
     const int gabl = gabl_env ? atoi(gabl_env) : 0;
     {
@@ -738,7 +699,7 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         SKM_PROF(ctx, "k_gram_sparse");
 #define SKM_GRAM(GABL)                                                                                               \
     k_gram_sparse<GABL, 1, 2048, 256, 2, 4><<<(unsigned)nrows, 256, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr,  \
-                                                                             d_ypost, row0, row1, nchunk, g_ent, cap_ent, \
+                                                                             d_ypost, row0, row1, SLOT, g_ent, cap_ent,   \
                                                                              g_counter, g_start, g_len, over_list, over_count)
         if (gabl == 1)
             SKM_GRAM(1);
@@ -761,7 +722,7 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         // rows the small tables cannot hold: 8192 slots and up to 4096 non-zeros, one row per workgroup
         SKM_PROF(ctx, "k_gram_sparse_big");
         k_gram_sparse_big<8192, 512, 8, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
-            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, nchunk, g_ent, cap_ent, g_counter, g_start, g_len,
+            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, g_ent, cap_ent, g_counter, g_start, g_len,
             over_list, over_count, nullptr, nullptr);
     }
     SKM_TRY(skm_check_launch("k_gram_sparse_big"));
@@ -769,7 +730,7 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         // one row per workgroup, 16 KiB per row and step (measured best shape)
         SKM_PROF(ctx, "k_cosine_write");
 #define SKM_WRITE(MODE, VEC)                                                                                         \
-    k_cosine_write<MODE, VEC, 1, 4096><<<(unsigned)nrows, 1024, 0, st>>>(g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, \
+    k_cosine_write<MODE, VEC, 4096><<<(unsigned)nrows, 1024, 0, st>>>(g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, \
                                                                           row1, d_out, ld, fb_list, fb_count, fb_flag)
         SKM_BY_MODE_VEC(SKM_WRITE);
 #undef SKM_WRITE

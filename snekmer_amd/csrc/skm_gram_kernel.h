@@ -5,11 +5,10 @@
 // (rows j of Y holding c, with counts v') contributes v*v' to G[i][j].  All (task, posting) pairs
 // of the strip are flattened with an LDS prefix sum over the posting-list lengths, so each
 // posting is read exactly once, by independent and mostly coalesced loads; products are summed in
-// per-row LDS hash tables keyed by j.  Finally each row's (j, dot) entries are appended to a
-// global list, grouped by 1024-column output chunk (LDS counting sort) for the streaming writer.
+// per-row LDS hash tables keyed by j.  Finally each row's (j, dot) entries are written to a
+// global list (in no particular order: the streaming writer and the top-k kernel do not need one).
 #pragma once
 
-constexpr int GNB = 1024;  // output chunks (of CH columns) a neighbour list can be grouped by
 // diagnostic only (GABL == 3): summed shader-clock ticks per phase over all workgroups
 __device__ unsigned long long g_gram_phase_ticks[8];
 
@@ -26,25 +25,27 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
                                                     const uint32_t *__restrict__ xcounts,
                                                     const uint32_t *__restrict__ ycolptr,
                                                     const uint64_t *__restrict__ ypost, int64_t row0, int64_t row1,
-                                                    int nchunk, uint64_t *__restrict__ g_ent, unsigned long long cap_ent,
+                                                    unsigned long long fixed_stride, uint64_t *__restrict__ g_ent,
+                                                    unsigned long long cap_ent,
                                                     unsigned long long *__restrict__ g_counter,
                                                     uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len,
                                                     uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_count)
 {
+    // fixed_stride != 0: row r of the block owns g_ent[r * fixed_stride ...) (no allocation needed);
+    // fixed_stride == 0: lists are allocated back to back from *g_counter, up to cap_ent entries.
     constexpr int GTCAP = GQ * GT;
     constexpr int GMAXD = GH / 2;
     constexpr int HBITS = __builtin_ctz(GH);
-    // tasks (pair phase) and chunk histograms (emit phase) share one region
-    __shared__ uint32_t s_u[3 * GTCAP + 1 > GR * GNB ? 3 * GTCAP + 1 : GR * GNB];
+    __shared__ uint32_t s_u[3 * GTCAP + 1];
     __shared__ uint32_t hkeys[GR][GH];
     __shared__ int hvals[GR][GH];
     __shared__ int64_t s_rp[GR + 1];
     __shared__ uint32_t s_wsum[GT / 64];
     __shared__ uint32_t s_distinct[GR];
+    __shared__ uint32_t s_fill[GR];
     __shared__ unsigned long long s_off[GR];
     __shared__ int s_over;
     uint32_t *t_start = s_u, *t_scan = s_u + GTCAP, *t_liv = s_u + 2 * GTCAP + 1;
-    uint32_t *hist = s_u;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int rows = (int)min((int64_t)GR, row1 - i0);
     unsigned long long stamp = 0;
@@ -68,8 +69,10 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
 
     if (tid <= GR)
         s_rp[tid] = xrowptr[i0 + (tid <= rows ? tid : rows)];
-    if (tid < GR)
+    if (tid < GR) {
         s_distinct[tid] = 0;
+        s_fill[tid] = 0;
+    }
     if (tid == 0)
         s_over = 0;
     for (int z = tid; z < GR * GH; z += GT) {
@@ -217,59 +220,41 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
         return;
     }
 
-    // emit each row's neighbours grouped by output chunk (counting sort on j / CH); the order inside a group is unspecified and does not matter to the writer
-    for (int z = tid; z < GR * GNB; z += GT)
-        if ((z & (GNB - 1)) < nchunk)
-            hist[z] = 0;
+    // emit each row's (j, dot) entries; one LDS counter bump per wave and step
     if (tid < GR) {
         unsigned long long off = 0;
         if (tid < rows)
-            off = atomicAdd(g_counter, (unsigned long long)s_distinct[tid]);
+            off = fixed_stride ? (unsigned long long)(i0 - row0 + tid) * fixed_stride
+                               : atomicAdd(g_counter, (unsigned long long)s_distinct[tid]);
         s_off[tid] = off;
     }
     __syncthreads();
-    for (int z = tid; z < GR * GH; z += GT) {
-        const uint32_t key = (&hkeys[0][0])[z];
-        if (key)
-            atomicAdd(&hist[(z / GH) * GNB + min((int)((key - 1u) / CH), nchunk - 1)], 1u);
-    }
-    __syncthreads();
-    if (wid < GR) {  // exclusive scan of row wid's chunk counters by one wave
-        uint32_t *hrow = hist + wid * GNB;
-        uint32_t carry = 0;
-        for (int base = 0; base < nchunk; base += 64) {
-            const uint32_t x = base + lane < nchunk ? hrow[base + lane] : 0u;
-            uint32_t inc = x;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                uint32_t up = __shfl_up(inc, o);
-                if (lane >= o)
-                    inc += up;
-            }
-            if (base + lane < nchunk)
-                hrow[base + lane] = carry + inc - x;
-            carry += __shfl(inc, 63);
-        }
-    }
-    __syncthreads();
-    phase(3);  // chunk histogram + scan
     bool fits[GR];
 #pragma unroll
     for (int r = 0; r < GR; ++r)
-        fits[r] = s_off[r] + (unsigned long long)s_distinct[r] <= cap_ent;
+        fits[r] = fixed_stride ? (unsigned long long)s_distinct[r] <= fixed_stride
+                               : s_off[r] + (unsigned long long)s_distinct[r] <= cap_ent;
+    static_assert((GR * GH) % GT == 0 && GH % 64 == 0, "emit loop must be wave-uniform");
     for (int z = tid; z < GR * GH; z += GT) {
         const uint32_t key = (&hkeys[0][0])[z];
-        const int r = z / GH;
-        if (key && fits[r]) {
-            const uint32_t pos = atomicAdd(&hist[r * GNB + min((int)((key - 1u) / CH), nchunk - 1)], 1u);
-            g_ent[s_off[r] + pos] = ((uint64_t)(key - 1u) << 32) | (uint32_t)(&hvals[0][0])[z];
+        const int r = z / GH;  // the same for all lanes of a wave
+        const bool has = key != 0u && fits[r];
+        const unsigned long long bal = __ballot(has);
+        if (bal) {
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(&s_fill[r], (uint32_t)__popcll(bal));
+            base = __shfl(base, 0);
+            if (has)
+                g_ent[s_off[r] + base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] =
+                    ((uint64_t)(key - 1u) << 32) | (uint32_t)(&hvals[0][0])[z];
         }
     }
     if (tid < rows) {
         g_start[i0 - row0 + tid] = s_off[tid];
         g_len[i0 - row0 + tid] = fits[tid] ? s_distinct[tid] : G_OVERFLOW;
     }
-    phase(4);  // emit
+    phase(3);  // emit
 }
 
 // One strip of GR consecutive rows per workgroup.
@@ -279,13 +264,14 @@ __global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ 
                                                     const uint32_t *__restrict__ xcounts,
                                                     const uint32_t *__restrict__ ycolptr,
                                                     const uint64_t *__restrict__ ypost, int64_t row0, int64_t row1,
-                                                    int nchunk, uint64_t *__restrict__ g_ent, unsigned long long cap_ent,
+                                                    unsigned long long fixed_stride, uint64_t *__restrict__ g_ent,
+                                                    unsigned long long cap_ent,
                                                     unsigned long long *__restrict__ g_counter,
                                                     uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len,
                                                     uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_count)
 {
     gram_strip<GABL, GR, GH, GT, GQ, SL>(row0 + (int64_t)blockIdx.x * GR, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0,
-                                         row1, nchunk, g_ent, cap_ent, g_counter, g_start, g_len, over_list, over_count);
+                                         row1, fixed_stride, g_ent, cap_ent, g_counter, g_start, g_len, over_list, over_count);
 }
 
 // Second pass with a large table (one row per workgroup) over the rows the first pass listed.
@@ -296,7 +282,7 @@ __global__ __launch_bounds__(GT) void k_gram_sparse_big(const int64_t *__restric
                                                         const uint32_t *__restrict__ xcounts,
                                                         const uint32_t *__restrict__ ycolptr,
                                                         const uint64_t *__restrict__ ypost, int64_t row0, int64_t row1,
-                                                        int nchunk, uint64_t *__restrict__ g_ent,
+                                                        uint64_t *__restrict__ g_ent,
                                                         unsigned long long cap_ent,
                                                         unsigned long long *__restrict__ g_counter,
                                                         uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len,
@@ -309,7 +295,7 @@ __global__ __launch_bounds__(GT) void k_gram_sparse_big(const int64_t *__restric
     for (uint32_t idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
         const int64_t i0 = row0 + row_list[idx];
         // a one-row strip: clamp row1 so that the strip never spills into the next row
-        gram_strip<0, 1, GH, GT, GQ, SL>(i0, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0, i0 + 1, nchunk, g_ent, cap_ent,
+        gram_strip<0, 1, GH, GT, GQ, SL>(i0, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0, i0 + 1, 0ull, g_ent, cap_ent,
                                          g_counter, g_start, g_len, over_list, over_count);
         __syncthreads();
     }

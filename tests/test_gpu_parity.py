@@ -440,6 +440,94 @@ def test_sharded_pipeline_over_rccl_single_rank_equals_pipeline(ctx):
         ctx.call("skm_comm_destroy")
 
 
+# ------------------------------------------------------------------ sharded step, two ranks on one GPU
+class _HostStagedExchange:
+    """Test-only stand-in for dist.RcclExchange (same interface): shards travel through host
+    memory with gloo, so that two ranks sharing ONE GPU can run ShardedPipeline.step for real.
+    The RCCL all-gather itself is covered by the one-rank test above."""
+
+    def __init__(self, ctx, world, rank):
+        self.ctx, self.world, self.rank = ctx, world, rank
+
+    def allgather_i64(self, values):
+        import torch
+        import torch.distributed as dist
+
+        t = torch.tensor(np.atleast_1d(np.asarray(values, dtype=np.int64)))
+        outs = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(outs, t)
+        return np.stack([o.numpy() for o in outs])
+
+    def allgatherv(self, d_send, nbytes_per_rank, d_recv):
+        import torch
+        import torch.distributed as dist
+
+        sizes = [int(x) for x in nbytes_per_rank]
+        mine = np.zeros(max(max(sizes), 1), dtype=np.uint8)
+        if sizes[self.rank]:
+            self.ctx._d2h(mine[: sizes[self.rank]], d_send.ptr)
+        outs = [torch.zeros(mine.size, dtype=torch.uint8) for _ in range(self.world)]
+        dist.all_gather(outs, torch.from_numpy(mine))
+        packed = np.concatenate([o.numpy()[:sz] for o, sz in zip(outs, sizes)])
+        if packed.size:
+            self.ctx._h2d(d_recv.ptr, np.ascontiguousarray(packed))
+
+
+def _sharded_rank(rank, world, port, n, tmpdir):
+    import torch.distributed as dist
+
+    from snekmer_amd import _hip
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.dist import ShardedPipeline, shard_bounds_by_residues
+    from snekmer_amd.synth import synth_families
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        A.register_alphabet("red6", A.RED6_GROUPS)
+        ctx = _hip.Context(0)
+        lut = A.build_lut("red6")
+        res, off, _ = synth_families(n, 300, family=30, seed=33)
+        bounds = shard_bounds_by_residues(off, world)
+        lo, hi = bounds[rank]
+        shard = engine.SeqBatch(ctx, res[off[lo]:off[hi]], off[lo:hi + 1] - off[lo])
+        sp = ShardedPipeline(ctx, lut, 12, _HostStagedExchange(ctx, world, rank), bounds, int(off[-1]))
+        for _ in range(2):  # second step reuses every buffer
+            out = sp.step(shard)
+        block = out.download().reshape(out.shape)[: hi - lo, :n]
+        np.save(os.path.join(tmpdir, f"block{rank}.npy"), block)
+        np.save(os.path.join(tmpdir, f"meta{rank}.npy"), np.asarray([lo, hi, sp.full.nnz, sp.basis.ncols]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_pipeline_two_ranks_on_one_gpu_equals_pipeline(ctx, tmp_path):
+    """World size 2 through the real ShardedPipeline.step (count shard, exchange, concat, basis,
+    row-block cosine): the stacked row blocks must equal the single-process result bit for bit."""
+    import torch.multiprocessing as mp
+
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+
+    n, world = 1500, 2
+    port = 29500 + (os.getpid() % 400)
+    mp.start_processes(_sharded_rank, args=(world, port, n, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    lut = A.build_lut("red6")
+    res, off, _ = synth_families(n, 300, family=30, seed=33)
+    ref = engine.Pipeline(ctx, lut, 12)
+    S = ref.step(engine.SeqBatch(ctx, res, off))
+    S = S.download().reshape(S.shape)[:n, :n]
+    covered = 0
+    for r in range(world):
+        lo, hi, nnz, ncols = np.load(tmp_path / f"meta{r}.npy")
+        assert (nnz, ncols) == (ref.csr.nnz, ref.basis.ncols)
+        assert (np.load(tmp_path / f"block{r}.npy") == S[lo:hi]).all()
+        covered += hi - lo
+    assert covered == n
+
+
 # ------------------------------------------------------------------ BASELINE full sizes
 def _sampled_row_check(ctx, name, k, n, seed_idx, nsample=48, family=100):
     from snekmer_amd import alphabet as A

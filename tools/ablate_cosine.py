@@ -59,7 +59,7 @@ ticks = (C.c_ulonglong * 8)()
 ctx.lib.skm_debug_gram_phases.argtypes = [C.c_void_p, C.c_void_p]
 ctx.lib.skm_debug_gram_phases(ctx.handle, ticks)
 os.environ.pop("SKM_GRAM_ABLATE")
-names = ["zero+rowptr", "tasks+scan", "pair loop", "hist+scan", "emit"]
-tot = sum(ticks[:5]) or 1
+names = ["zero+rowptr", "tasks+scan", "pair loop", "emit"]
+tot = sum(ticks[:4]) or 1
 print("gram phases (ticks per row, share of workgroup lifetime): " +
       ", ".join(f"{nm} {ticks[i] / pipe.csr.n:.0f} ({100 * ticks[i] / tot:.0f}%)" for i, nm in enumerate(names)))
