@@ -20,19 +20,13 @@ namespace {
 
 constexpr int BLK = 256;
 
-__global__ void k_iota_u32(uint32_t *out, int64_t n)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride)
-        out[i] = (uint32_t)i;
-}
-
 __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
 
-// rowid[e] = row owning CSR entry e; one wave per row.
+// rowcount[e] = (row owning CSR entry e) | count << 32, i.e. the entry's posting word, so that the
+// passes over the sorted order fetch both with one gather; one wave per row.
 __global__ __launch_bounds__(BLK) void k_expand_rowid(const int64_t *__restrict__ rowptr, int64_t n,
-                                                      uint32_t *__restrict__ rowid)
+                                                      const uint32_t *__restrict__ counts,
+                                                      uint64_t *__restrict__ rowcount)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -40,7 +34,7 @@ __global__ __launch_bounds__(BLK) void k_expand_rowid(const int64_t *__restrict_
     for (int64_t i = wave; i < n; i += nwaves) {
         const int64_t b = rowptr[i], e = rowptr[i + 1];
         for (int64_t t = b + lane; t < e; t += 64)
-            rowid[t] = (uint32_t)i;
+            rowcount[t] = (uint64_t)(uint32_t)i | ((uint64_t)counts[t] << 32);
     }
 }
 
@@ -56,8 +50,7 @@ template <typename K>
 __global__ __launch_bounds__(BLK) void k_basis_scatter(int64_t nnz, const K *__restrict__ skeys,
                                                        const uint32_t *__restrict__ sidx,
                                                        const uint32_t *__restrict__ colid1,
-                                                       const uint32_t *__restrict__ rowid,
-                                                       const uint32_t *__restrict__ counts,
+                                                       const uint64_t *__restrict__ rowcount,
                                                        const uint32_t *__restrict__ firstpos,
                                                        K *__restrict__ basis, uint32_t *__restrict__ colidx,
                                                        uint32_t *__restrict__ colptr, uint64_t *__restrict__ post,
@@ -79,11 +72,12 @@ __global__ __launch_bounds__(BLK) void k_basis_scatter(int64_t nnz, const K *__r
             continue;
         }
         colidx[e] = c;
-        uint32_t row = 0;
+        uint64_t rc = 0;
         if (post || (head && firstkey))
-            row = rowid[e];
+            rc = rowcount[e];
+        const uint32_t row = (uint32_t)rc;
         if (post)
-            post[t] = (uint64_t)row | ((uint64_t)counts[e] << 32);
+            post[t] = rc;
         if (head) {
             if (basis)
                 basis[c] = key;
@@ -294,14 +288,13 @@ __global__ void k_colptr_search(int64_t ncols, int64_t nnz, const uint32_t *__re
 }
 
 __global__ void k_gather_postings(int64_t nnz, const uint32_t *__restrict__ sidx,
-                                  const uint32_t *__restrict__ rowid, const uint32_t *__restrict__ counts,
-                                  uint64_t *__restrict__ post)
+                                  const uint64_t *__restrict__ rowcount, uint64_t *__restrict__ post)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; t < nnz; t += stride) {
         uint32_t e = sidx[t];
-        post[t] = (uint64_t)rowid[e] | ((uint64_t)counts[e] << 32);
+        post[t] = rowcount[e];
     }
 }
 
@@ -370,10 +363,11 @@ __global__ __launch_bounds__(BLK) void k_row_norms(int64_t n, const int64_t *__r
     }
 }
 
+// stable sort of (key, position) pairs: the payload is the entry's index before the sort
 template <typename K>
-int sort_pairs(skm_ctx *ctx, const K *kin, K *kout, const uint32_t *vin, uint32_t *vout, int64_t nnz, int bits,
-               const char *label)
+int sort_pairs(skm_ctx *ctx, const K *kin, K *kout, uint32_t *vout, int64_t nnz, int bits, const char *label)
 {
+    const rocprim::counting_iterator<uint32_t> vin(0);
     size_t tmp = 0;
     SKM_HIP(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, (size_t)nnz, 0u, (unsigned)bits, ctx->stream));
     void *p;
@@ -393,14 +387,12 @@ int basis_impl(skm_ctx *ctx, int key_bits, int flags, int64_t n, int64_t nnz, co
     void *p;
     SKM_TRY(skm_ws(ctx, WS_A, sizeof(K) * (size_t)nnz, &p));
     K *skeys = (K *)p;
-    SKM_TRY(skm_ws(ctx, WS_B, sizeof(uint32_t) * (size_t)nnz, &p));
-    uint32_t *iota = (uint32_t *)p;
     SKM_TRY(skm_ws(ctx, WS_C, sizeof(uint32_t) * (size_t)nnz, &p));
     uint32_t *sidx = (uint32_t *)p;
     SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)nnz, &p));
     uint32_t *colid1 = (uint32_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint32_t) * (size_t)nnz, &p));
-    uint32_t *rowid = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint64_t) * (size_t)nnz, &p));
+    uint64_t *rowcount = (uint64_t *)p;
 
     const bool need_stats = d_df || d_total;
     const bool need_fs = d_fs_order != nullptr;
@@ -422,15 +414,11 @@ int basis_impl(skm_ctx *ctx, int key_bits, int flags, int64_t n, int64_t nnz, co
 
     const int g_ent = skm_grid_cap(ctx, skm_ceil_div(nnz, BLK), 16);
     {
-        SKM_PROF(ctx, "k_iota_u32");
-        k_iota_u32<<<g_ent, BLK, 0, st>>>(iota, nnz);
-    }
-    {
         SKM_PROF(ctx, "k_expand_rowid");
-        k_expand_rowid<<<skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16), BLK, 0, st>>>(d_rowptr, n, rowid);
+        k_expand_rowid<<<skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16), BLK, 0, st>>>(d_rowptr, n, d_counts, rowcount);
     }
     SKM_TRY(skm_check_launch("k_expand_rowid"));
-    SKM_TRY(sort_pairs<K>(ctx, d_codes, skeys, iota, sidx, nnz, key_bits, "rocprim_radix_sort_codes"));
+    SKM_TRY(sort_pairs<K>(ctx, d_codes, skeys, sidx, nnz, key_bits, "rocprim_radix_sort_codes"));
     {
         size_t tmp = 0;
         auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), head_flag<K>{skeys});
@@ -444,7 +432,7 @@ int basis_impl(skm_ctx *ctx, int key_bits, int flags, int64_t n, int64_t nnz, co
         SKM_HIP(hipMemsetAsync(d_colidx, 0xFF, sizeof(uint32_t) * (size_t)nnz, st));
     {
         SKM_PROF(ctx, "k_basis_scatter");
-        k_basis_scatter<K><<<g_ent, BLK, 0, st>>>(nnz, skeys, sidx, colid1, rowid, d_counts, d_firstpos, d_basis,
+        k_basis_scatter<K><<<g_ent, BLK, 0, st>>>(nnz, skeys, sidx, colid1, rowcount, d_firstpos, d_basis,
                                                    d_colidx, colptr, post, firstkey, elide);
     }
     SKM_TRY(skm_check_launch("k_basis_scatter"));
@@ -465,8 +453,7 @@ int basis_impl(skm_ctx *ctx, int key_bits, int flags, int64_t n, int64_t nnz, co
         // first-seen order = ascending (row, first window) key
         SKM_TRY(skm_ws(ctx, WS_A, sizeof(uint64_t) * (size_t)B, &p));  // skeys no longer needed
         uint64_t *fk_sorted = (uint64_t *)p;
-        k_iota_u32<<<skm_grid_cap(ctx, skm_ceil_div(B, BLK), 16), BLK, 0, st>>>(iota, B);
-        SKM_TRY(sort_pairs<uint64_t>(ctx, firstkey, fk_sorted, iota, d_fs_order, B, 64, "rocprim_radix_sort_firstseen"));
+        SKM_TRY(sort_pairs<uint64_t>(ctx, firstkey, fk_sorted, d_fs_order, B, 64, "rocprim_radix_sort_firstseen"));
     }
     return SKM_OK;
 }
@@ -521,26 +508,23 @@ extern "C" int skm_csr_transpose(skm_ctx *ctx, int64_t n, int64_t nnz, int64_t n
     void *p;
     SKM_TRY(skm_ws(ctx, WS_A, sizeof(uint32_t) * (size_t)nnz, &p));
     uint32_t *skeys = (uint32_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_B, sizeof(uint32_t) * (size_t)nnz, &p));
-    uint32_t *iota = (uint32_t *)p;
     SKM_TRY(skm_ws(ctx, WS_C, sizeof(uint32_t) * (size_t)nnz, &p));
     uint32_t *sidx = (uint32_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint32_t) * (size_t)nnz, &p));
-    uint32_t *rowid = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint64_t) * (size_t)nnz, &p));
+    uint64_t *rowcount = (uint64_t *)p;
     const int g_ent = skm_grid_cap(ctx, skm_ceil_div(nnz, BLK), 16);
-    k_iota_u32<<<g_ent, BLK, 0, st>>>(iota, nnz);
-    k_expand_rowid<<<skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16), BLK, 0, st>>>(d_rowptr, n, rowid);
+    k_expand_rowid<<<skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16), BLK, 0, st>>>(d_rowptr, n, d_counts, rowcount);
     int bits = 1;
     while (bits < 32 && ((int64_t)1 << bits) < ncols)
         ++bits;
-    SKM_TRY(sort_pairs<uint32_t>(ctx, d_colidx, skeys, iota, sidx, nnz, bits, "rocprim_radix_sort_cols"));
+    SKM_TRY(sort_pairs<uint32_t>(ctx, d_colidx, skeys, sidx, nnz, bits, "rocprim_radix_sort_cols"));
     {
         SKM_PROF(ctx, "k_colptr_search");
         k_colptr_search<<<(unsigned)skm_ceil_div(ncols + 1, BLK), BLK, 0, st>>>(ncols, nnz, skeys, d_colptr);
     }
     {
         SKM_PROF(ctx, "k_gather_postings");
-        k_gather_postings<<<g_ent, BLK, 0, st>>>(nnz, sidx, rowid, d_counts, d_post);
+        k_gather_postings<<<g_ent, BLK, 0, st>>>(nnz, sidx, rowcount, d_post);
     }
     return skm_check_launch("k_gather_postings");
 }

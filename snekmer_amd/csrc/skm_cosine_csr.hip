@@ -692,7 +692,7 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     uint32_t *over_count = fb_count + 1;
     SKM_HIP(hipMemsetAsync(g_counter, 0, 16, st));
     k_set_u64<<<1, 1, 0, st>>>(g_counter, fixed_ent);
-    const char *gabl_env = getenv("SKM_GRAM_ABLATE");  // diagnostic builds of k_gram_sparse (1, 2, 4, 5: results NOT valid)
+    const char *gabl_env = getenv("SKM_GRAM_ABLATE");  // diagnostic builds of k_gram_sparse (1, 2, 4: results NOT valid)
     const int gabl = gabl_env ? atoi(gabl_env) : 0;
     {
         // one row per workgroup, 2048 slots: 22 KB of LDS -> 7 workgroups per CU (measured best shape)
@@ -707,8 +707,6 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
             SKM_GRAM(2);
         else if (gabl == 4)
             SKM_GRAM(4);
-        else if (gabl == 5)
-            SKM_GRAM(5);
         else if (gabl == 3) {  // phase stamps (exact results, slower): read with skm_debug_gram_phases
             unsigned long long zeros[8] = {};
             SKM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gram_phase_ticks), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice, st));

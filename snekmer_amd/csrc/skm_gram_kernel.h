@@ -170,8 +170,7 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
                     jj[u] = (uint32_t)(i0 + (lv[u] >> 28));
                     ww[u] = lv[u] & 0x0FFFFFFFu;
                 } else {
-                    const uint64_t pw = GABL == 5 ? (uint64_t)((g * 2654435761u) % 100000u) | (1ull << 32)  // diagnostic: no load
-                                                  : ypost[t_start[t] + (g - t_scan[t])];
+                    const uint64_t pw = ypost[t_start[t] + (g - t_scan[t])];
                     jj[u] = (uint32_t)pw;
                     ww[u] = (uint32_t)(pw >> 32);
                 }
