@@ -157,7 +157,10 @@ __global__ __launch_bounds__(64) void k_kmer_codes(skm_lut256 lut, int nsym, int
     }
 }
 
-// Wave-per-sequence count kernel for sequences with 1..512 windows.
+// Wave-per-sequence count kernel for sequences with 1..512 windows.  Lane l owns the 8
+// consecutive windows 8l..8l+7 (one code from k ranks, the next seven by a rolling update), the
+// wave sorts the 512 codes in registers (skm_wave_sort.h), run heads are ranked with a wave scan,
+// and (code, run start) go through LDS so that the global stores are contiguous.
 template <typename K, bool WITH_POS>
 __global__ __launch_bounds__(64) void k_count_short(skm_lut256 lut, int nsym, int k,
                                                     const uint8_t *__restrict__ seq,
@@ -168,12 +171,16 @@ __global__ __launch_bounds__(64) void k_count_short(skm_lut256 lut, int nsym, in
                                                     uint32_t *__restrict__ tmp_first, int32_t *__restrict__ row_nnz)
 {
     __shared__ uint8_t s_lut[256];
-    __shared__ uint8_t s_rank[SHORT_MAX + 64];
-    __shared__ K s_uniq[WITH_POS ? SHORT_MAX : 1];
+    __shared__ uint8_t s_rank[SHORT_MAX + 64 + 8];
+    __shared__ K s_uniq[SHORT_MAX];
+    __shared__ uint32_t s_start[SHORT_MAX + 1];
     __shared__ uint32_t s_pos[WITH_POS ? SHORT_MAX : 1];
     const int lane = threadIdx.x;
     const K SENT = sentinel<K>();
     reinterpret_cast<uint32_t *>(s_lut)[lane] = reinterpret_cast<const uint32_t *>(lut.b)[lane];
+    K msd = 1;  // nsym^(k-1): weight of the rank that leaves a window
+    for (int j = 1; j < k; ++j)
+        msd *= (K)nsym;
 
     for (uint32_t it = blockIdx.x; it < nlist; it += gridDim.x) {
         const uint32_t i = list[it];
@@ -187,71 +194,81 @@ __global__ __launch_bounds__(64) void k_count_short(skm_lut256 lut, int nsym, in
 
         K v[8];
         K orig[WITH_POS ? 8 : 1];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            int p = r * 64 + lane;
-            v[r] = p < w ? window_code<K>(s_rank, p, k, nsym) : SENT;
-            if constexpr (WITH_POS)
-                orig[r] = v[r];
-        }
-        wave_bitonic_512<K>(v, lane);
-
-        // run-length encode the sorted keys
-        unsigned long long hmask[8];
-        int nvalid = 0;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            K prev = shfl_idx_k<K>(v[r], (lane + 63) & 63);  // lane-1 (lane 0 reads lane 63: replaced below)
-            if (r > 0) {
-                K tail = shfl_idx_k<K>(v[r - 1], 63);
-                if (lane == 0)
-                    prev = tail;
-            }
-            bool valid = v[r] != SENT;
-            bool first = (r == 0 && lane == 0);
-            bool head = valid && (first || v[r] != prev);
-            hmask[r] = __ballot(head);
-            nvalid += __popcll(__ballot(valid));
-        }
-        int pre[9];
-        pre[0] = 0;
+        const int p0 = lane * 8;
 #pragma unroll
         for (int r = 0; r < 8; ++r)
-            pre[r + 1] = pre[r] + __popcll(hmask[r]);
-        const int nruns = pre[8];
+            v[r] = SENT;
+        if (p0 < w) {
+            K c = 0;
+            int bad = 0;
+            for (int j = 0; j < k; ++j) {
+                const uint32_t x = s_rank[p0 + j];
+                bad += x == 0xFFu;
+                c = c * (K)nsym + (K)(x == 0xFFu ? 0u : x);
+            }
+            v[0] = bad ? SENT : c;
+#pragma unroll
+            for (int r = 1; r < 8; ++r) {
+                // ranks past the sequence end may be stale; they only reach windows >= w, which stay SENT
+                const uint32_t out = s_rank[p0 + r - 1], in = s_rank[p0 + r - 1 + k];
+                bad += (int)(in == 0xFFu) - (int)(out == 0xFFu);
+                c = (c - (K)(out == 0xFFu ? 0u : out) * msd) * (K)nsym + (K)(in == 0xFFu ? 0u : in);
+                if (p0 + r < w && bad == 0)
+                    v[r] = c;
+            }
+        }
+        if constexpr (WITH_POS) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                orig[r] = v[r];
+        }
+        wave_bitonic_512_blocked<K>(v, lane);
+
+        // run heads: element e = lane*8 + r starts a run if it differs from element e-1
+        K prev = shfl_idx_k<K>(v[7], (lane + 63) & 63);
+        uint32_t hm = 0, nval = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const bool valid = v[r] != SENT;
+            const bool head = valid && ((r == 0 && lane == 0) || v[r] != prev);
+            hm |= head ? (1u << r) : 0u;
+            nval += valid ? 1u : 0u;
+            prev = v[r];
+        }
+        // exclusive wave scan of the per-lane head counts (low half) and valid counts (high half)
+        const uint32_t mine = (uint32_t)__popc(hm) | (nval << 16);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o)
+                incl += up;
+        }
+        const uint32_t tot = __shfl(incl, 63);
+        const int nruns = (int)(tot & 0xFFFFu), nvalid = (int)(tot >> 16);
+        const uint32_t base = (incl - mine) & 0xFFFFu;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if ((hm >> r) & 1u) {
+                const uint32_t idx = base + (uint32_t)__popc(hm & ((1u << r) - 1u));
+                s_uniq[idx] = v[r];
+                s_start[idx] = (uint32_t)(p0 + r);
+            }
+        }
+        if (lane == 0) {
+            s_start[nruns] = (uint32_t)nvalid;
+            row_nnz[i] = nruns;
+        }
         if constexpr (WITH_POS) {
             for (int t = lane; t < nruns; t += 64)
                 s_pos[t] = 0xFFFFFFFFu;
         }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if ((hmask[r] >> lane) & 1ull) {
-                int e = r * 64 + lane;
-                int idx = pre[r] + __popcll(hmask[r] & ((1ull << lane) - 1ull));
-                int next = nvalid;
-                unsigned long long m = lane == 63 ? 0ull : (hmask[r] >> (lane + 1));
-                if (m) {
-                    next = e + 1 + __ffsll((long long)m) - 1;
-                } else {
-                    bool found = false;
-#pragma unroll
-                    for (int r2 = 0; r2 < 8; ++r2) {
-                        if (r2 > r && !found && hmask[r2]) {
-                            next = r2 * 64 + __ffsll((long long)hmask[r2]) - 1;
-                            found = true;
-                        }
-                    }
-                }
-                tmp_codes[b + idx] = v[r];
-                tmp_counts[b + idx] = (uint32_t)(next - e);
-                if constexpr (WITH_POS)
-                    s_uniq[idx] = v[r];
-            }
+        __syncthreads();
+        for (int t = lane; t < nruns; t += 64) {
+            tmp_codes[b + t] = s_uniq[t];
+            tmp_counts[b + t] = s_start[t + 1] - s_start[t];
         }
-        if (lane == 0)
-            row_nnz[i] = nruns;
         if constexpr (WITH_POS) {
-            __syncthreads();
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 K c = orig[r];
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(64) void k_count_short(skm_lut256 lut, int nsym, in
                         else
                             hi = mid;
                     }
-                    atomicMin(&s_pos[lo], (uint32_t)(r * 64 + lane));
+                    atomicMin(&s_pos[lo], (uint32_t)(p0 + r));
                 }
             }
             __syncthreads();
