@@ -183,8 +183,9 @@ def main():
         nnz = csr.nnz
         ld = (n_total + 3) // 4 * 4
         # algorithmic bytes of one k_cosine_write launch (DESIGN.md "Kernels"): the float32 output
-        # block it must write; the sparse neighbour lists it reads are <1% of that and not counted
-        algo_bytes = rows_local * ld * 4
+        # rows it must write; the sparse neighbour lists it reads are <1% of that and not counted.
+        # (One launch per step; written so that it stays right if a step ever splits the launch.)
+        algo_bytes = rows_local * ld * 4 * args.steps / max(launches, 1)
         achieved = algo_bytes / (strip_avg_ms * 1e-3) / 1e9 if strip_avg_ms > 0 else 0.0
         line = {
             "metric": "sequences/sec vectorize+pairwise-cosine, 100k x 300aa k=12",

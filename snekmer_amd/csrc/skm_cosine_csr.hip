@@ -252,7 +252,7 @@ __global__ __launch_bounds__(WCH / 4) void k_cosine_write(const uint64_t *__rest
                                                      uint32_t *__restrict__ fb_flag)
 {
     constexpr int CH = WCH, TB = WCH / 4, WREG = 2;
-    __shared__ __attribute__((aligned(16))) int s_acc[CH];
+    __shared__ __attribute__((aligned(16))) float s_acc[CH];
     const int tid = threadIdx.x;
     const int64_t r = blockIdx.x;  // row of the block
     const int64_t i = row0 + r;
@@ -269,56 +269,71 @@ __global__ __launch_bounds__(WCH / 4) void k_cosine_write(const uint64_t *__rest
         }
         return;
     }
+    // Entries become (column, final float) pairs BEFORE the column loop, so that the loop itself
+    // issues no loads: a wave never waits on vmcnt there and its stores stay in flight across
+    // steps (with a load per step, the wait for it also drains the previous step's stores).
     const uint64_t *ent = g_ent + g_start[r];
-    uint64_t w[WREG];
+    const float ri = xrnorm[i];
+    const float background = MODE == 1 ? 1.0f : 0.0f;
+    auto value = [&](uint64_t x, float rj) -> float {
+        float o = (float)(int)(uint32_t)x * ri * rj;
+        if (MODE == 1) {
+            o = fminf(fmaxf(1.0f - o, 0.0f), 2.0f);
+            if ((int64_t)(uint32_t)(x >> 32) == i)
+                o = 0.0f;
+        }
+        return o;
+    };
+    // both entry loads, then both norm gathers, are issued back to back (the slot memory is always
+    // readable, so lanes past the end of the list load entry 0 and discard it)
+    uint64_t wx[WREG];
+    float wr[WREG];
 #pragma unroll
     for (int u = 0; u < WREG; ++u)
-        w[u] = (uint32_t)(tid + u * TB) < len ? ent[tid + u * TB] : ~0ull;  // column 0xFFFFFFFF never matches
-    const float ri = xrnorm[i];
-    reinterpret_cast<int4 *>(s_acc)[tid] = make_int4(0, 0, 0, 0);
+        wx[u] = ent[(uint32_t)(tid + u * TB) < len ? tid + u * TB : 0];
+#pragma unroll
+    for (int u = 0; u < WREG; ++u) {
+        const uint32_t j = (uint32_t)(wx[u] >> 32);
+        wr[u] = yrnorm[(uint32_t)(tid + u * TB) < len && (int64_t)j < m ? j : 0u];
+    }
+    uint32_t wj[WREG];
+    float wv[WREG];
+#pragma unroll
+    for (int u = 0; u < WREG; ++u) {
+        const bool have = (uint32_t)(tid + u * TB) < len;
+        wj[u] = have ? (uint32_t)(wx[u] >> 32) : 0xFFFFFFFFu;  // 0xFFFFFFFF never matches a column
+        wv[u] = value(wx[u], wr[u]);
+    }
+    const f32x4 bg4 = {background, background, background, background};
+    reinterpret_cast<f32x4 *>(s_acc)[tid] = bg4;
     __syncthreads();
 
     for (int64_t j0 = 0; j0 < m; j0 += CH) {
         const uint32_t j0u = (uint32_t)j0;
 #pragma unroll
         for (int u = 0; u < WREG; ++u) {
-            const uint32_t dj = (uint32_t)(w[u] >> 32) - j0u;
+            const uint32_t dj = wj[u] - j0u;
             if (dj < (uint32_t)CH)
-                s_acc[dj] = (int)(uint32_t)w[u];
+                s_acc[dj] = wv[u];
         }
-        for (uint32_t e = (uint32_t)tid + WREG * TB; e < len; e += TB) {
+        for (uint32_t e = (uint32_t)tid + WREG * TB; e < len; e += TB) {  // long lists: tail from L2 every step
             const uint64_t x = ent[e];
             const uint32_t dj = (uint32_t)(x >> 32) - j0u;
             if (dj < (uint32_t)CH)
-                s_acc[dj] = (int)(uint32_t)x;
+                s_acc[dj] = value(x, yrnorm[(uint32_t)(x >> 32)]);
+        }
+        if (MODE == 1) {  // the diagonal is an exact zero even when the row has no entry for itself
+            const uint32_t dj = (uint32_t)i - j0u;
+            if (tid == 0 && dj < (uint32_t)CH && i < m)
+                s_acc[dj] = 0.0f;
         }
         __syncthreads();
         const int64_t jc = j0 + 4 * tid;
-        float rj[4] = {0.f, 0.f, 0.f, 0.f};
-        if (VEC && jc + 3 < m) {
-            const float4 t4 = *reinterpret_cast<const float4 *>(yrnorm + jc);
-            rj[0] = t4.x, rj[1] = t4.y, rj[2] = t4.z, rj[3] = t4.w;
-        } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (jc + u < m)
-                    rj[u] = yrnorm[jc + u];
-        }
-        const int4 a = reinterpret_cast<int4 *>(s_acc)[tid];
-        reinterpret_cast<int4 *>(s_acc)[tid] = make_int4(0, 0, 0, 0);
-        float o[4] = {(float)a.x * ri * rj[0], (float)a.y * ri * rj[1], (float)a.z * ri * rj[2], (float)a.w * ri * rj[3]};
-        if (MODE == 1) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float d = 1.0f - o[u];
-                d = fminf(fmaxf(d, 0.0f), 2.0f);
-                o[u] = (jc + u == i) ? 0.0f : d;
-            }
-        }
+        const f32x4 o = reinterpret_cast<f32x4 *>(s_acc)[tid];
+        reinterpret_cast<f32x4 *>(s_acc)[tid] = bg4;
         float *dst = out + r * ld + jc;
         if (VEC && jc + 3 < m) {
-            f32x4 pack = {o[0], o[1], o[2], o[3]};
-            __builtin_nontemporal_store(pack, reinterpret_cast<f32x4 *>(dst));
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(dst));
         } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -547,7 +562,7 @@ extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrow
     {
         SKM_PROF(ctx, "k_gram_sparse");
         k_gram_sparse<0, 1, 2048, 256, 2, 4><<<(unsigned)nrows, 256, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr,
-                                                                              d_ypost, row0, row1, 0ull, d_ent, cap,
+                                                                              d_ypost, row0, row1, 0ull, 0, d_ent, cap,
                                                                               g_counter, d_start, d_len, list1, cnt1);
     }
     SKM_TRY(skm_check_launch("k_gram_sparse"));
@@ -699,7 +714,7 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         SKM_PROF(ctx, "k_gram_sparse");
 #define SKM_GRAM(GABL)                                                                                               \
     k_gram_sparse<GABL, 1, 2048, 256, 2, 4><<<(unsigned)nrows, 256, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr,  \
-                                                                             d_ypost, row0, row1, SLOT, g_ent, cap_ent,   \
+                                                                             d_ypost, row0, row1, SLOT, 0, g_ent, cap_ent, \
                                                                              g_counter, g_start, g_len, over_list, over_count)
         if (gabl == 1)
             SKM_GRAM(1);
@@ -725,7 +740,7 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     }
     SKM_TRY(skm_check_launch("k_gram_sparse_big"));
     {
-        // one row per workgroup, 16 KiB per row and step (measured best shape)
+        // one output row per workgroup, 16 KiB per step (measured best shape)
         SKM_PROF(ctx, "k_cosine_write");
 #define SKM_WRITE(MODE, VEC)                                                                                         \
     k_cosine_write<MODE, VEC, 4096><<<(unsigned)nrows, 1024, 0, st>>>(g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, \

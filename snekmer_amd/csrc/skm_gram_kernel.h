@@ -25,14 +25,15 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
                                                     const uint32_t *__restrict__ xcounts,
                                                     const uint32_t *__restrict__ ycolptr,
                                                     const uint64_t *__restrict__ ypost, int64_t row0, int64_t row1,
-                                                    unsigned long long fixed_stride, uint64_t *__restrict__ g_ent,
-                                                    unsigned long long cap_ent,
+                                                    unsigned long long fixed_stride, int64_t slot0,
+                                                    uint64_t *__restrict__ g_ent, unsigned long long cap_ent,
                                                     unsigned long long *__restrict__ g_counter,
                                                     uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len,
                                                     uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_count)
 {
-    // fixed_stride != 0: row r of the block owns g_ent[r * fixed_stride ...) (no allocation needed);
+    // fixed_stride != 0: row r of the launch owns g_ent[(slot0 + r) * fixed_stride ...) (no allocation);
     // fixed_stride == 0: lists are allocated back to back from *g_counter, up to cap_ent entries.
+    // g_start / g_len / over_list are indexed by the row's position in the launch (i - row0).
     constexpr int GTCAP = GQ * GT;
     constexpr int GMAXD = GH / 2;
     constexpr int HBITS = __builtin_ctz(GH);
@@ -223,7 +224,7 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     if (tid < GR) {
         unsigned long long off = 0;
         if (tid < rows)
-            off = fixed_stride ? (unsigned long long)(i0 - row0 + tid) * fixed_stride
+            off = fixed_stride ? (unsigned long long)(slot0 + i0 - row0 + tid) * fixed_stride
                                : atomicAdd(g_counter, (unsigned long long)s_distinct[tid]);
         s_off[tid] = off;
     }
@@ -263,14 +264,14 @@ __global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ 
                                                     const uint32_t *__restrict__ xcounts,
                                                     const uint32_t *__restrict__ ycolptr,
                                                     const uint64_t *__restrict__ ypost, int64_t row0, int64_t row1,
-                                                    unsigned long long fixed_stride, uint64_t *__restrict__ g_ent,
-                                                    unsigned long long cap_ent,
+                                                    unsigned long long fixed_stride, int64_t slot0,
+                                                    uint64_t *__restrict__ g_ent, unsigned long long cap_ent,
                                                     unsigned long long *__restrict__ g_counter,
                                                     uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len,
                                                     uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_count)
 {
     gram_strip<GABL, GR, GH, GT, GQ, SL>(row0 + (int64_t)blockIdx.x * GR, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0,
-                                         row1, fixed_stride, g_ent, cap_ent, g_counter, g_start, g_len, over_list, over_count);
+                                         row1, fixed_stride, slot0, g_ent, cap_ent, g_counter, g_start, g_len, over_list, over_count);
 }
 
 // Second pass with a large table (one row per workgroup) over the rows the first pass listed.
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(GT) void k_gram_sparse_big(const int64_t *__restric
     for (uint32_t idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
         const int64_t i0 = row0 + row_list[idx];
         // a one-row strip: clamp row1 so that the strip never spills into the next row
-        gram_strip<0, 1, GH, GT, GQ, SL>(i0, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0, i0 + 1, 0ull, g_ent, cap_ent,
+        gram_strip<0, 1, GH, GT, GQ, SL>(i0, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0, i0 + 1, 0ull, 0, g_ent, cap_ent,
                                          g_counter, g_start, g_len, over_list, over_count);
         __syncthreads();
     }
