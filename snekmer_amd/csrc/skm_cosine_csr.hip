@@ -11,12 +11,12 @@
 // entries are zero.  The output matrix itself (N*M float32) is the irreducible traffic, so the
 // stage is organised around a streaming writer bound by HBM write bandwidth:
 //
-//   k_gram_sparse      (skm_gram_kernel.h) workgroup per row: every (non-zero, posting) pair of the
-//                      row is read once with independent loads and accumulated in an LDS hash
-//                      table keyed by the neighbour row; the row's (j, exact int32 dot) entries
-//                      are appended to a global neighbour list grouped by 1024-column chunk.
+//   k_gram_sparse      (skm_gram_kernel.h) workgroup per row: groups of lanes walk the posting lists
+//                      of the row's non-zeros (each posting read once, next lists' loads in flight)
+//                      and accumulate v*v' in an LDS hash table keyed by the neighbour row; the
+//                      row's (j, exact int32 dot) entries go to the row's slot of a global list.
 //   k_gram_sparse_big  the same with an 8192-slot table and room for 4096 non-zeros, for the rows
-//                      the first pass flags (more than 1024 neighbours or 512 distinct k-mers).
+//                      the first pass flags (more than 1536 neighbours or 512 distinct k-mers).
 //   k_cosine_write     workgroup per output row, pure streaming writer: per 4096-column step it
 //                      drops the step's neighbour entries into a zeroed LDS tile, scales to float32
 //                      (mode 1: cosine distance) and stores 16 B per lane.  Dominant kernel.
@@ -566,19 +566,19 @@ extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrow
     const unsigned long long cap = (unsigned long long)cap_ent;
     {
         SKM_PROF(ctx, "k_gram_sparse");
-        k_gram_sparse<0, 1, 2048, 256, 2, 4><<<(unsigned)nrows, 256, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr,
+        k_gram_sparse<0, 1, 2048, 256, 2, 32, 2><<<(unsigned)nrows, 256, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr,
                                                                               d_ypost, row0, row1, 0ull, 0, d_ent, cap,
                                                                               g_counter, d_start, d_len, list1, cnt1);
     }
     SKM_TRY(skm_check_launch("k_gram_sparse"));
     {
         SKM_PROF(ctx, "k_gram_sparse_big");
-        k_gram_sparse_big<8192, 512, 8, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
+        k_gram_sparse_big<8192, 512, 8, 16, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
             d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, d_ent, cap, g_counter, d_start, d_len,
             list1, cnt1, list2, cnt2);
         // largest table that fits LDS: 16384 slots (8192 neighbours), up to 1024 distinct k-mers
         SKM_HIP(hipMemsetAsync(cnt1, 0, 4, st));
-        k_gram_sparse_big<16384, 512, 2, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
+        k_gram_sparse_big<16384, 512, 2, 16, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
             d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, d_ent, cap, g_counter, d_start, d_len,
             list2, cnt2, list1, cnt1);
     }
@@ -689,7 +689,7 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     // ---- fast path: sparse Gram (+ large-table pass) -> streaming writer -> cursor kernel for what is left
     // neighbour lists: row r of the block owns SLOT entries at g_ent[r * SLOT] (all the first pass
     // can produce); the lists of the large-table pass are allocated behind that region
-    constexpr unsigned long long SLOT = 1024;
+    constexpr unsigned long long SLOT = 1536;  // = the first pass's table capacity
     const unsigned long long fixed_ent = (unsigned long long)nrows * SLOT;
     const unsigned long long cap_ent = fixed_ent + (unsigned long long)max((int64_t)(1 << 20), nrows * 256);
     void *p;
@@ -717,10 +717,11 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     {
         // one row per workgroup, 2048 slots: 22 KB of LDS -> 7 workgroups per CU (measured best shape)
         SKM_PROF(ctx, "k_gram_sparse");
-#define SKM_GRAM(GABL)                                                                                               \
-    k_gram_sparse<GABL, 1, 2048, 256, 2, 4><<<(unsigned)nrows, 256, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr,  \
-                                                                             d_ypost, row0, row1, SLOT, 0, g_ent, cap_ent, \
-                                                                             g_counter, g_start, g_len, over_list, over_count)
+#define SKM_GRAM_S(GABL, GG, UU)                                                                                     \
+    k_gram_sparse<GABL, 1, 2048, 256, 2, GG, UU><<<(unsigned)nrows, 256, 0, st>>>(                                   \
+        d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, SLOT, 0, g_ent, cap_ent, g_counter, g_start, \
+        g_len, over_list, over_count)
+#define SKM_GRAM(GABL) SKM_GRAM_S(GABL, 32, 2)
         if (gabl == 1)
             SKM_GRAM(1);
         else if (gabl == 2)
@@ -734,12 +735,13 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         } else
             SKM_GRAM(0);
 #undef SKM_GRAM
+#undef SKM_GRAM_S
     }
     SKM_TRY(skm_check_launch("k_gram_sparse"));
     {
         // rows the small tables cannot hold: 8192 slots and up to 4096 non-zeros, one row per workgroup
         SKM_PROF(ctx, "k_gram_sparse_big");
-        k_gram_sparse_big<8192, 512, 8, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
+        k_gram_sparse_big<8192, 512, 8, 16, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
             d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, g_ent, cap_ent, g_counter, g_start, g_len,
             over_list, over_count, nullptr, nullptr);
     }

@@ -2,11 +2,13 @@
 // Included by skm_cosine_csr.hip inside its anonymous namespace (needs CH from there).
 //
 // For the rows of one strip every non-zero (row i, column c, count v) is a task whose posting list
-// (rows j of Y holding c, with counts v') contributes v*v' to G[i][j].  All (task, posting) pairs
-// of the strip are flattened with an LDS prefix sum over the posting-list lengths, so each
-// posting is read exactly once, by independent and mostly coalesced loads; products are summed in
-// per-row LDS hash tables keyed by j.  Finally each row's (j, dot) entries are written to a
-// global list (in no particular order: the streaming writer and the top-k kernel do not need one).
+// (rows j of Y holding c, with counts v') contributes v*v' to G[i][j].  The strip's tasks are
+// compacted into LDS; groups of G lanes then take one task each and walk its posting list (every
+// posting is read once, G*8 contiguous bytes per load); products are summed in per-row LDS hash
+// tables keyed by j.  Finally each row's (j, dot) entries are written to a global list (in no
+// particular order: the streaming writer and the top-k kernel do not need one).
+// (An earlier version flattened all (task, posting) pairs with a prefix sum and a per-step binary
+// search: perfectly balanced, but ~8 LDS operations per pair made the LDS pipe the bound.)
 #pragma once
 
 // diagnostic only (GABL == 3): summed shader-clock ticks per phase over all workgroups
@@ -16,10 +18,10 @@ constexpr uint32_t G_OVERFLOW = 0xFFFFFFFFu;
 constexpr uint32_t G_SINGLETON = 0xFFFFFFFFu;  // colidx of a k-mer that occurs in one row only
 
 // GABL  diagnostic ablation (0 = real kernel)
-// GR    rows per workgroup           GH  hash slots per row (at most GH/2 distinct neighbours)
-// GT    threads per workgroup        GQ  tasks per thread (GQ*GT non-zeros per strip)
-// SL    consecutive pairs a thread handles per step
-template <int GABL, int GR, int GH, int GT, int GQ, int SL>
+// GR    rows per workgroup           GH  hash slots per row (at most 3/4 GH distinct neighbours)
+// GT    threads per workgroup        GQ  non-zeros per thread (GQ*GT non-zeros per strip)
+// G     lanes that share one posting list          U  posting loads a lane issues before it inserts
+template <int GABL, int GR, int GH, int GT, int GQ, int G, int U>
 __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__restrict__ xrowptr,
                                                     const uint32_t *__restrict__ xcolidx,
                                                     const uint32_t *__restrict__ xcounts,
@@ -34,20 +36,23 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     // fixed_stride != 0: row r of the launch owns g_ent[(slot0 + r) * fixed_stride ...) (no allocation);
     // fixed_stride == 0: lists are allocated back to back from *g_counter, up to cap_ent entries.
     // g_start / g_len / over_list are indexed by the row's position in the launch (i - row0).
+    static_assert(GR <= 16 && G <= 64 && 64 % G == 0 && GT % 64 == 0, "shape");
     constexpr int GTCAP = GQ * GT;
-    constexpr int GMAXD = GH / 2;
+    constexpr int GMAXD = GH / 4 * 3;  // load factor at most 0.75
     constexpr int HBITS = __builtin_ctz(GH);
-    __shared__ uint32_t s_u[3 * GTCAP + 1];
+    constexpr int NG = GT / G;  // posting lists in flight per workgroup
+    constexpr int LONG_DF = 4 * G * U;
+    __shared__ uint32_t t_start[GTCAP], t_df[GTCAP], t_liv[GTCAP];
     __shared__ uint32_t hkeys[GR][GH];
     __shared__ int hvals[GR][GH];
     __shared__ int64_t s_rp[GR + 1];
-    __shared__ uint32_t s_wsum[GT / 64];
     __shared__ uint32_t s_distinct[GR];
     __shared__ uint32_t s_fill[GR];
+    __shared__ uint32_t s_self[GR];
     __shared__ unsigned long long s_off[GR];
+    __shared__ uint32_t s_ntask, s_nlong;
     __shared__ int s_over;
-    uint32_t *t_start = s_u, *t_scan = s_u + GTCAP, *t_liv = s_u + 2 * GTCAP + 1;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int rows = (int)min((int64_t)GR, row1 - i0);
     unsigned long long stamp = 0;
     auto phase = [&](int idx) {
@@ -67,15 +72,41 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
                 over_list[atomicAdd(over_count, 1u)] = (uint32_t)(i0 - row0 + tid);
         }
     };
+    // G[li][j] += prod.  Most pairs hit a key that is already present, so look with a plain LDS
+    // read first and pay for the compare-and-swap only when the slot still looks empty.
+    auto insert = [&](int li, uint32_t j, int prod) {
+        const uint32_t key = j + 1u;
+        uint32_t h = (j * 2654435761u) >> (32 - HBITS);
+        for (int probe = 0; probe < GH; ++probe) {
+            uint32_t seen = __atomic_load_n(&hkeys[li][h], __ATOMIC_RELAXED);
+            if (seen == 0u) {
+                seen = atomicCAS(&hkeys[li][h], 0u, key);
+                if (seen == 0u) {
+                    seen = key;
+                    if (atomicAdd(&s_distinct[li], 1u) >= (uint32_t)GMAXD)
+                        s_over = 1;
+                }
+            }
+            if (seen == key) {
+                atomicAdd(&hvals[li][h], prod);
+                break;
+            }
+            h = (h + 1) & (GH - 1);
+        }
+    };
 
     if (tid <= GR)
         s_rp[tid] = xrowptr[i0 + (tid <= rows ? tid : rows)];
     if (tid < GR) {
         s_distinct[tid] = 0;
         s_fill[tid] = 0;
+        s_self[tid] = 0;
     }
-    if (tid == 0)
+    if (tid == 0) {
         s_over = 0;
+        s_ntask = 0;
+        s_nlong = 0;
+    }
     for (int z = tid; z < GR * GH; z += GT) {
         (&hkeys[0][0])[z] = 0u;
         (&hvals[0][0])[z] = 0;
@@ -83,129 +114,175 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     __syncthreads();
     phase(0);  // table zeroing + row pointers
     const int64_t e0 = s_rp[0];
-    const int64_t ntasks64 = s_rp[GR] - e0;
-    if (ntasks64 > GTCAP) {
+    const int64_t nnz64 = s_rp[GR] - e0;
+    if (nnz64 > GTCAP) {
         flag_rows();
         return;
     }
-    const int ntasks = (int)ntasks64;
+    const int nnz = (int)nnz64;
 
-    // posting-list length of every task + exclusive prefix sum over the strip
-    uint32_t mydf[GQ];
-    uint32_t mysum = 0;
+    // Tasks: one per non-zero (row li, column c, count v) whose k-mer also occurs in another row.
+    // A k-mer of this row only (skm_basis_build, ELIDE_SINGLETONS) pairs with nothing but its own
+    // row: its v*v goes straight to the row's self product.
+    uint32_t col[GQ], val[GQ], pb[GQ], pe[GQ];
+    uint32_t self = 0;  // GR == 1: summed over the wave, then one LDS add
 #pragma unroll
     for (int q = 0; q < GQ; ++q) {
-        const int t = tid * GQ + q;
-        mydf[q] = 0;
-        if (t < ntasks) {
-            const int64_t e = e0 + t;
-            int li = 0;
-#pragma unroll
-            for (int r = 1; r < GR; ++r)
-                li += (e >= s_rp[r]) ? 1 : 0;
-            const uint32_t c = xcolidx[e];
-            t_liv[t] = ((uint32_t)li << 28) | (xcounts[e] & 0x0FFFFFFFu);
-            if (c == G_SINGLETON) {  // k-mer of this row only (skm_basis_build, ELIDE_SINGLETONS)
-                t_start[t] = G_SINGLETON;
-                mydf[q] = 1;
-            } else {
-                const uint32_t pb = ycolptr[c], pe = ycolptr[c + 1];
-                t_start[t] = pb;
-                mydf[q] = pe - pb;
-            }
+        const int t = q * GT + tid;
+        col[q] = G_SINGLETON;
+        val[q] = 0;
+        if (t < nnz) {
+            col[q] = xcolidx[e0 + t];
+            val[q] = xcounts[e0 + t];
         }
-        mysum += mydf[q];
     }
-    uint32_t incl = mysum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t up = __shfl_up(incl, o);
-        if (lane >= o)
-            incl += up;
-    }
-    if (lane == 63)
-        s_wsum[wid] = incl;
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-#pragma unroll
-    for (int q = 0; q < GT / 64; ++q) {
-        wbase += q < wid ? s_wsum[q] : 0;
-        total += s_wsum[q];
-    }
-    uint32_t run = wbase + incl - mysum;
 #pragma unroll
     for (int q = 0; q < GQ; ++q) {
-        const int t = tid * GQ + q;
-        if (t < ntasks)
-            t_scan[t] = run;
-        run += mydf[q];
+        pb[q] = pe[q] = 0;
+        if (col[q] != G_SINGLETON) {
+            pb[q] = ycolptr[col[q]];
+            pe[q] = ycolptr[col[q] + 1];
+        }
     }
-    if (tid == 0)
-        t_scan[ntasks] = total;
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) {
+        const int t = q * GT + tid;
+        int li = 0;
+#pragma unroll
+        for (int r = 1; r < GR; ++r)
+            li += (e0 + t >= s_rp[r]) ? 1 : 0;
+        const bool task = pe[q] > pb[q];
+        if (col[q] == G_SINGLETON && t < nnz) {
+            const uint32_t vv = (val[q] & 0x0FFFFFFFu) * (val[q] & 0x0FFFFFFFu);
+            if (GR == 1)
+                self += vv;
+            else
+                atomicAdd(&s_self[li], vv);
+        }
+        const bool is_long = task && pe[q] - pb[q] > (uint32_t)LONG_DF;
+        const bool is_short = task && !is_long;
+        const unsigned long long bal = __ballot(is_short), bal_long = __ballot(is_long);
+        if (bal | bal_long) {
+            uint32_t base = 0, base_long = 0;
+            if (lane == 0) {
+                if (bal)
+                    base = atomicAdd(&s_ntask, (uint32_t)__popcll(bal));
+                if (bal_long)
+                    base_long = atomicAdd(&s_nlong, (uint32_t)__popcll(bal_long));
+            }
+            base = __shfl(base, 0);
+            base_long = __shfl(base_long, 0);
+            if (task) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                // short lists fill the arrays from the front, long ones from the back
+                const uint32_t pos = is_long ? (uint32_t)(GTCAP - 1) - (base_long + (uint32_t)__popcll(bal_long & below))
+                                             : base + (uint32_t)__popcll(bal & below);
+                t_start[pos] = pb[q];
+                t_df[pos] = pe[q] - pb[q];
+                t_liv[pos] = ((uint32_t)li << 28) | (val[q] & 0x0FFFFFFFu);
+            }
+        }
+    }
+    if (GR == 1) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            self += __shfl_xor(self, o);
+        if (lane == 0 && self)
+            atomicAdd(&s_self[0], self);
+    }
     __syncthreads();
-    phase(1);  // task loads + prefix sum
+    phase(1);  // task loads + compaction
+    if (tid < rows && s_self[tid] && GABL != 1 && GABL != 4)
+        insert(tid, (uint32_t)(i0 + tid), (int)s_self[tid]);
 
-    // every (task, posting) pair once.  A thread takes SL consecutive pairs per step: one
-    // branch-free binary search locates the first pair's task, the rest walk forward; all posting
-    // loads of the step are issued before the first hash insert.
-    for (uint32_t g0 = (uint32_t)tid * SL; GABL != 1 && g0 < total; g0 += GT * SL) {
-        if (s_over)
-            break;
-        int t = 0;
+    // A batch = U postings of one list per lane (lane u-th posting at first + u*stride).
+    // Lanes past the end of the list load posting 0 and discard it: loads under a branch would make
+    // the compiler wait for ALL outstanding loads (vmcnt(0)) before the next LDS phase.  Only called
+    // when the strip has a task, so posting 0 exists.
+    auto load_batch = [&](uint64_t (&pw)[U], uint32_t start, uint32_t df, uint32_t first, uint32_t stride) {
 #pragma unroll
-        for (int w = GTCAP / 2; w > 0; w >>= 1) {
-            const int cand = t + w;
-            if (cand < ntasks && t_scan[cand] <= g0)
-                t = cand;
+        for (int u = 0; u < U; ++u)
+            pw[u] = ypost[first + u * stride < df ? start + first + u * stride : 0u];
+    };
+    // all first-probe key reads, then the adds (a key that is not where the first probe looks takes
+    // the general insert)
+    auto insert_batch = [&](const uint64_t (&pw)[U], uint32_t df, int v, int li, uint32_t first, uint32_t stride) {
+        if (GABL == 4) {  // diagnostic: loads only, no hash insert
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                asm volatile("" ::"v"((uint32_t)pw[u]), "v"((uint32_t)(pw[u] >> 32)));
+            return;
         }
-        uint32_t jj[SL], ww[SL], lv[SL];
+        uint32_t hh[U], seen[U];
 #pragma unroll
-        for (int u = 0; u < SL; ++u) {
-            const uint32_t g = g0 + u;
-            jj[u] = ww[u] = lv[u] = 0;
-            if (g < total) {
-                while (t_scan[t + 1] <= g)
-                    ++t;
-                lv[u] = t_liv[t];
-                if (t_start[t] == G_SINGLETON) {  // pairs with its own row only
-                    jj[u] = (uint32_t)(i0 + (lv[u] >> 28));
-                    ww[u] = lv[u] & 0x0FFFFFFFu;
-                } else {
-                    const uint64_t pw = ypost[t_start[t] + (g - t_scan[t])];
-                    jj[u] = (uint32_t)pw;
-                    ww[u] = (uint32_t)(pw >> 32);
-                }
-            }
+        for (int u = 0; u < U; ++u) {
+            hh[u] = ((uint32_t)pw[u] * 2654435761u) >> (32 - HBITS);
+            seen[u] = __atomic_load_n(&hkeys[li][hh[u]], __ATOMIC_RELAXED);
         }
 #pragma unroll
-        for (int u = 0; u < SL; ++u) {
-            if (GABL == 4) {  // diagnostic: loads only, no hash insert
-                asm volatile("" ::"v"(jj[u]), "v"(ww[u]), "v"(lv[u]));
-            } else if (g0 + u < total) {
-                const uint32_t j = jj[u];
-                const int prod = (int)(lv[u] & 0x0FFFFFFFu) * (int)ww[u];
-                const int li = (int)(lv[u] >> 28);
-                const uint32_t key = j + 1u;
-                uint32_t h = (j * 2654435761u) >> (32 - HBITS);
-                // Most pairs hit a key that is already present, so look with a plain LDS read first
-                // and pay for the compare-and-swap only when the slot still looks empty.
-                for (int probe = 0; probe < GH; ++probe) {
-                    uint32_t seen = __atomic_load_n(&hkeys[li][h], __ATOMIC_RELAXED);
-                    if (seen == 0u) {
-                        seen = atomicCAS(&hkeys[li][h], 0u, key);
-                        if (seen == 0u) {
-                            seen = key;
-                            if (atomicAdd(&s_distinct[li], 1u) >= (uint32_t)GMAXD)
-                                s_over = 1;
-                        }
-                    }
-                    if (seen == key) {
-                        atomicAdd(&hvals[li][h], prod);
-                        break;
-                    }
-                    h = (h + 1) & (GH - 1);
-                }
+        for (int u = 0; u < U; ++u) {
+            if (first + u * stride < df) {
+                const uint32_t j = (uint32_t)pw[u];
+                const int prod = v * (int)(uint32_t)(pw[u] >> 32);
+                if (seen[u] == j + 1u)
+                    atomicAdd(&hvals[li][hh[u]], prod);
+                else
+                    insert(li, j, prod);
             }
+        }
+    };
+    auto walk = [&](uint32_t start, uint32_t df, int v, int li, uint32_t first, uint32_t stride) {
+        for (uint32_t p = first; p < df; p += stride * U) {
+            uint64_t pw[U];
+            load_batch(pw, start, df, p, stride);
+            insert_batch(pw, df, v, li, p, stride);
+        }
+    };
+    // Short lists (at most LONG_DF postings): G consecutive lanes walk one list, software
+    // pipelined so that the loads of a group's next list are in flight while it inserts the
+    // current one (the gather, not the LDS, is the slow side).  Long lists (a few low-complexity
+    // k-mers occur in thousands of rows) are walked by the whole workgroup.
+    const int nshort = (int)s_ntask, nlong = (int)s_nlong;
+    if (GABL != 1 && nshort + nlong > 0) {
+        const uint32_t gl = (uint32_t)(tid % G);
+        struct hdr {
+            uint32_t start, df, lv;
+        };
+        auto fetch = [&](uint64_t (&pw)[U], int t) -> hdr {
+            hdr h = {0u, 0u, 0u};
+            if (t < nshort)
+                h = {t_start[t], t_df[t], t_liv[t]};
+            load_batch(pw, h.start, h.df, gl, G);
+            return h;
+        };
+        auto consume = [&](const uint64_t (&pw)[U], const hdr &h) {
+            const int v = (int)(h.lv & 0x0FFFFFFFu), li = (int)(h.lv >> 28);
+            insert_batch(pw, h.df, v, li, gl, G);
+            if (h.df > (uint32_t)(G * U))  // the rest of a list longer than one batch
+                walk(h.start, h.df, v, li, gl + G * U, G);
+        };
+        // D register sets used in turn (no copies: a copy would wait for the load): while a group
+        // inserts one batch, the loads of its next D-1 lists are in flight
+        constexpr int D = 2;
+        uint64_t buf[D][U];
+        hdr hd[D];
+        int t = tid / G;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            hd[d] = fetch(buf[d], t + d * NG);
+        while (t < nshort && !s_over) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {  // lists past the end have df == 0: nothing is inserted
+                consume(buf[d], hd[d]);
+                hd[d] = fetch(buf[d], t + (d + D) * NG);
+            }
+            t += D * NG;
+        }
+        for (int tl = GTCAP - 1; tl > GTCAP - 1 - nlong; --tl) {
+            if (s_over)
+                break;
+            const uint32_t lv = t_liv[tl];
+            walk(t_start[tl], t_df[tl], (int)(lv & 0x0FFFFFFFu), (int)(lv >> 28), (uint32_t)tid, GT);
         }
     }
     __syncthreads();
@@ -258,7 +335,7 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
 }
 
 // One strip of GR consecutive rows per workgroup.
-template <int GABL, int GR, int GH, int GT, int GQ, int SL>
+template <int GABL, int GR, int GH, int GT, int GQ, int G, int U>
 __global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ xrowptr,
                                                     const uint32_t *__restrict__ xcolidx,
                                                     const uint32_t *__restrict__ xcounts,
@@ -270,13 +347,13 @@ __global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ 
                                                     uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len,
                                                     uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_count)
 {
-    gram_strip<GABL, GR, GH, GT, GQ, SL>(row0 + (int64_t)blockIdx.x * GR, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0,
+    gram_strip<GABL, GR, GH, GT, GQ, G, U>(row0 + (int64_t)blockIdx.x * GR, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0,
                                          row1, fixed_stride, slot0, g_ent, cap_ent, g_counter, g_start, g_len, over_list, over_count);
 }
 
 // Second pass with a large table (one row per workgroup) over the rows the first pass listed.
 // The grid is fixed; workgroups stride over the list, whose length is only known on the device.
-template <int GH, int GT, int GQ, int SL>
+template <int GH, int GT, int GQ, int G, int U>
 __global__ __launch_bounds__(GT) void k_gram_sparse_big(const int64_t *__restrict__ xrowptr,
                                                         const uint32_t *__restrict__ xcolidx,
                                                         const uint32_t *__restrict__ xcounts,
@@ -295,7 +372,7 @@ __global__ __launch_bounds__(GT) void k_gram_sparse_big(const int64_t *__restric
     for (uint32_t idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
         const int64_t i0 = row0 + row_list[idx];
         // a one-row strip: clamp row1 so that the strip never spills into the next row
-        gram_strip<0, 1, GH, GT, GQ, SL>(i0, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0, i0 + 1, 0ull, 0, g_ent, cap_ent,
+        gram_strip<0, 1, GH, GT, GQ, G, U>(i0, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0, i0 + 1, 0ull, 0, g_ent, cap_ent,
                                          g_counter, g_start, g_len, over_list, over_count);
         __syncthreads();
     }
