@@ -80,6 +80,8 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
         for (int probe = 0; probe < GH; ++probe) {
             uint32_t seen = __atomic_load_n(&hkeys[li][h], __ATOMIC_RELAXED);
             if (seen == 0u) {
+                if (s_over)  // the row is already lost: no new keys, so the table never fills up
+                    return;  // (a full table would make every later probe walk all GH slots)
                 seen = atomicCAS(&hkeys[li][h], 0u, key);
                 if (seen == 0u) {
                     seen = key;
@@ -232,7 +234,7 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
         }
     };
     auto walk = [&](uint32_t start, uint32_t df, int v, int li, uint32_t first, uint32_t stride) {
-        for (uint32_t p = first; p < df; p += stride * U) {
+        for (uint32_t p = first; p < df && !s_over; p += stride * U) {
             uint64_t pw[U];
             load_batch(pw, start, df, p, stride);
             insert_batch(pw, df, v, li, p, stride);

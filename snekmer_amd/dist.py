@@ -124,7 +124,9 @@ class ShardedPipeline:
         self.rnorm = None
         self.out = None
 
-    def step(self, shard_batch):
+    def exchange(self, shard_batch):
+        """vectorize the local shard and all-gather the CSR shards: afterwards `self.full` (all N
+        rows), `self.basis` (postings of the full matrix) and `self.rnorm` are set on every rank."""
         e, ctx = self.engine, self.ctx
         self.local = e.count_csr(ctx, shard_batch, self.lut, self.k, out=self.local)
         meta = self.ex.allgather_i64([self.local.nnz, e.csr_max_count(ctx, self.local)])
@@ -146,6 +148,12 @@ class ShardedPipeline:
         self.full.nnz = int(h_nnz.sum())
         self.basis = e.build_basis(ctx, self.full, self.lut.nsym, self.k, out=self.basis, elide_singletons=True)
         self.rnorm = e.row_norms(ctx, self.n_total, self.full.rowptr, self.full.counts, out=self.rnorm)
+        return self.full
+
+    def step(self, shard_batch):
+        """Rows [lo_r, hi_r) of the N x N cosine matrix as a dense float32 block in HBM."""
+        e, ctx = self.engine, self.ctx
+        self.exchange(shard_batch)
         lo, hi = self.bounds[self.rank]
         ld = (self.n_total + 3) // 4 * 4
         if self.out is None:
@@ -154,3 +162,19 @@ class ShardedPipeline:
         e.cosine_matrix(ctx, self.full, self.rnorm, self.n_total, b.ncols, b.colptr, b.post, self.rnorm,
                         row0=lo, row1=hi, out=self.out, ld=ld)
         return self.out
+
+    def step_topk(self, shard_batch, k: int, exclude_self: bool = True, cap_entries=None):
+        """Reduced output for batches whose dense matrix cannot be stored (BASELINE configs[3],
+        1 M sequences: SURVEY.md H6): the k best cosine neighbours of rows [lo_r, hi_r) against all
+        N sequences, from the exact neighbour lists.  Returns (idx uint32[rows,k], score
+        float32[rows,k], NeighborLists); idx is 0xFFFFFFFF where a row has fewer than k neighbours."""
+        e, ctx = self.engine, self.ctx
+        self.exchange(shard_batch)
+        lo, hi = self.bounds[self.rank]
+        b = self.basis
+        nb = e.gram_neighbors(ctx, self.full, self.n_total, b.ncols, b.colptr, b.post, row0=lo, row1=hi,
+                              cap_entries=cap_entries)
+        if nb.overflow_rows:
+            raise OverflowError(f"{nb.overflow_rows} rows exceed the neighbour-list capacity; raise cap_entries")
+        idx, val = e.neighbors_topk(ctx, nb, self.rnorm, self.rnorm, k, exclude_self=exclude_self)
+        return idx, val, nb

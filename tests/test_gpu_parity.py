@@ -497,6 +497,10 @@ def _sharded_rank(rank, world, port, n, tmpdir):
         block = out.download().reshape(out.shape)[: hi - lo, :n]
         np.save(os.path.join(tmpdir, f"block{rank}.npy"), block)
         np.save(os.path.join(tmpdir, f"meta{rank}.npy"), np.asarray([lo, hi, sp.full.nnz, sp.basis.ncols]))
+        # reduced output of the same exchange (BASELINE configs[3]): top-5 neighbours of the row block
+        idx, val, _ = sp.step_topk(shard, 5)
+        np.save(os.path.join(tmpdir, f"topidx{rank}.npy"), idx)
+        np.save(os.path.join(tmpdir, f"topval{rank}.npy"), val)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -524,6 +528,17 @@ def test_sharded_pipeline_two_ranks_on_one_gpu_equals_pipeline(ctx, tmp_path):
         lo, hi, nnz, ncols = np.load(tmp_path / f"meta{r}.npy")
         assert (nnz, ncols) == (ref.csr.nnz, ref.basis.ncols)
         assert (np.load(tmp_path / f"block{r}.npy") == S[lo:hi]).all()
+        # top-5 (self excluded) from the neighbour lists: the same scores as the 5 largest
+        # off-diagonal entries of the dense block (indices may differ between tied scores)
+        idx, val = np.load(tmp_path / f"topidx{r}.npy"), np.load(tmp_path / f"topval{r}.npy")
+        blk = S[lo:hi].copy()
+        blk[np.arange(hi - lo), np.arange(lo, hi)] = -1.0
+        want = -np.sort(-blk, axis=1)[:, :5]
+        have = np.where(idx == 0xFFFFFFFF, 0.0, val)
+        assert np.abs(have - np.maximum(want, 0.0)).max() <= 1e-6
+        ok = idx != 0xFFFFFFFF
+        rr = np.repeat(np.arange(hi - lo), 5).reshape(-1, 5)
+        assert np.abs(blk[rr[ok], idx[ok].astype(np.int64)] - val[ok]).max() <= 1e-6
         covered += hi - lo
     assert covered == n
 
