@@ -5,8 +5,9 @@ One "step" = one pass of the hot path over one synthetic batch that is already r
 HBM: recode + k-mer count (CSR) -> observed basis / postings -> row norms -> N x N float32
 cosine, all outputs left in HBM.  Workload at any --gpus: BASELINE.json configs[2]
 (100k x 300 aa, alphabet=red6, k=12); with N > 1 the same 100k sequences are sharded by rows
-(strong scaling): each rank vectorizes its shard, one RCCL all-gather of the CSR shards, then
-each rank computes its row block of the matrix.
+(strong scaling): each rank vectorizes its shard, the ranks build the postings of the full
+matrix together (RCCL all-to-all by k-mer owner, all-gather of the postings; snekmer_amd/dist.py),
+then each rank computes its row block of the matrix.
 
 Prints ONE JSON line on rank 0 (contract: see repo prompt / DESIGN.md section "Measurement").
 """
@@ -179,8 +180,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         launches, strip_ms = prof.get("k_cosine_write", (0, 0.0))
         strip_avg_ms = strip_ms / max(launches, 1)
-        csr = pipe.full if sharded else pipe.csr
-        nnz = csr.nnz
+        nnz = pipe.nnz_total if sharded else pipe.csr.nnz
         ld = (n_total + 3) // 4 * 4
         # algorithmic bytes of one k_cosine_write launch (DESIGN.md "Kernels"): the float32 output
         # rows it must write; the sparse neighbour lists it reads are <1% of that and not counted.
@@ -208,7 +208,8 @@ def main():
                 "residues": residues_total,
                 "nnz": nnz,
                 "basis_columns": pipe.basis.ncols,
-                "parallelism": f"row-sharded x{world}, 1 RCCL all-gather of CSR" if sharded else "single GPU",
+                "parallelism": f"row-sharded x{world}, postings built by k-mer owner (RCCL all-to-all + all-gathers)"
+                if sharded else "single GPU",
             },
             "residues_per_s": residues_total / (elapsed / args.steps),
             "stage_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},

@@ -264,6 +264,52 @@ int skm_comm_destroy(skm_ctx *ctx);
  * all contributions back to back (rank order) in d_recv.  h_bytes has nranks entries and must be
  * identical on all ranks. */
 int skm_allgatherv(skm_ctx *ctx, const void *d_send, const int64_t *h_bytes, void *d_recv);
+/* Variable-size all-to-all: the bytes for rank p are the p-th segment of d_send (segments back to
+ * back in rank order, h_send_bytes[p] long); the bytes from rank p arrive as the p-th segment of
+ * d_recv (h_recv_bytes[p] long).  h_recv_bytes[p] on this rank must equal h_send_bytes[this rank]
+ * on rank p.  Grouped ncclSend/ncclRecv; the segment a rank sends to itself is a device copy. */
+int skm_alltoallv(skm_ctx *ctx, const void *d_send, const int64_t *h_send_bytes, void *d_recv,
+                  const int64_t *h_recv_bytes);
+
+/* ---- multi-GPU basis: postings of a row-sharded count matrix, built in parallel ------------- *
+ * Sharded form of skm_basis_build for the cosine pipeline (singletons elided); there is no
+ * reference counterpart (one process per FASTA file, snekmer/rules/kmerize.smk:57-65).  A code's
+ * OWNER rank is a fixed hash of the code, so ranks agree on it without a dictionary
+ * (snekmer_amd/csrc/skm_shard.hip has the data flow; snekmer_amd/dist.py drives it). */
+#define SKM_MAX_RANKS 64
+/* Entries of a local CSR shard (n rows, first global row = row_base) grouped by owner, original
+ * order kept inside a group: d_out_codes[nnz], d_out_rowcount[nnz] = global row | count << 32;
+ * h_counts[nbuckets] = entries per owner.  Host-synchronous. */
+int skm_bucket_partition(skm_ctx *ctx, int code_bits, int nbuckets, int64_t n, int64_t nnz, const int64_t *d_rowptr,
+                         const void *d_codes, const uint32_t *d_counts, int64_t row_base, void *d_out_codes,
+                         uint64_t *d_out_rowcount, int64_t *h_counts);
+/* Owner side: from the nrecv (code, row | count << 32) entries an owner received (ascending rows
+ * within equal codes once stably sorted, which holds when sources are concatenated in rank order)
+ * build d_post[npost] (postings of k-mers found in >= 2 rows, column after column, rows ascending),
+ * d_cols_start[ncols] (index of each such column's first posting in d_post) and an open-addressing
+ * hash table code -> column: d_tab_vals[tsize] (0xFFFFFFFF = empty) / d_tab_keys[tsize], tsize a
+ * power of two >= 2 * ncols.  h_out4 = {distinct k-mers incl. single-row ones, ncols, npost, tsize}.
+ * d_cols_start / d_post need room for nrecv elements, the table for
+ * skm_bucket_table_capacity(nrecv) slots.  Host-synchronous. */
+int64_t skm_bucket_table_capacity(int64_t nrecv);
+int skm_bucket_postings(skm_ctx *ctx, int code_bits, int key_bits, int64_t nrecv, const void *d_codes,
+                        const uint64_t *d_rowcount, int64_t *h_out4, uint32_t *d_cols_start, uint64_t *d_post,
+                        void *d_tab_keys, uint32_t *d_tab_vals);
+/* Global column starts from the gathered per-owner arrays: d_starts holds the owners' d_cols_start
+ * arrays back to back (h_ncols[p] entries each); d_colptr[sum(h_ncols) + 1] gets them rebased by
+ * the owners' posting offsets (prefix sums of h_npost), closed by the total. */
+int skm_concat_colptr(skm_ctx *ctx, int nparts, const int64_t *h_ncols, const int64_t *h_npost, const uint32_t *d_starts,
+                      uint32_t *d_colptr);
+/* Column id of every entry of a CSR shard, from the gathered owner tables (back to back in owner
+ * order, h_tab_sizes[b] slots each; owner b's columns start at global id sum(h_ncols[:b])):
+ * 0xFFFFFFFF if the code is in no table (k-mer of one row). */
+int skm_colidx_lookup(skm_ctx *ctx, int code_bits, int nbuckets, int64_t nnz, const void *d_codes,
+                      const int64_t *h_tab_sizes, const int64_t *h_ncols, const void *d_tab_keys,
+                      const uint32_t *d_tab_vals, uint32_t *d_colidx);
+/* d_rowptr[n_total + 1] of an n_total-row matrix that is empty except rows [lo, lo + nloc), which
+ * are the local shard (d_local[nloc + 1]): lets skm_cosine_csr / skm_gram_neighbors run on a shard
+ * with global row numbers. */
+int skm_embed_rowptr(skm_ctx *ctx, int64_t n_total, int64_t lo, int64_t nloc, const int64_t *d_local, int64_t *d_rowptr);
 
 #ifdef __cplusplus
 }

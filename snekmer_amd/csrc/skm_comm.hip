@@ -20,6 +20,8 @@ typedef int (*fn_init_rank)(void **, int, nccl_uid, int);
 typedef int (*fn_destroy)(void *);
 typedef int (*fn_bcast)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef int (*fn_allgather)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*fn_send)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_recv)(void *, size_t, int, int, void *, hipStream_t);
 typedef int (*fn_group)(void);
 typedef const char *(*fn_errstr)(int);
 
@@ -30,6 +32,8 @@ struct rccl_api {
     fn_destroy destroy = nullptr;
     fn_bcast bcast = nullptr;
     fn_allgather allgather = nullptr;
+    fn_send send = nullptr;
+    fn_recv recv = nullptr;
     fn_group group_start = nullptr, group_end = nullptr;
     fn_errstr errstr = nullptr;
 };
@@ -55,10 +59,12 @@ int load_rccl()
     g_rccl.destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy");
     g_rccl.bcast = (fn_bcast)dlsym(lib, "ncclBroadcast");
     g_rccl.allgather = (fn_allgather)dlsym(lib, "ncclAllGather");
+    g_rccl.send = (fn_send)dlsym(lib, "ncclSend");
+    g_rccl.recv = (fn_recv)dlsym(lib, "ncclRecv");
     g_rccl.group_start = (fn_group)dlsym(lib, "ncclGroupStart");
     g_rccl.group_end = (fn_group)dlsym(lib, "ncclGroupEnd");
     g_rccl.errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
-    if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.bcast || !g_rccl.allgather || !g_rccl.group_start ||
+    if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.bcast || !g_rccl.allgather || !g_rccl.send || !g_rccl.recv || !g_rccl.group_start ||
         !g_rccl.group_end) {
         skm_set_error("librccl lacks a required symbol");
         dlclose(lib);
@@ -156,5 +162,51 @@ extern "C" int skm_allgatherv(skm_ctx *ctx, const void *d_send, const int64_t *h
                                    hipMemcpyDeviceToDevice, ctx->stream));
         offset += h_bytes[r];
     }
+    return SKM_OK;
+}
+
+// Variable-size all-to-all as one group of point-to-point transfers (what RCCL's own all-to-all
+// does); xGMI is point to point, so every pair uses its own link.
+extern "C" int skm_alltoallv(skm_ctx *ctx, const void *d_send, const int64_t *h_send_bytes, void *d_recv,
+                             const int64_t *h_recv_bytes)
+{
+    SKM_REQUIRE(ctx && h_send_bytes && h_recv_bytes, SKM_E_BADARG, "skm_alltoallv: bad argument");
+    SKM_HIP(hipSetDevice(ctx->device));
+    const int nr = ctx->comm ? ctx->nranks : 1, me = ctx->comm ? ctx->rank : 0;
+    SKM_REQUIRE(ctx->comm || ctx->nranks == 1, SKM_E_COMM, "skm_alltoallv: communicator not initialised");
+    int64_t soff = 0, roff = 0, my_soff = 0, my_roff = 0;
+    for (int p = 0; p < nr; ++p) {
+        SKM_REQUIRE(h_send_bytes[p] >= 0 && h_recv_bytes[p] >= 0, SKM_E_BADARG, "skm_alltoallv: negative size for rank %d", p);
+        if (p == me) {
+            my_soff = soff;
+            my_roff = roff;
+        }
+        soff += h_send_bytes[p];
+        roff += h_recv_bytes[p];
+    }
+    SKM_REQUIRE(h_send_bytes[me] == h_recv_bytes[me], SKM_E_BADARG, "skm_alltoallv: self segment sizes differ");
+    SKM_REQUIRE((soff == 0 || d_send) && (roff == 0 || d_recv), SKM_E_BADARG, "skm_alltoallv: null buffer");
+    SKM_PROF(ctx, "rccl_alltoallv");
+    if (h_send_bytes[me] > 0)
+        SKM_HIP(hipMemcpyAsync((uint8_t *)d_recv + my_roff, (const uint8_t *)d_send + my_soff, (size_t)h_send_bytes[me],
+                               hipMemcpyDeviceToDevice, ctx->stream));
+    if (nr == 1)
+        return SKM_OK;
+    SKM_NCCL(g_rccl.group_start());
+    soff = roff = 0;
+    int status = 0;
+    for (int p = 0; p < nr && status == 0; ++p) {
+        if (p != me) {
+            if (h_send_bytes[p] > 0)
+                status = g_rccl.send((const uint8_t *)d_send + soff, (size_t)h_send_bytes[p], NCCL_INT8, p, ctx->comm, ctx->stream);
+            if (status == 0 && h_recv_bytes[p] > 0)
+                status = g_rccl.recv((uint8_t *)d_recv + roff, (size_t)h_recv_bytes[p], NCCL_INT8, p, ctx->comm, ctx->stream);
+        }
+        soff += h_send_bytes[p];
+        roff += h_recv_bytes[p];
+    }
+    const int end_status = g_rccl.group_end();  // always close the group, also after a failed call
+    SKM_NCCL(status);
+    SKM_NCCL(end_status);
     return SKM_OK;
 }

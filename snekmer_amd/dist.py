@@ -7,8 +7,18 @@ column identity without exchanging a dictionary; the single exchange is an all-g
 per-shard CSR rows, after which rank r computes rows [lo_r, hi_r) of the
 similarity matrix against all N columns.
 
+Two forms of the exchange (`ShardedPipeline(basis=...)`):
+
+* ``"distributed"`` (default): the postings are built in parallel.  Every rank groups its entries
+  by OWNER rank (a fixed hash of the k-mer code), one all-to-all moves them, each owner sorts its
+  share (1/G of the entries) and builds the postings of its k-mers, and all-gathers of the
+  postings and of the owners' column tables give every rank the full column-major copy; a rank
+  then finds the columns of its own rows by binary search.  No rank ever sorts the whole matrix.
+* ``"replicated"``: all-gather of the raw CSR shards, then every rank builds the basis of the full
+  matrix itself (simple; the replicated sort is the Amdahl term of strong scaling).
+
 `plan_*` functions are pure host logic (covered by world_size-2 gloo tests on CPU);
-`RcclExchange` is the device implementation over skm_allgatherv.
+`RcclExchange` is the device implementation over skm_allgatherv / skm_alltoallv.
 """
 import ctypes as C
 from typing import List, Sequence, Tuple
@@ -53,6 +63,44 @@ def plan_allgather(nnz_per_rank: Sequence[int], rows_per_rank: Sequence[int], co
     }
 
 
+def plan_alltoall(counts: np.ndarray, rank: int, itemsize: int):
+    """Byte sizes of one all-to-all from the gathered [src, dst] matrix of entry counts:
+    (send_bytes[dst], recv_bytes[src]) for `rank`."""
+    counts = np.asarray(counts, dtype=np.int64)
+    return counts[rank, :] * itemsize, counts[:, rank] * itemsize
+
+
+def owner_host(codes: np.ndarray, world: int) -> np.ndarray:
+    """Host statement of the device's bucket_of (snekmer_amd/csrc/skm_shard.hip): owner rank of
+    every k-mer code.  uint32 codes and uint64 codes hash differently, as on the device."""
+    codes = np.asarray(codes)
+    if codes.dtype == np.uint64:
+        m = codes * np.uint64(0x9E3779B97F4A7C15)
+        x = ((m >> np.uint64(32)) ^ (m & np.uint64(0xFFFFFFFF))).astype(np.uint64)
+    else:
+        x = codes.astype(np.uint64)
+    mask = np.uint64(0xFFFFFFFF)
+    h = (x * np.uint64(0x9E3779B1)) & mask
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x85EBCA77)) & mask
+    return ((h * np.uint64(world)) >> np.uint64(32)).astype(np.int64)
+
+
+def postings_host(codes: np.ndarray, rowcount: np.ndarray):
+    """Host statement of skm_bucket_postings: from the (code, row | count << 32) entries an owner
+    received -> (distinct k-mers, codes of its shared columns ascending, start of every shared
+    column in `post`, post)."""
+    order = np.argsort(codes, kind="stable")
+    sk, rc = codes[order], rowcount[order]
+    head = np.r_[True, sk[1:] != sk[:-1]] if len(sk) else np.zeros(0, bool)
+    more = np.r_[sk[1:] == sk[:-1], False] if len(sk) else np.zeros(0, bool)
+    shared = ~head | more
+    post = rc[shared]
+    col_head = head & more
+    starts = np.cumsum(shared)[col_head] - 1
+    return int(head.sum()), sk[col_head], starts.astype(np.uint32), post
+
+
 def concat_rowptr_host(local_rowptrs: Sequence[np.ndarray]) -> np.ndarray:
     """Host statement of skm_csr_concat_rowptr (used by the CPU tests to check the plan)."""
     out, base = [], 0
@@ -70,8 +118,7 @@ class RcclExchange:
         self.ctx, self.world, self.rank = ctx, world, rank
         buf = np.frombuffer(unique_id, dtype=np.uint8).copy()
         ctx.call("skm_comm_init", world, rank, buf.ctypes.data_as(_p))
-        self._sizes = ctx.empty(world, np.int64)
-        self._mine = ctx.empty(1, np.int64)
+        self._small = {}  # (send, recv) device buffers of allgather_i64, by vector length
 
     @staticmethod
     def new_unique_id() -> bytes:
@@ -85,48 +132,154 @@ class RcclExchange:
     def allgather_i64(self, values) -> np.ndarray:
         """Gather a small fixed-length int64 vector from every rank -> [world, len]."""
         vals = np.atleast_1d(np.asarray(values, dtype=np.int64))
-        if self._mine.size != vals.size:
-            self._mine = self.ctx.empty(vals.size, np.int64)
-            self._sizes = self.ctx.empty(self.world * vals.size, np.int64)
-        self._mine.upload(vals)
+        if vals.size not in self._small:
+            self._small[vals.size] = (self.ctx.empty(vals.size, np.int64), self.ctx.empty(self.world * vals.size, np.int64))
+        mine, gathered = self._small[vals.size]
+        mine.upload(vals)
         sizes = np.full(self.world, 8 * vals.size, dtype=np.int64)
-        self.ctx.call("skm_allgatherv", _p(self._mine.ptr), sizes.ctypes.data_as(_p), _p(self._sizes.ptr))
-        return self._sizes.download(self.world * vals.size).reshape(self.world, vals.size)
+        self.ctx.call("skm_allgatherv", _p(mine.ptr), sizes.ctypes.data_as(_p), _p(gathered.ptr))
+        return gathered.download(self.world * vals.size).reshape(self.world, vals.size)
 
     def allgatherv(self, d_send, nbytes_per_rank: Sequence[int], d_recv):
         sizes = np.asarray(nbytes_per_rank, dtype=np.int64)
         self.ctx.call("skm_allgatherv", _p(d_send.ptr), sizes.ctypes.data_as(_p), _p(d_recv.ptr))
 
+    def alltoallv(self, d_send, send_bytes: Sequence[int], d_recv, recv_bytes: Sequence[int]):
+        sb = np.ascontiguousarray(send_bytes, dtype=np.int64)
+        rb = np.ascontiguousarray(recv_bytes, dtype=np.int64)
+        self.ctx.call("skm_alltoallv", _p(d_send.ptr), sb.ctypes.data_as(_p), _p(d_recv.ptr), rb.ctypes.data_as(_p))
+
+
+class _ColumnMajor:
+    """Postings of the full matrix as the cosine kernels take them (colptr/post), plus the number of
+    distinct k-mers (`ncols`, single-row ones included) for reporting."""
+
+    def __init__(self):
+        self.ncols = 0          # distinct k-mers of the whole batch
+        self.ncols_shared = 0   # those found in >= 2 rows: the columns of colptr/post
+        self.colptr = self.post = None
+
 
 class ShardedPipeline:
-    """vectorize the local shard, all-gather CSR, then cosine for the local row block."""
+    """vectorize the local shard, exchange, then cosine (or top-k) for the local row block."""
 
-    def __init__(self, ctx, lut, k: int, exchange, bounds: Sequence[Tuple[int, int]], total_residues: int):
+    def __init__(self, ctx, lut, k: int, exchange, bounds: Sequence[Tuple[int, int]], total_residues: int,
+                 basis: str = "distributed"):
         from . import engine
 
+        if basis not in ("distributed", "replicated"):
+            raise ValueError("basis must be 'distributed' or 'replicated'")
         self.engine = engine
         self.ctx, self.lut, self.k, self.ex = ctx, lut, k, exchange
+        self.mode = basis
         self.bounds = list(bounds)
         self.rank = exchange.rank
+        self.world = len(self.bounds)
         self.n_total = self.bounds[-1][1]
         self.rows = [hi - lo for lo, hi in self.bounds]
         bits = lut.code_bits(k)
+        self.code_bits = bits
         self.code_dtype = np.uint32 if bits == 32 else np.uint64
-        cap = total_residues + 1
         self.local = None
-        self.bytes_local = ctx.empty(cap, np.uint8)   # counts of the local shard, one byte each
-        self.bytes_full = ctx.empty(cap, np.uint8)
-        self.g_rowptr_local = ctx.empty(self.n_total + len(self.bounds), np.int64)
-        full = engine.CountsCSR(ctx, self.n_total, 0, bits, ctx.empty(self.n_total + 1, np.int64),
-                                ctx.empty(cap, self.code_dtype), ctx.empty(cap, np.uint32), None)
-        self.full = full
         self.basis = None
         self.rnorm = None
         self.out = None
+        self.nnz_total = 0
+        self.x = None  # the CSR view the cosine kernels read rows [lo, hi) from
+        if basis == "replicated":
+            cap = total_residues + 1
+            self.bytes_local = ctx.empty(cap, np.uint8)   # counts of the local shard, one byte each
+            self.bytes_full = ctx.empty(cap, np.uint8)
+            self.g_rowptr_local = ctx.empty(self.n_total + len(self.bounds), np.int64)
+            self.full = engine.CountsCSR(ctx, self.n_total, 0, bits, ctx.empty(self.n_total + 1, np.int64),
+                                         ctx.empty(cap, self.code_dtype), ctx.empty(cap, np.uint32), None)
+        else:
+            self.full = None
+            self._buf = {}
+            self.rowptr_g = ctx.empty(self.n_total + 1, np.int64)
+            self.rnorm = ctx.empty(self.n_total + 4, np.float32)
+
+    # ------------------------------------------------------------------ buffers (distributed mode)
+    def _need(self, name: str, size: int, dtype):
+        cur = self._buf.get(name)
+        size = max(int(size), 1)
+        if cur is None or cur.size < size or cur.dtype != np.dtype(dtype):
+            self._buf[name] = None
+            cur = self._buf[name] = self.ctx.empty(size + size // 8, dtype)  # head-room: sizes drift between steps
+        return cur
 
     def exchange(self, shard_batch):
-        """vectorize the local shard and all-gather the CSR shards: afterwards `self.full` (all N
-        rows), `self.basis` (postings of the full matrix) and `self.rnorm` are set on every rank."""
+        """vectorize the local shard and exchange: afterwards `self.x` (rows [lo, hi) with global row
+        numbers and column ids), `self.basis` (colptr/post of the full matrix) and `self.rnorm` (all N
+        rows) are set on every rank."""
+        if self.mode == "replicated":
+            return self._exchange_replicated(shard_batch)
+        return self._exchange_distributed(shard_batch)
+
+    def _exchange_distributed(self, shard_batch):
+        e, ctx, ex, G, me = self.engine, self.ctx, self.ex, self.world, self.rank
+        lo, hi = self.bounds[me]
+        nloc = hi - lo
+        cb = np.dtype(self.code_dtype).itemsize
+        self.local = loc = e.count_csr(ctx, shard_batch, self.lut, self.k, out=self.local)
+        # 1. entries grouped by owner rank
+        p_codes = self._need("p_codes", loc.nnz, self.code_dtype)
+        p_rc = self._need("p_rc", loc.nnz, np.uint64)
+        counts = np.zeros(G, dtype=np.int64)
+        ctx.call("skm_bucket_partition", self.code_bits, G, _i64(loc.n), _i64(loc.nnz), _p(loc.rowptr.ptr),
+                 _p(loc.codes.ptr), _p(loc.counts.ptr), _i64(lo), _p(p_codes.ptr), _p(p_rc.ptr), counts.ctypes.data_as(_p))
+        cmat = ex.allgather_i64(counts)  # [src, dst]
+        self.nnz_total = int(cmat.sum())
+        nrecv = int(cmat[:, me].sum())
+        # 2. all-to-all: every owner receives its k-mers' entries from all ranks, sources in rank order
+        r_codes = self._need("r_codes", nrecv, self.code_dtype)
+        r_rc = self._need("r_rc", nrecv, np.uint64)
+        sb, rb = plan_alltoall(cmat, me, cb)
+        ex.alltoallv(p_codes, sb, r_codes, rb)
+        sb, rb = plan_alltoall(cmat, me, 8)
+        ex.alltoallv(p_rc, sb, r_rc, rb)
+        # 3. owner: sort its share by code, compact postings, column starts, hash table code -> column
+        o_start = self._need("o_start", nrecv, np.uint32)
+        o_post = self._need("o_post", nrecv, np.uint64)
+        tcap = int(ctx.lib.skm_bucket_table_capacity(nrecv))
+        o_tkeys = self._need("o_tkeys", tcap, self.code_dtype)
+        o_tvals = self._need("o_tvals", tcap, np.uint32)
+        out4 = np.zeros(4, dtype=np.int64)
+        ctx.call("skm_bucket_postings", self.code_bits, e.key_bits(self.lut.nsym, self.k), _i64(nrecv), _p(r_codes.ptr),
+                 _p(r_rc.ptr), out4.ctypes.data_as(_p), _p(o_start.ptr), _p(o_post.ptr), _p(o_tkeys.ptr), _p(o_tvals.ptr))
+        meta = ex.allgather_i64(out4)  # [rank, (distinct, shared columns, postings, table slots)]
+        ncols, npost, tsize = meta[:, 1].copy(), meta[:, 2].copy(), meta[:, 3].copy()
+        tot_cols, tot_post, tot_slots = int(ncols.sum()), int(npost.sum()), int(tsize.sum())
+        # 4. every rank gets all postings, column starts and tables
+        b = self.basis or _ColumnMajor()
+        b.ncols, b.ncols_shared = int(meta[:, 0].sum()), tot_cols
+        b.post = self._need("post", tot_post, np.uint64)
+        b.colptr = self._need("colptr", tot_cols + 1, np.uint32)
+        a_start = self._need("a_start", tot_cols, np.uint32)
+        a_tkeys = self._need("a_tkeys", tot_slots, self.code_dtype)
+        a_tvals = self._need("a_tvals", tot_slots, np.uint32)
+        ex.allgatherv(o_post, npost * 8, b.post)
+        ex.allgatherv(o_start, ncols * 4, a_start)
+        ex.allgatherv(o_tkeys, tsize * cb, a_tkeys)
+        ex.allgatherv(o_tvals, tsize * 4, a_tvals)
+        ctx.call("skm_concat_colptr", G, ncols.ctypes.data_as(_p), npost.ctypes.data_as(_p), _p(a_start.ptr),
+                 _p(b.colptr.ptr))
+        self.basis = b
+        # 5. columns of the local rows; the shard as rows [lo, hi) of an N-row matrix
+        colidx = self._need("colidx", loc.nnz, np.uint32)
+        ctx.call("skm_colidx_lookup", self.code_bits, G, _i64(loc.nnz), _p(loc.codes.ptr), tsize.ctypes.data_as(_p),
+                 ncols.ctypes.data_as(_p), _p(a_tkeys.ptr), _p(a_tvals.ptr), _p(colidx.ptr))
+        ctx.call("skm_embed_rowptr", _i64(self.n_total), _i64(lo), _i64(nloc), _p(loc.rowptr.ptr), _p(self.rowptr_g.ptr))
+        # 6. norms of all rows
+        rn = self._need("rn_local", nloc + 4, np.float32)
+        e.row_norms(ctx, nloc, loc.rowptr, loc.counts, out=rn)
+        ex.allgatherv(rn, np.asarray(self.rows, dtype=np.int64) * 4, self.rnorm)
+        x = e.CountsCSR(ctx, self.n_total, loc.nnz, self.code_bits, self.rowptr_g, loc.codes, loc.counts, None)
+        x.colidx = colidx
+        self.x = x
+        return x
+
+    def _exchange_replicated(self, shard_batch):
         e, ctx = self.engine, self.ctx
         self.local = e.count_csr(ctx, shard_batch, self.lut, self.k, out=self.local)
         meta = self.ex.allgather_i64([self.local.nnz, e.csr_max_count(ctx, self.local)])
@@ -145,9 +298,10 @@ class ShardedPipeline:
         h_nnz = np.asarray(nnz, dtype=np.int64)
         ctx.call("skm_csr_concat_rowptr", len(self.rows), h_rows.ctypes.data_as(_p), h_nnz.ctypes.data_as(_p),
                  _p(self.g_rowptr_local.ptr), _p(self.full.rowptr.ptr))
-        self.full.nnz = int(h_nnz.sum())
+        self.full.nnz = self.nnz_total = int(h_nnz.sum())
         self.basis = e.build_basis(ctx, self.full, self.lut.nsym, self.k, out=self.basis, elide_singletons=True)
         self.rnorm = e.row_norms(ctx, self.n_total, self.full.rowptr, self.full.counts, out=self.rnorm)
+        self.x = self.full
         return self.full
 
     def step(self, shard_batch):
@@ -159,8 +313,8 @@ class ShardedPipeline:
         if self.out is None:
             self.out = ctx.empty((max(hi - lo, 1), ld), np.float32)
         b = self.basis
-        e.cosine_matrix(ctx, self.full, self.rnorm, self.n_total, b.ncols, b.colptr, b.post, self.rnorm,
-                        row0=lo, row1=hi, out=self.out, ld=ld)
+        e.cosine_matrix(ctx, self.x, self.rnorm, self.n_total, getattr(b, "ncols_shared", b.ncols), b.colptr, b.post,
+                        self.rnorm, row0=lo, row1=hi, out=self.out, ld=ld)
         return self.out
 
     def step_topk(self, shard_batch, k: int, exclude_self: bool = True, cap_entries=None):
@@ -172,8 +326,10 @@ class ShardedPipeline:
         self.exchange(shard_batch)
         lo, hi = self.bounds[self.rank]
         b = self.basis
-        nb = e.gram_neighbors(ctx, self.full, self.n_total, b.ncols, b.colptr, b.post, row0=lo, row1=hi,
-                              cap_entries=cap_entries)
+        if cap_entries is None:
+            cap_entries = 16 * max(self.nnz_total // max(self.world, 1), 1) + (1 << 20)
+        nb = e.gram_neighbors(ctx, self.x, self.n_total, getattr(b, "ncols_shared", b.ncols), b.colptr, b.post,
+                              row0=lo, row1=hi, cap_entries=cap_entries)
         if nb.overflow_rows:
             raise OverflowError(f"{nb.overflow_rows} rows exceed the neighbour-list capacity; raise cap_entries")
         idx, val = e.neighbors_topk(ctx, nb, self.rnorm, self.rnorm, k, exclude_self=exclude_self)

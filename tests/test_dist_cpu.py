@@ -94,6 +94,134 @@ def _worker(rank, world, port, outdir):
         dist.destroy_process_group()
 
 
+def _worker_owner(rank, world, port, outdir):
+    """The distributed-basis exchange (ShardedPipeline(basis="distributed")) restated on the host:
+    entries grouped by owner, all-to-all sized by plan_alltoall, owner postings (postings_host),
+    all-gather, local column lookup, row block of the cosine matrix from the postings."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from oracle import c_oracle
+    from snekmer_amd import alphabet as A
+    from snekmer_amd.dist import owner_host, plan_alltoall, postings_host, shard_bounds
+    from snekmer_amd.synth import synth_families
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if "red6" not in A.ALPHABETS:
+            A.register_alphabet("red6", A.RED6_GROUPS)
+        lut = A.build_lut("red6")
+        k, n = 12, 211
+        res, off, _ = synth_families(n, 300, family=25, seed=98)
+        bounds = shard_bounds(n, world)
+        lo, hi = bounds[rank]
+        rp, codes, counts, _ = c_oracle.count_csr(lut.rank, lut.nsym, k, res[off[lo]:off[hi]], off[lo:hi + 1] - off[lo])
+        codes = codes.astype(np.uint32)
+        rows = np.repeat(np.arange(lo, hi, dtype=np.uint64), np.diff(rp))
+        rowcount = rows | (counts.astype(np.uint64) << np.uint64(32))
+
+        def allgather_obj(x):
+            out = [None] * world
+            dist.all_gather_object(out, x)
+            return out
+
+        def alltoallv(buf: np.ndarray, send_bytes, recv_bytes):
+            raw = np.frombuffer(buf.tobytes(), dtype=np.uint8)
+            so = np.concatenate([[0], np.cumsum(send_bytes)])
+            outs = [torch.zeros(int(b), dtype=torch.uint8) for b in recv_bytes]
+            reqs = []
+            for p in range(world):
+                seg = torch.from_numpy(raw[so[p]:so[p + 1]].copy())
+                if p == rank:
+                    outs[p].copy_(seg)
+                    continue
+                if seg.numel():
+                    reqs.append(dist.isend(seg, dst=p))
+                if outs[p].numel():
+                    reqs.append(dist.irecv(outs[p], src=p))
+            for r in reqs:
+                r.wait()
+            return np.concatenate([o.numpy() for o in outs]) if sum(recv_bytes) else np.zeros(0, np.uint8)
+
+        # 1. group by owner (stable), 2. all-to-all
+        own = owner_host(codes, world)
+        order = np.argsort(own, kind="stable")
+        cmat = np.asarray(allgather_obj(np.bincount(own, minlength=world)))
+        sb, rb = plan_alltoall(cmat, rank, 4)
+        r_codes = alltoallv(codes[order], sb, rb).view(np.uint32)
+        sb, rb = plan_alltoall(cmat, rank, 8)
+        r_rc = alltoallv(rowcount[order], sb, rb).view(np.uint64)
+        assert len(r_codes) == cmat[:, rank].sum() and (owner_host(r_codes, world) == rank).all()
+        # 3. owner postings, 4. all-gather
+        distinct, o_code, o_start, o_post = postings_host(r_codes, r_rc)
+        parts = allgather_obj((distinct, o_code, o_start, o_post))
+        ncols_total = sum(p[0] for p in parts)
+        post = np.concatenate([p[3] for p in parts])
+        base = np.cumsum([0] + [len(p[3]) for p in parts])
+        colptr = np.concatenate([p[2].astype(np.int64) + base[i] for i, p in enumerate(parts)] + [[base[-1]]])
+        table = {}
+        for p in parts:
+            for c in p[1]:
+                table[int(c)] = len(table)
+        # 5. own rows against the postings; norms all-gathered
+        norms = np.concatenate(allgather_obj(np.sqrt(np.add.reduceat(counts.astype(np.float64) ** 2, rp[:-1]))
+                                             if len(counts) else np.zeros(hi - lo)))
+        inv = np.where(norms > 0, 1.0 / np.where(norms > 0, norms, 1.0), 1.0)
+        block = np.zeros((hi - lo, n))
+        for i in range(lo, hi):
+            for e in range(rp[i - lo], rp[i - lo + 1]):
+                c = table.get(int(codes[e]))
+                v = float(counts[e])
+                if c is None:
+                    block[i - lo, i] += v * v
+                else:
+                    seg = post[colptr[c]:colptr[c + 1]]
+                    js = (seg & np.uint64(0xFFFFFFFF)).astype(np.int64)
+                    assert (np.diff(js) > 0).all()  # rows ascending within a column
+                    block[i - lo, js] += v * (seg >> np.uint64(32)).astype(np.float64)
+        block *= inv[lo:hi, None] * inv[None, :]
+        np.save(os.path.join(outdir, f"oblock{rank}.npy"), block)
+        dist.barrier()
+        if rank == 0:
+            full = np.concatenate([np.load(os.path.join(outdir, f"oblock{r}.npy")) for r in range(world)])
+            f_rp, f_codes, f_counts, f_first = c_oracle.count_csr(lut.rank, lut.nsym, k, res, off)
+            fb, _, _, _, fcol = c_oracle.basis(f_rp, f_codes, f_counts, f_first)
+            assert ncols_total == len(fb)
+            ref = c_oracle.cosine_rows(f_rp, fcol, f_counts, len(fb), np.arange(n))
+            assert full.shape == ref.shape and np.abs(full - ref).max() < 1e-12
+            open(os.path.join(outdir, "ok_owner"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_owner_exchange_plan(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker_owner, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert (tmp_path / "ok_owner").exists()
+
+
+def test_plan_alltoall_and_owner_hash():
+    from snekmer_amd.dist import owner_host, plan_alltoall
+
+    cmat = np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]])
+    sb, rb = plan_alltoall(cmat, 1, 4)
+    assert sb.tolist() == [16, 20, 24] and rb.tolist() == [8, 20, 32]
+    rng = np.random.default_rng(3)
+    for dt, hi in ((np.uint32, 6**12), (np.uint64, 7**12)):
+        codes = rng.integers(0, hi, size=200000).astype(dt)
+        for w in (1, 2, 3, 8):
+            o = owner_host(codes, w)
+            assert o.min() >= 0 and o.max() < w
+            assert np.bincount(o, minlength=w).min() > 0.9 * len(codes) / w  # balanced
+    # neighbouring codes (low-complexity k-mers) spread over owners
+    assert len(set(owner_host(np.arange(64, dtype=np.uint32), 8).tolist())) == 8
+
+
 def test_two_rank_csr_exchange_plan(tmp_path):
     import torch.multiprocessing as mp
 

@@ -412,9 +412,11 @@ def test_dense_pipeline_matches_sparse_pipeline_and_oracle(ctx, name, k):
 
 
 # ------------------------------------------------------------------ RCCL path, one rank
-def test_sharded_pipeline_over_rccl_single_rank_equals_pipeline(ctx):
-    """The multi-GPU step (count shard -> RCCL all-gather of CSR -> concat rowptr -> basis ->
-    row-block cosine) run with a one-rank communicator must reproduce the single-GPU pipeline."""
+@pytest.mark.parametrize("mode", ["distributed", "replicated"])
+def test_sharded_pipeline_over_rccl_single_rank_equals_pipeline(ctx, mode):
+    """The multi-GPU step (count shard -> exchange over RCCL: all-to-all + all-gathers of the
+    distributed basis, or the raw CSR all-gather of the replicated one -> row-block cosine) run
+    with a one-rank communicator must reproduce the single-GPU pipeline."""
     from snekmer_amd import alphabet as A
     from snekmer_amd import engine
     from snekmer_amd.dist import RcclExchange, ShardedPipeline, shard_bounds
@@ -429,15 +431,73 @@ def test_sharded_pipeline_over_rccl_single_rank_equals_pipeline(ctx):
     S = S.download().reshape(S.shape)[:n, :n]
     ex = RcclExchange(ctx, 1, 0, RcclExchange.new_unique_id())
     try:
-        sp = ShardedPipeline(ctx, lut, 12, ex, shard_bounds(n, 1), int(off[-1]))
+        sp = ShardedPipeline(ctx, lut, 12, ex, shard_bounds(n, 1), int(off[-1]), basis=mode)
         out = sp.step(batch)
         T = out.download().reshape(out.shape)[:n, :n]
         assert (T == S).all()
-        assert sp.full.nnz == ref.csr.nnz and sp.basis.ncols == ref.basis.ncols
+        assert sp.nnz_total == ref.csr.nnz and sp.basis.ncols == ref.basis.ncols
         out = sp.step(batch)  # buffers are reused on the second step
         assert (out.download().reshape(out.shape)[:n, :n] == S).all()
     finally:
         ctx.call("skm_comm_destroy")
+
+
+@pytest.mark.parametrize("name", ["red6", "standard"])
+def test_owner_partition_postings_lookup_match_host_statements(ctx, name):
+    """The C-ABI pieces of the distributed basis against their host statements in dist.py
+    (owner_host = bucket_of, postings_host = skm_bucket_postings), uint32 and uint64 codes."""
+    import ctypes as C
+
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.dist import owner_host, postings_host
+    from snekmer_amd.synth import synth_families
+
+    lut = A.build_lut(name)
+    k, nb, base = 12, 3, 1000
+    res, off, _ = synth_families(400, 300, family=20, seed=5)
+    csr = engine.count_csr(ctx, engine.SeqBatch(ctx, res, off), lut, k)
+    rowptr, codes, counts, _ = csr.host()
+    dt, nnz = csr.code_dtype, csr.nnz
+    p = C.c_void_p
+    d_codes, d_rc = ctx.empty(nnz, dt), ctx.empty(nnz, np.uint64)
+    h_counts = np.zeros(nb, dtype=np.int64)
+    ctx.call("skm_bucket_partition", csr.code_bits, nb, C.c_int64(csr.n), C.c_int64(nnz), p(csr.rowptr.ptr), p(csr.codes.ptr),
+             p(csr.counts.ptr), C.c_int64(base), p(d_codes.ptr), p(d_rc.ptr), h_counts.ctypes.data_as(p))
+    own = owner_host(codes, nb)
+    order = np.argsort(own, kind="stable")
+    rows = np.repeat(np.arange(csr.n, dtype=np.uint64) + np.uint64(base), np.diff(rowptr))
+    rc = rows | (counts.astype(np.uint64) << np.uint64(32))
+    assert (h_counts == np.bincount(own, minlength=nb)).all()
+    assert (d_codes.download(nnz) == codes[order]).all() and (d_rc.download(nnz) == rc[order]).all()
+
+    # owner 1's share -> postings, column starts, table; looked up for every entry of the shard
+    seg = slice(int(h_counts[0]), int(h_counts[0] + h_counts[1]))
+    r_codes, r_rc = ctx.to_device(np.ascontiguousarray(codes[order][seg])), ctx.to_device(np.ascontiguousarray(rc[order][seg]))
+    nrecv = int(h_counts[1])
+    cap = int(ctx.lib.skm_bucket_table_capacity(nrecv))
+    o_start, o_post = ctx.empty(nrecv, np.uint32), ctx.empty(nrecv, np.uint64)
+    t_keys, t_vals = ctx.empty(cap, dt), ctx.empty(cap, np.uint32)
+    out4 = np.zeros(4, dtype=np.int64)
+    ctx.call("skm_bucket_postings", csr.code_bits, 0, C.c_int64(nrecv), p(r_codes.ptr), p(r_rc.ptr), out4.ctypes.data_as(p),
+             p(o_start.ptr), p(o_post.ptr), p(t_keys.ptr), p(t_vals.ptr))
+    distinct, h_code, h_start, h_post = postings_host(codes[order][seg], rc[order][seg])
+    assert out4[:3].tolist() == [distinct, len(h_code), len(h_post)] and out4[3] >= 2 * len(h_code)
+    assert (o_start.download(len(h_code)) == h_start).all() and (o_post.download(len(h_post)) == h_post).all()
+    # the other owners have empty tables here: only owner 1's k-mers resolve
+    tsize = np.array([2, out4[3], 2], dtype=np.int64)
+    ncols = np.array([0, len(h_code), 0], dtype=np.int64)
+    a_keys, a_vals = ctx.empty(int(tsize.sum()), dt), ctx.empty(int(tsize.sum()), np.uint32)
+    ctx.call("skm_memset", p(a_vals.ptr), 0xFF, C.c_size_t(4 * int(tsize.sum())))
+    ctx.call("skm_memcpy_d2d", p(a_keys.ptr + 2 * np.dtype(dt).itemsize), p(t_keys.ptr), C.c_size_t(int(out4[3]) * np.dtype(dt).itemsize))
+    ctx.call("skm_memcpy_d2d", p(a_vals.ptr + 8), p(t_vals.ptr), C.c_size_t(int(out4[3]) * 4))
+    colidx = ctx.empty(nnz, np.uint32)
+    ctx.call("skm_colidx_lookup", csr.code_bits, nb, C.c_int64(nnz), p(csr.codes.ptr), tsize.ctypes.data_as(p),
+             ncols.ctypes.data_as(p), p(a_keys.ptr), p(a_vals.ptr), p(colidx.ptr))
+    pos = np.searchsorted(h_code, codes)
+    hit = (pos < len(h_code)) & (h_code[np.minimum(pos, len(h_code) - 1)] == codes) if len(h_code) else np.zeros(nnz, bool)
+    want = np.where(hit, pos, 0xFFFFFFFF).astype(np.uint32)
+    assert (colidx.download(nnz) == want).all()
 
 
 # ------------------------------------------------------------------ sharded step, two ranks on one GPU
@@ -473,7 +533,41 @@ class _HostStagedExchange:
             self.ctx._h2d(d_recv.ptr, np.ascontiguousarray(packed))
 
 
-def _sharded_rank(rank, world, port, n, tmpdir):
+    def alltoallv(self, d_send, send_bytes, d_recv, recv_bytes):
+        import torch
+        import torch.distributed as dist
+
+        sb, rb = [int(x) for x in send_bytes], [int(x) for x in recv_bytes]
+        send = np.zeros(max(sum(sb), 1), dtype=np.uint8)
+        if sum(sb):
+            self.ctx._d2h(send[: sum(sb)], d_send.ptr)
+        so = np.concatenate([[0], np.cumsum(sb)])
+        ins = [torch.from_numpy(send[so[p]:so[p + 1]].copy()) for p in range(self.world)]
+        outs = [torch.zeros(rb[p], dtype=torch.uint8) for p in range(self.world)]
+        self._p2p_all_to_all(outs, ins)
+        packed = np.concatenate([o.numpy() for o in outs]) if sum(rb) else np.zeros(0, np.uint8)
+        if packed.size:
+            self.ctx._h2d(d_recv.ptr, np.ascontiguousarray(packed))
+
+    def _p2p_all_to_all(self, outs, ins):
+        """gloo has no all_to_all: the segments travel point to point (their sizes are known on
+        both sides, as in skm_alltoallv)."""
+        import torch.distributed as dist
+
+        reqs = []
+        for p in range(self.world):
+            if p == self.rank:
+                outs[p].copy_(ins[p])
+                continue
+            if ins[p].numel():
+                reqs.append(dist.isend(ins[p], dst=p))
+            if outs[p].numel():
+                reqs.append(dist.irecv(outs[p], src=p))
+        for r in reqs:
+            r.wait()
+
+
+def _sharded_rank(rank, world, port, n, tmpdir, mode):
     import torch.distributed as dist
 
     from snekmer_amd import _hip
@@ -491,12 +585,12 @@ def _sharded_rank(rank, world, port, n, tmpdir):
         bounds = shard_bounds_by_residues(off, world)
         lo, hi = bounds[rank]
         shard = engine.SeqBatch(ctx, res[off[lo]:off[hi]], off[lo:hi + 1] - off[lo])
-        sp = ShardedPipeline(ctx, lut, 12, _HostStagedExchange(ctx, world, rank), bounds, int(off[-1]))
+        sp = ShardedPipeline(ctx, lut, 12, _HostStagedExchange(ctx, world, rank), bounds, int(off[-1]), basis=mode)
         for _ in range(2):  # second step reuses every buffer
             out = sp.step(shard)
         block = out.download().reshape(out.shape)[: hi - lo, :n]
         np.save(os.path.join(tmpdir, f"block{rank}.npy"), block)
-        np.save(os.path.join(tmpdir, f"meta{rank}.npy"), np.asarray([lo, hi, sp.full.nnz, sp.basis.ncols]))
+        np.save(os.path.join(tmpdir, f"meta{rank}.npy"), np.asarray([lo, hi, sp.nnz_total, sp.basis.ncols]))
         # reduced output of the same exchange (BASELINE configs[3]): top-5 neighbours of the row block
         idx, val, _ = sp.step_topk(shard, 5)
         np.save(os.path.join(tmpdir, f"topidx{rank}.npy"), idx)
@@ -506,18 +600,21 @@ def _sharded_rank(rank, world, port, n, tmpdir):
         dist.destroy_process_group()
 
 
-def test_sharded_pipeline_two_ranks_on_one_gpu_equals_pipeline(ctx, tmp_path):
-    """World size 2 through the real ShardedPipeline.step (count shard, exchange, concat, basis,
-    row-block cosine): the stacked row blocks must equal the single-process result bit for bit."""
+@pytest.mark.parametrize("mode,world", [("distributed", 2), ("distributed", 3), ("replicated", 2)])
+def test_sharded_pipeline_two_ranks_on_one_gpu_equals_pipeline(ctx, tmp_path, mode, world):
+    """World size 2 or 3 through the real ShardedPipeline.step (count shard, exchange, postings,
+    row-block cosine), both forms of the exchange: the stacked row blocks must equal the
+    single-process result bit for bit."""
     import torch.multiprocessing as mp
 
     from snekmer_amd import alphabet as A
     from snekmer_amd import engine
     from snekmer_amd.synth import synth_families
 
-    n, world = 1500, 2
-    port = 29500 + (os.getpid() % 400)
-    mp.start_processes(_sharded_rank, args=(world, port, n, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    n = 1500
+    port = 29500 + (os.getpid() % 400) + 7 * world + (3 if mode == "replicated" else 0)
+    mp.start_processes(_sharded_rank, args=(world, port, n, str(tmp_path), mode), nprocs=world, join=True,
+                       start_method="spawn")
     lut = A.build_lut("red6")
     res, off, _ = synth_families(n, 300, family=30, seed=33)
     ref = engine.Pipeline(ctx, lut, 12)

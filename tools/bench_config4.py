@@ -56,7 +56,7 @@ if world > 1:
     same = float(np.mean(fam[idx[:, 0].astype(np.int64) % n] == fam[lo:hi]))
     if rank == 0:
         print(json.dumps({"config": f"{n} x 300aa red6 k=12 sharded x{world}: all-gather CSR, top-10 per row", "step_ms": float(t.item()) * 1e3,
-                          "sequences_per_s": n / float(t.item()), "nnz": sp.full.nnz, "basis_columns": sp.basis.ncols,
+                          "sequences_per_s": n / float(t.item()), "nnz": sp.nnz_total, "basis_columns": sp.basis.ncols,
                           "rank0_top1_same_family_frac": same}))
     dist.barrier()
     dist.destroy_process_group()
