@@ -85,6 +85,36 @@ int load_rccl()
 
 constexpr int NCCL_INT8 = 0;  // ncclInt8 / ncclChar
 
+struct seg_table {
+    int64_t off[SKM_MAX_RANKS + 1];
+};
+
+// Padded slots (one per rank, `maxb` apart) -> segments back to back; blockIdx.y = rank.  One launch
+// instead of one device copy per rank.
+__global__ __launch_bounds__(256) void k_unpack_slots(const uint8_t *__restrict__ slots, int64_t maxb, seg_table t,
+                                                      uint8_t *__restrict__ out)
+{
+    const int r = blockIdx.y;
+    const int64_t bytes = t.off[r + 1] - t.off[r];
+    const uint8_t *src = slots + maxb * r;
+    uint8_t *dst = out + t.off[r];
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
+    int64_t done = 0;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const int64_t nvec = bytes >> 4;
+        for (int64_t i = tid; i < nvec; i += nthreads)
+            reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+        done = nvec << 4;
+    } else if ((((uintptr_t)src | (uintptr_t)dst) & 3) == 0) {
+        const int64_t nw = bytes >> 2;
+        for (int64_t i = tid; i < nw; i += nthreads)
+            reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+        done = nw << 2;
+    }
+    for (int64_t i = done + tid; i < bytes; i += nthreads)
+        dst[i] = src[i];
+}
+
 }  // namespace
 
 extern "C" int skm_comm_unique_id(uint8_t *h_id)
@@ -100,7 +130,8 @@ extern "C" int skm_comm_unique_id(uint8_t *h_id)
 
 extern "C" int skm_comm_init(skm_ctx *ctx, int nranks, int rank, const uint8_t *h_id)
 {
-    SKM_REQUIRE(ctx && h_id && nranks >= 1 && rank >= 0 && rank < nranks, SKM_E_BADARG, "skm_comm_init: bad argument");
+    SKM_REQUIRE(ctx && h_id && nranks >= 1 && nranks <= SKM_MAX_RANKS && rank >= 0 && rank < nranks, SKM_E_BADARG,
+                "skm_comm_init: bad argument (1 <= nranks <= %d)", SKM_MAX_RANKS);
     SKM_REQUIRE(!ctx->comm, SKM_E_BADARG, "skm_comm_init: communicator already initialised");
     SKM_TRY(load_rccl());
     SKM_HIP(hipSetDevice(ctx->device));
@@ -155,14 +186,12 @@ extern "C" int skm_allgatherv(skm_ctx *ctx, const void *d_send, const int64_t *h
     if (h_bytes[ctx->rank] > 0)
         SKM_HIP(hipMemcpyAsync(mine, d_send, (size_t)h_bytes[ctx->rank], hipMemcpyDeviceToDevice, ctx->stream));
     SKM_NCCL(g_rccl.allgather(mine, slots, (size_t)maxb, NCCL_INT8, ctx->comm, ctx->stream));
-    int64_t offset = 0;
-    for (int r = 0; r < ctx->nranks; ++r) {
-        if (h_bytes[r] > 0)
-            SKM_HIP(hipMemcpyAsync((uint8_t *)d_recv + offset, slots + (size_t)maxb * (size_t)r, (size_t)h_bytes[r],
-                                   hipMemcpyDeviceToDevice, ctx->stream));
-        offset += h_bytes[r];
-    }
-    return SKM_OK;
+    seg_table t = {};
+    for (int r = 0; r < ctx->nranks; ++r)
+        t.off[r + 1] = t.off[r] + h_bytes[r];
+    const unsigned gx = (unsigned)skm_grid_cap(ctx, skm_ceil_div(maxb, 256 * 16), 4);
+    k_unpack_slots<<<dim3(gx, (unsigned)ctx->nranks), 256, 0, ctx->stream>>>(slots, maxb, t, (uint8_t *)d_recv);
+    return skm_check_launch("k_unpack_slots");
 }
 
 // Variable-size all-to-all as one group of point-to-point transfers (what RCCL's own all-to-all
