@@ -3,13 +3,21 @@
 //
 // For the rows of one strip every non-zero (row i, column c, count v) is a task whose posting list
 // (rows j of Y holding c, with counts v') contributes v*v' to G[i][j].  The strip's tasks are
-// compacted into LDS; groups of G lanes then take one task each and walk its posting list (every
-// posting is read once, G*8 contiguous bytes per load); products are summed in per-row LDS hash
-// tables keyed by j.  Finally each row's (j, dot) entries are written to a global list (in no
-// particular order: the streaming writer and the top-k kernel do not need one).
-// (An earlier version flattened all (task, posting) pairs with a prefix sum and a per-step binary
-// search: perfectly balanced, but ~8 LDS operations per pair made the LDS pipe the bound.)
+// binned by list length in LDS; groups of 4, 16 or G lanes then take one list each and walk it
+// (every posting is read once; the loads of a group's next list are in flight while it inserts
+// the current one; lists of thousands of postings are walked by the whole workgroup); products are
+// summed in per-row LDS hash tables keyed by j; pairs whose key is not at its first-probe slot are
+// parked in a per-wave queue and inserted 64 at a time.  Finally each row's (j, dot) entries are
+// written to a global list (in no particular order: the streaming writer and the top-k kernel do
+// not need one).
+//
+// Measured on the bench workload (PMC, profiles/): the kernel is bound by VALU issue (about 100
+// vector instructions per 64 pairs, lanes 45 % busy because list lengths vary) on top of a gather
+// of 8-byte postings that alone takes 0.85 ms (4.6 TB/s of 128-byte lines from beyond L2).  An
+// earlier version flattened all (task, posting) pairs with a prefix sum and a per-step binary
+// search: perfectly balanced lanes, but ~8 LDS operations per pair.
 #pragma once
+#include <type_traits>
 
 // diagnostic only (GABL == 3): summed shader-clock ticks per phase over all workgroups
 __device__ unsigned long long g_gram_phase_ticks[8];
@@ -36,11 +44,10 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     // fixed_stride != 0: row r of the launch owns g_ent[(slot0 + r) * fixed_stride ...) (no allocation);
     // fixed_stride == 0: lists are allocated back to back from *g_counter, up to cap_ent entries.
     // g_start / g_len / over_list are indexed by the row's position in the launch (i - row0).
-    static_assert(GR <= 16 && G <= 64 && 64 % G == 0 && GT % 64 == 0, "shape");
+    static_assert(GR <= 16 && G <= 64 && 64 % G == 0 && GT % 64 == 0 && G * U >= 16, "shape");
     constexpr int GTCAP = GQ * GT;
     constexpr int GMAXD = GH / 4 * 3;  // load factor at most 0.75
     constexpr int HBITS = __builtin_ctz(GH);
-    constexpr int NG = GT / G;  // posting lists in flight per workgroup
     constexpr int LONG_DF = 4 * G * U;
     __shared__ uint32_t t_start[GTCAP], t_df[GTCAP], t_liv[GTCAP];
     __shared__ uint32_t hkeys[GR][GH];
@@ -50,7 +57,10 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     __shared__ uint32_t s_fill[GR];
     __shared__ uint32_t s_self[GR];
     __shared__ unsigned long long s_off[GR];
-    __shared__ uint32_t s_ntask, s_nlong;
+    constexpr int NBIN = 4, B0 = 4, B1 = 16;  // list-length bins: <= 4, <= 16, <= LONG_DF, longer
+    __shared__ uint32_t s_cnt[NBIN], s_fillc[NBIN];
+    constexpr int GQCAP = 128;  // queue words per wave
+    __shared__ uint64_t s_queue[GT / 64][GQCAP];
     __shared__ int s_over;
     const int tid = threadIdx.x, lane = tid & 63;
     const int rows = (int)min((int64_t)GR, row1 - i0);
@@ -104,10 +114,11 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
         s_fill[tid] = 0;
         s_self[tid] = 0;
     }
-    if (tid == 0) {
+    if (tid == 0)
         s_over = 0;
-        s_ntask = 0;
-        s_nlong = 0;
+    if (tid < NBIN) {
+        s_cnt[tid] = 0;
+        s_fillc[tid] = 0;
     }
     for (int z = tid; z < GR * GH; z += GT) {
         (&hkeys[0][0])[z] = 0u;
@@ -146,6 +157,27 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
             pe[q] = ycolptr[col[q] + 1];
         }
     }
+    // Lists are binned by length so that every bin gets lane groups of a fitting width (a list
+    // of 2 postings on a 32-lane group would leave 30 lanes idle: at 100 k sequences half of the
+    // lists have fewer than 5 postings).  Bin c holds t_*[s_off[c] .. s_off[c + 1]).
+    int cls[GQ];
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) {
+        const uint32_t df = pe[q] - pb[q];
+        cls[q] = pe[q] > pb[q] ? (df <= (uint32_t)B0 ? 0 : df <= (uint32_t)B1 ? 1 : df <= (uint32_t)LONG_DF ? 2 : 3) : -1;
+#pragma unroll
+        for (int c = 0; c < NBIN; ++c) {
+            const unsigned long long bal = __ballot(cls[q] == c);
+            if (bal && lane == 0)
+                atomicAdd(&s_cnt[c], (uint32_t)__popcll(bal));
+        }
+    }
+    __syncthreads();
+    uint32_t boff[NBIN + 1];
+    boff[0] = 0;
+#pragma unroll
+    for (int c = 0; c < NBIN; ++c)
+        boff[c + 1] = boff[c] + s_cnt[c];
 #pragma unroll
     for (int q = 0; q < GQ; ++q) {
         const int t = q * GT + tid;
@@ -153,7 +185,6 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
 #pragma unroll
         for (int r = 1; r < GR; ++r)
             li += (e0 + t >= s_rp[r]) ? 1 : 0;
-        const bool task = pe[q] > pb[q];
         if (col[q] == G_SINGLETON && t < nnz) {
             const uint32_t vv = (val[q] & 0x0FFFFFFFu) * (val[q] & 0x0FFFFFFFu);
             if (GR == 1)
@@ -161,27 +192,20 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
             else
                 atomicAdd(&s_self[li], vv);
         }
-        const bool is_long = task && pe[q] - pb[q] > (uint32_t)LONG_DF;
-        const bool is_short = task && !is_long;
-        const unsigned long long bal = __ballot(is_short), bal_long = __ballot(is_long);
-        if (bal | bal_long) {
-            uint32_t base = 0, base_long = 0;
-            if (lane == 0) {
-                if (bal)
-                    base = atomicAdd(&s_ntask, (uint32_t)__popcll(bal));
-                if (bal_long)
-                    base_long = atomicAdd(&s_nlong, (uint32_t)__popcll(bal_long));
-            }
-            base = __shfl(base, 0);
-            base_long = __shfl(base_long, 0);
-            if (task) {
-                const unsigned long long below = (1ull << lane) - 1ull;
-                // short lists fill the arrays from the front, long ones from the back
-                const uint32_t pos = is_long ? (uint32_t)(GTCAP - 1) - (base_long + (uint32_t)__popcll(bal_long & below))
-                                             : base + (uint32_t)__popcll(bal & below);
-                t_start[pos] = pb[q];
-                t_df[pos] = pe[q] - pb[q];
-                t_liv[pos] = ((uint32_t)li << 28) | (val[q] & 0x0FFFFFFFu);
+#pragma unroll
+        for (int c = 0; c < NBIN; ++c) {
+            const unsigned long long bal = __ballot(cls[q] == c);
+            if (bal) {
+                uint32_t base = 0;
+                if (lane == 0)
+                    base = atomicAdd(&s_fillc[c], (uint32_t)__popcll(bal));
+                base = __shfl(base, 0);
+                if (cls[q] == c) {
+                    const uint32_t pos = boff[c] + base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    t_start[pos] = pb[q];
+                    t_df[pos] = pe[q] - pb[q];
+                    t_liv[pos] = ((uint32_t)li << 28) | (val[q] & 0x0FFFFFFFu);
+                }
             }
         }
     }
@@ -201,92 +225,134 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     // Lanes past the end of the list load posting 0 and discard it: loads under a branch would make
     // the compiler wait for ALL outstanding loads (vmcnt(0)) before the next LDS phase.  Only called
     // when the strip has a task, so posting 0 exists.
-    auto load_batch = [&](uint64_t (&pw)[U], uint32_t start, uint32_t df, uint32_t first, uint32_t stride) {
+    auto load_batch = [&](auto &pw, uint32_t start, uint32_t df, uint32_t first, uint32_t stride) {
+        constexpr int UU = (int)(sizeof(pw) / sizeof(pw[0]));
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < UU; ++u)
             pw[u] = ypost[first + u * stride < df ? start + first + u * stride : 0u];
     };
-    // all first-probe key reads, then the adds (a key that is not where the first probe looks takes
-    // the general insert)
-    auto insert_batch = [&](const uint64_t (&pw)[U], uint32_t df, int v, int li, uint32_t first, uint32_t stride) {
+    // Pairs whose key is not where the first probe looks (new neighbours, collisions: about a
+    // quarter of all pairs) are parked in a per-wave queue and inserted QDRAIN at a time with every
+    // lane busy.  Taking the general insert on the spot would run its branchy probe loop for a
+    // handful of lanes in nearly every batch (measured: two thirds of the kernel's instructions).
+    uint32_t qn = 0;  // wave-uniform
+    uint64_t *const queue = s_queue[tid >> 6];
+    auto drain = [&]() {
+        for (uint32_t q = (uint32_t)lane; q < qn; q += 64) {
+            const uint64_t it = queue[q];
+            insert((int)(it >> 60), (uint32_t)(it >> 28), (int)(uint32_t)(it & 0x0FFFFFFFull));
+        }
+        qn = 0;
+    };
+    // all first-probe key reads, then the adds
+    // `uniform`: every lane of the wave makes this call together (the queue counter is wave-uniform);
+    // elsewhere misses take the general insert directly.
+    auto insert_batch = [&](const auto &pw, uint32_t df, int v, int li, uint32_t first, uint32_t stride, auto uniform) {
+        constexpr int UU = (int)(sizeof(pw) / sizeof(pw[0]));
         if (GABL == 4) {  // diagnostic: loads only, no hash insert
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int u = 0; u < UU; ++u)
                 asm volatile("" ::"v"((uint32_t)pw[u]), "v"((uint32_t)(pw[u] >> 32)));
             return;
         }
-        uint32_t hh[U], seen[U];
+        uint32_t hh[UU], seen[UU];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < UU; ++u) {
             hh[u] = ((uint32_t)pw[u] * 2654435761u) >> (32 - HBITS);
             seen[u] = __atomic_load_n(&hkeys[li][hh[u]], __ATOMIC_RELAXED);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (first + u * stride < df) {
-                const uint32_t j = (uint32_t)pw[u];
-                const int prod = v * (int)(uint32_t)(pw[u] >> 32);
-                if (seen[u] == j + 1u)
-                    atomicAdd(&hvals[li][hh[u]], prod);
-                else
-                    insert(li, j, prod);
+        for (int u = 0; u < UU; ++u) {
+            const bool valid = first + u * stride < df;
+            const uint32_t j = (uint32_t)pw[u];
+            const uint32_t prod = (uint32_t)v * (uint32_t)(pw[u] >> 32);
+            const bool hit = valid && seen[u] == j + 1u;
+            if (hit)
+                atomicAdd(&hvals[li][hh[u]], (int)prod);
+            const bool miss = valid && !hit;
+            const bool parked = decltype(uniform)::value && miss && prod <= 0x0FFFFFFFu;
+            if (miss && !parked)
+                insert(li, j, (int)prod);  // does not fit the queue word (a count above 2^14)
+            const unsigned long long bal = decltype(uniform)::value ? __ballot(parked) : 0ull;
+            if (bal) {
+                if (parked)
+                    queue[qn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] =
+                        ((uint64_t)li << 60) | ((uint64_t)j << 28) | prod;
+                qn += (uint32_t)__popcll(bal);
+                if (qn > (uint32_t)(GQCAP - 64))
+                    drain();
             }
         }
     };
-    auto walk = [&](uint32_t start, uint32_t df, int v, int li, uint32_t first, uint32_t stride) {
-        for (uint32_t p = first; p < df && !s_over; p += stride * U) {
+    // workgroup walk of one list: every wave runs the same number of steps with all lanes
+    auto walk_all = [&](uint32_t start, uint32_t df, int v, int li) {
+        for (uint32_t p0 = 0; p0 < df && !s_over; p0 += GT * U) {
             uint64_t pw[U];
-            load_batch(pw, start, df, p, stride);
-            insert_batch(pw, df, v, li, p, stride);
+            load_batch(pw, start, df, p0 + (uint32_t)tid, GT);
+            insert_batch(pw, df, v, li, p0 + (uint32_t)tid, GT, std::true_type{});
         }
     };
-    // Short lists (at most LONG_DF postings): G consecutive lanes walk one list, software
+    // Bins 0-2: GC consecutive lanes walk one list, UC postings per lane and step, software
     // pipelined so that the loads of a group's next list are in flight while it inserts the
-    // current one (the gather, not the LDS, is the slow side).  Long lists (a few low-complexity
-    // k-mers occur in thousands of rows) are walked by the whole workgroup.
-    const int nshort = (int)s_ntask, nlong = (int)s_nlong;
-    if (GABL != 1 && nshort + nlong > 0) {
-        const uint32_t gl = (uint32_t)(tid % G);
-        struct hdr {
-            uint32_t start, df, lv;
-        };
-        auto fetch = [&](uint64_t (&pw)[U], int t) -> hdr {
+    // current one.  Bin 3 (a few low-complexity k-mers occur in thousands of rows) is walked by the
+    // whole workgroup, list after list.
+    struct hdr {
+        uint32_t start, df, lv;
+    };
+    auto run_bin = [&](auto gc_, auto uc_, int tb, int te) {
+        constexpr int GC = decltype(gc_)::value, UC = decltype(uc_)::value, NGC = GT / GC;
+        const uint32_t gl = (uint32_t)(tid % GC);
+        auto fetch = [&](uint64_t (&pw)[UC], int t) -> hdr {
             hdr h = {0u, 0u, 0u};
-            if (t < nshort)
+            if (t < te)
                 h = {t_start[t], t_df[t], t_liv[t]};
-            load_batch(pw, h.start, h.df, gl, G);
+            load_batch(pw, h.start, h.df, gl, GC);
             return h;
         };
-        auto consume = [&](const uint64_t (&pw)[U], const hdr &h) {
+        auto consume = [&](const uint64_t (&pw)[UC], const hdr &h) {
             const int v = (int)(h.lv & 0x0FFFFFFFu), li = (int)(h.lv >> 28);
-            insert_batch(pw, h.df, v, li, gl, G);
-            if (h.df > (uint32_t)(G * U))  // the rest of a list longer than one batch
-                walk(h.start, h.df, v, li, gl + G * U, G);
+            insert_batch(pw, h.df, v, li, gl, GC, std::true_type{});
+            if (h.df > (uint32_t)(GC * UC)) {  // the rest of a list longer than one batch (bin 2 only)
+                for (uint32_t p = gl + GC * UC; p < h.df && !s_over; p += GC * UC) {
+                    uint64_t more[UC];  // lanes of one wave may be in different lists here:
+                    load_batch(more, h.start, h.df, p, GC);  // misses are inserted directly
+                    insert_batch(more, h.df, v, li, p, GC, std::false_type{});
+                }
+            }
         };
-        // D register sets used in turn (no copies: a copy would wait for the load): while a group
-        // inserts one batch, the loads of its next D-1 lists are in flight
+        // D register sets used in turn (no copies: a copy would wait for the load)
         constexpr int D = 2;
-        uint64_t buf[D][U];
+        uint64_t buf[D][UC];
         hdr hd[D];
-        int t = tid / G;
-#pragma unroll
+        int t = tb + tid / GC;
+        int tw = tb + (tid >> 6) * (64 / GC);  // the wave's first list: every lane of a wave runs the
+#pragma unroll                                 // same number of steps (the queue counter needs that)
         for (int d = 0; d < D; ++d)
-            hd[d] = fetch(buf[d], t + d * NG);
-        while (t < nshort && !s_over) {
+            hd[d] = fetch(buf[d], t + d * NGC);
+        while (tw < te && !s_over) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {  // lists past the end have df == 0: nothing is inserted
                 consume(buf[d], hd[d]);
-                hd[d] = fetch(buf[d], t + (d + D) * NG);
+                hd[d] = fetch(buf[d], t + (d + D) * NGC);
             }
-            t += D * NG;
+            t += D * NGC;
+            tw += D * NGC;
         }
-        for (int tl = GTCAP - 1; tl > GTCAP - 1 - nlong; --tl) {
-            if (s_over)
-                break;
+    };
+    if (GABL != 1 && boff[NBIN] > 0) {
+        if (boff[1] > boff[0])
+            run_bin(std::integral_constant<int, B0>{}, std::integral_constant<int, 1>{}, (int)boff[0], (int)boff[1]);
+        if (boff[2] > boff[1])
+            run_bin(std::integral_constant<int, B1>{}, std::integral_constant<int, 1>{}, (int)boff[1], (int)boff[2]);
+        if (boff[3] > boff[2])
+            run_bin(std::integral_constant<int, G>{}, std::integral_constant<int, U>{}, (int)boff[2], (int)boff[3]);
+        for (int tl = (int)boff[3]; tl < (int)boff[4] && !s_over; ++tl) {
             const uint32_t lv = t_liv[tl];
-            walk(t_start[tl], t_df[tl], (int)(lv & 0x0FFFFFFFu), (int)(lv >> 28), (uint32_t)tid, GT);
+            walk_all(t_start[tl], t_df[tl], (int)(lv & 0x0FFFFFFFu), (int)(lv >> 28));
         }
     }
+    if (GABL != 1 && GABL != 4)
+        drain();
     __syncthreads();
     phase(2);  // pair loop
     if (s_over) {
