@@ -2,6 +2,8 @@
 #include <cstring>
 #include <map>
 
+#include <cstdlib>
+
 #include "skm_common.h"
 
 static thread_local char g_err[1024] = "";
@@ -69,6 +71,12 @@ extern "C" int skm_destroy(skm_ctx *ctx)
             hipFree(ctx->ws[i]);
     if (ctx->h_pinned)
         hipHostFree(ctx->h_pinned);
+    for (auto e : ctx->sync_events)
+        hipEventDestroy(e);
+    if (ctx->s_writer)
+        hipStreamDestroy(ctx->s_writer);
+    if (ctx->s_gram)
+        hipStreamDestroy(ctx->s_gram);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return SKM_OK;

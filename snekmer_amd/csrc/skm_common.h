@@ -58,6 +58,11 @@ struct skm_ctx {
     bool profiling = false;
     std::vector<skm_prof_entry> prof;
     std::vector<hipEvent_t> event_pool;
+    // cosine stage: streams confined to disjoint CU sets (writer 3/4, sparse Gram 1/4) and the events
+    // that chain them; created on first use (skm_cosine_csr.hip), overlap_state: 0 untried, 1 ready, -1 unavailable
+    hipStream_t s_writer = nullptr, s_gram = nullptr;
+    std::vector<hipEvent_t> sync_events;
+    int overlap_state = 0;
     // RCCL (loaded lazily with dlopen; see skm_comm.hip)
     void *rccl_lib = nullptr;
     void *comm = nullptr;

@@ -247,14 +247,14 @@ __global__ __launch_bounds__(WTB) void k_cosine_write(const uint64_t *__restrict
                                                      const uint32_t *__restrict__ g_len,
                                                      const float *__restrict__ xrnorm,
                                                      const float *__restrict__ yrnorm, int64_t m, int64_t row0,
-                                                     int64_t row1, float *__restrict__ out, int64_t ld,
+                                                     int64_t rbase, float *__restrict__ out, int64_t ld,
                                                      uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_count,
                                                      uint32_t *__restrict__ fb_flag)
 {
     constexpr int CH = WCH, TB = WTB, NV = WCH / 4 / WTB, WREG = 2;  // NV 16-byte vectors per thread and step
     __shared__ __attribute__((aligned(16))) float s_acc[CH];
     const int tid = threadIdx.x;
-    const int64_t r = blockIdx.x;  // row of the block
+    const int64_t r = rbase + blockIdx.x;  // row of the workgroup, counted from row0 (a launch covers rows rbase...)
     const int64_t i = row0 + r;
     const uint32_t len = g_len[r];
     if (len == G_OVERFLOW) {
@@ -619,6 +619,36 @@ extern "C" int skm_neighbors_topk(skm_ctx *ctx, int64_t nrows, int64_t row0, con
 }
 
 namespace {
+// Two streams confined to disjoint CU sets (mask bit i: CU group (i / 8) % 8; groups 0-2 build the
+// neighbour lists, groups 3-7 write) and the events that chain them.
+int overlap_streams(skm_ctx *ctx)
+{
+    if (ctx->overlap_state != 0)
+        return ctx->overlap_state > 0 ? SKM_OK : SKM_E_UNSUPPORTED;
+    ctx->overlap_state = -1;
+    const int ncu = ctx->num_cus;
+    if (ncu < 64 || ncu > 512)
+        return SKM_E_UNSUPPORTED;
+    uint32_t mw[16] = {}, mg[16] = {};
+    for (int i = 0; i < ncu; ++i)  // measured best split: 3/8 of the CUs build lists, 5/8 write
+        ((i / 8) % 8 >= 3 ? mw : mg)[i / 32] |= 1u << (i % 32);
+    const uint32_t words = (uint32_t)((ncu + 31) / 32);
+    if (hipExtStreamCreateWithCUMask(&ctx->s_writer, words, mw) != hipSuccess ||
+        hipExtStreamCreateWithCUMask(&ctx->s_gram, words, mg) != hipSuccess) {
+        (void)hipGetLastError();
+        return SKM_E_UNSUPPORTED;
+    }
+    for (int i = 0; i < 16 + 3; ++i) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return SKM_E_UNSUPPORTED;
+        }
+        ctx->sync_events.push_back(e);
+    }
+    ctx->overlap_state = 1;
+    return SKM_OK;
+}
 }  // namespace
 
 extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
@@ -710,58 +740,96 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     unsigned long long *g_counter = (unsigned long long *)((uint8_t *)p + 2048);
     fb_count = (uint32_t *)((uint8_t *)p + 2048 + 8);
     uint32_t *over_count = fb_count + 1;
-    SKM_HIP(hipMemsetAsync(g_counter, 0, 16, st));
+    constexpr int MAXB = 16;  // row blocks of the overlapped schedule (one overflow counter each)
+    SKM_HIP(hipMemsetAsync(g_counter, 0, 16 + 4 * MAXB, st));
     k_set_u64<<<1, 1, 0, st>>>(g_counter, fixed_ent);
     const char *gabl_env = getenv("SKM_GRAM_ABLATE");  // diagnostic builds of k_gram_sparse (1, 2, 4: results NOT valid)
     const int gabl = gabl_env ? atoi(gabl_env) : 0;
-    {
-        // one row per workgroup, 2048 slots: 22 KB of LDS -> 7 workgroups per CU (measured best shape)
-        SKM_PROF(ctx, "k_gram_sparse");
-#define SKM_GRAM_S(GABL, GG, UU)                                                                                     \
-    k_gram_sparse<GABL, 1, 2048, 256, 2, GG, UU><<<(unsigned)nrows, 256, 0, st>>>(                                   \
-        d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, SLOT, 0, g_ent, cap_ent, g_counter, g_start, \
-        g_len, over_list, over_count)
-#define SKM_GRAM(GABL) SKM_GRAM_S(GABL, 32, 2)
-        if (gabl == 1)
-            SKM_GRAM(1);
-        else if (gabl == 2)
-            SKM_GRAM(2);
-        else if (gabl == 4)
-            SKM_GRAM(4);
-        else if (gabl == 3) {  // phase stamps (exact results, slower): read with skm_debug_gram_phases
-            unsigned long long zeros[8] = {};
-            SKM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gram_phase_ticks), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice, st));
-            SKM_GRAM(3);
-        } else
-            SKM_GRAM(0);
+
+    // Schedule.  By default the three kernels run back to back on the context's stream.
+    // SKM_COSINE_OVERLAP=1 selects a blocked schedule for large outputs: the rows are cut into 8
+    // blocks; block b's lists are built on a stream confined to 3/8 of the CUs while block b-1 is
+    // written on a stream confined to the other 5/8 (unconfined, the Gram workgroups take the
+    // writer's LDS and wave slots and the pair runs slower than back to back).  Measured at config 3:
+    // 10.75 vs 10.97 ms per step (+2 %), but both kernels run slower side by side (writer 7.8 vs 6.8 ms
+    // summed over its launches: the Gram's 4.4 GB of gathers share HBM with the stores), so the
+    // writer's own roofline fraction drops from 0.72 to 0.64; it is therefore opt-in.
+    const char *ov_env = getenv("SKM_COSINE_OVERLAP");
+    int nblk = 1;
+    if (gabl == 0 && ov_env && atoi(ov_env) == 1 && nrows >= 4096 && (double)nrows * (double)ld * 4.0 >= 2e9 &&
+        overlap_streams(ctx) == SKM_OK)
+        nblk = 8;
+    const int64_t brows = skm_ceil_div(skm_ceil_div(nrows, nblk), 8) * 8;  // whole cursor strips per block
+    hipStream_t s_g = nblk > 1 ? ctx->s_gram : st, s_w = nblk > 1 ? ctx->s_writer : st;
+    if (nblk > 1) {
+        SKM_HIP(hipEventRecord(ctx->sync_events[0], st));
+        SKM_HIP(hipStreamWaitEvent(s_g, ctx->sync_events[0], 0));
+        SKM_HIP(hipStreamWaitEvent(s_w, ctx->sync_events[0], 0));
+    }
+    for (int b = 0; b < nblk; ++b) {
+        const int64_t b0 = (int64_t)b * brows, b1 = min(nrows, b0 + brows);
+        if (b0 >= b1)
+            break;
+        const int64_t bn = b1 - b0;
+        hipStream_t gs = b == 0 ? st : s_g;
+        uint32_t *b_over_list = over_list + b0, *b_over_count = over_count + b;
+        {
+            // one row per workgroup, 2048 slots: 26 KB of LDS -> 6 workgroups per CU
+            SKM_PROF_ON(ctx, "k_gram_sparse", gs);
+#define SKM_GRAM(GABL)                                                                                               \
+    k_gram_sparse<GABL, 1, 2048, 256, 2, 32, 2><<<(unsigned)bn, 256, 0, gs>>>(                                       \
+        d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0 + b0, row0 + b1, SLOT, b0, g_ent, cap_ent, g_counter, \
+        g_start + b0, g_len + b0, b_over_list, b_over_count)
+            if (gabl == 1)
+                SKM_GRAM(1);
+            else if (gabl == 2)
+                SKM_GRAM(2);
+            else if (gabl == 4)
+                SKM_GRAM(4);
+            else if (gabl == 3) {  // phase stamps (exact results, slower): read with skm_debug_gram_phases
+                unsigned long long zeros[8] = {};
+                SKM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gram_phase_ticks), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice, st));
+                SKM_GRAM(3);
+            } else
+                SKM_GRAM(0);
 #undef SKM_GRAM
-#undef SKM_GRAM_S
-    }
-    SKM_TRY(skm_check_launch("k_gram_sparse"));
-    {
-        // rows the small tables cannot hold: 8192 slots and up to 4096 non-zeros, one row per workgroup
-        SKM_PROF(ctx, "k_gram_sparse_big");
-        k_gram_sparse_big<8192, 512, 8, 16, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
-            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, g_ent, cap_ent, g_counter, g_start, g_len,
-            over_list, over_count, nullptr, nullptr);
-    }
-    SKM_TRY(skm_check_launch("k_gram_sparse_big"));
-    {
-        // one output row per workgroup of 1024 threads
-        SKM_PROF(ctx, "k_cosine_write");
+        }
+        SKM_TRY(skm_check_launch("k_gram_sparse"));
+        {
+            // rows the small tables cannot hold: 8192 slots and up to 4096 non-zeros, one row per workgroup
+            SKM_PROF_ON(ctx, "k_gram_sparse_big", gs);
+            k_gram_sparse_big<8192, 512, 8, 16, 4><<<skm_grid_cap(ctx, bn, 1), 512, 0, gs>>>(
+                d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0 + b0, row0 + b1, g_ent, cap_ent, g_counter,
+                g_start + b0, g_len + b0, b_over_list, b_over_count, nullptr, nullptr);
+        }
+        SKM_TRY(skm_check_launch("k_gram_sparse_big"));
+        if (nblk > 1) {
+            SKM_HIP(hipEventRecord(ctx->sync_events[1 + b], gs));
+            SKM_HIP(hipStreamWaitEvent(s_w, ctx->sync_events[1 + b], 0));
+        }
+        {
+            // one output row per workgroup of 1024 threads
+            SKM_PROF_ON(ctx, "k_cosine_write", s_w);
 #define SKM_WRITE(MODE, VEC)                                                                                         \
     do {                                                                                                             \
         if (m >= 65536) /* wide rows: 128 KiB per step (fewer barriers, longer bursts: 6.9 vs 7.2 ms at m = 100k) */ \
-            k_cosine_write<MODE, VEC, 32768, 1024><<<(unsigned)nrows, 1024, 0, st>>>(                                \
-                g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, row1, d_out, ld, fb_list, fb_count, fb_flag);    \
+            k_cosine_write<MODE, VEC, 32768, 1024><<<(unsigned)bn, 1024, 0, s_w>>>(                                  \
+                g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, b0, d_out, ld, fb_list, fb_count, fb_flag);      \
         else                                                                                                         \
-            k_cosine_write<MODE, VEC, 4096, 1024><<<(unsigned)nrows, 1024, 0, st>>>(                                 \
-                g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, row1, d_out, ld, fb_list, fb_count, fb_flag);    \
+            k_cosine_write<MODE, VEC, 4096, 1024><<<(unsigned)bn, 1024, 0, s_w>>>(                                   \
+                g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, b0, d_out, ld, fb_list, fb_count, fb_flag);      \
     } while (0)
-        SKM_BY_MODE_VEC(SKM_WRITE);
+            SKM_BY_MODE_VEC(SKM_WRITE);
 #undef SKM_WRITE
+        }
+        SKM_TRY(skm_check_launch("k_cosine_write"));
     }
-    SKM_TRY(skm_check_launch("k_cosine_write"));
+    if (nblk > 1) {  // the context's stream continues after both side streams
+        SKM_HIP(hipEventRecord(ctx->sync_events[1 + MAXB], s_w));
+        SKM_HIP(hipEventRecord(ctx->sync_events[2 + MAXB], s_g));
+        SKM_HIP(hipStreamWaitEvent(st, ctx->sync_events[1 + MAXB], 0));
+        SKM_HIP(hipStreamWaitEvent(st, ctx->sync_events[2 + MAXB], 0));
+    }
     {
         // strips with a row still flagged; worst-case grid, surplus workgroups exit at once
         SKM_PROF(ctx, "k_cosine_strip");

@@ -640,6 +640,30 @@ def test_sharded_pipeline_two_ranks_on_one_gpu_equals_pipeline(ctx, tmp_path, mo
     assert covered == n
 
 
+def test_overlapped_cosine_schedule_equals_default(ctx, monkeypatch):
+    """SKM_COSINE_OVERLAP=1 (row blocks; lists built on one CU-masked stream while the previous block
+    is written on another) must give the default schedule's matrix bit for bit."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+
+    n = 24000  # 2.3 GB of output: above the size from which the blocked schedule applies
+    lut = A.build_lut("red6")
+    res, off, _ = synth_families(n, 300, family=100, seed=77)
+    batch = engine.SeqBatch(ctx, res, off)
+    pipe = engine.Pipeline(ctx, lut, 12)
+    pipe.vectorize(batch)
+    monkeypatch.setenv("SKM_COSINE_OVERLAP", "0")
+    ref = pipe.cosine()
+    pipe.out = None  # keep `ref`, write the second run to a fresh buffer
+    monkeypatch.setenv("SKM_COSINE_OVERLAP", "1")
+    got = pipe.cosine()
+    ld = ref.shape[1]
+    for r0 in range(0, n, 2000):  # 3000-row blocks: every chunk boundary and block edge is covered
+        cnt = min(2000, n - r0) * ld
+        assert (got.download(cnt, offset=r0 * ld) == ref.download(cnt, offset=r0 * ld)).all()
+
+
 # ------------------------------------------------------------------ BASELINE full sizes
 def _sampled_row_check(ctx, name, k, n, seed_idx, nsample=48, family=100):
     from snekmer_amd import alphabet as A
