@@ -567,22 +567,22 @@ class _HostStagedExchange:
             r.wait()
 
 
-def _sharded_rank(rank, world, port, n, tmpdir, mode):
+def _sharded_rank(rank, world, port, n, tmpdir, mode, name="red6"):
     import torch.distributed as dist
 
     from snekmer_amd import _hip
     from snekmer_amd import alphabet as A
     from snekmer_amd import engine
-    from snekmer_amd.dist import ShardedPipeline, shard_bounds_by_residues
+    from snekmer_amd.dist import ShardedPipeline, shard_bounds, shard_bounds_by_residues
     from snekmer_amd.synth import synth_families
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         A.register_alphabet("red6", A.RED6_GROUPS)
         ctx = _hip.Context(0)
-        lut = A.build_lut("red6")
+        lut = A.build_lut(name)
         res, off, _ = synth_families(n, 300, family=30, seed=33)
-        bounds = shard_bounds_by_residues(off, world)
+        bounds = shard_bounds_by_residues(off, world) if n >= world else shard_bounds(n, world)
         lo, hi = bounds[rank]
         shard = engine.SeqBatch(ctx, res[off[lo]:off[hi]], off[lo:hi + 1] - off[lo])
         sp = ShardedPipeline(ctx, lut, 12, _HostStagedExchange(ctx, world, rank), bounds, int(off[-1]), basis=mode)
@@ -600,8 +600,10 @@ def _sharded_rank(rank, world, port, n, tmpdir, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,world", [("distributed", 2), ("distributed", 3), ("replicated", 2)])
-def test_sharded_pipeline_two_ranks_on_one_gpu_equals_pipeline(ctx, tmp_path, mode, world):
+@pytest.mark.parametrize("mode,world,n,name", [("distributed", 2, 1500, "red6"), ("distributed", 3, 1500, "red6"),
+                                               ("replicated", 2, 1500, "red6"), ("distributed", 2, 700, "standard"),
+                                               ("distributed", 3, 2, "red6")])
+def test_sharded_pipeline_two_ranks_on_one_gpu_equals_pipeline(ctx, tmp_path, mode, world, n, name):
     """World size 2 or 3 through the real ShardedPipeline.step (count shard, exchange, postings,
     row-block cosine), both forms of the exchange: the stacked row blocks must equal the
     single-process result bit for bit."""
@@ -611,11 +613,10 @@ def test_sharded_pipeline_two_ranks_on_one_gpu_equals_pipeline(ctx, tmp_path, mo
     from snekmer_amd import engine
     from snekmer_amd.synth import synth_families
 
-    n = 1500
-    port = 29500 + (os.getpid() % 400) + 7 * world + (3 if mode == "replicated" else 0)
-    mp.start_processes(_sharded_rank, args=(world, port, n, str(tmp_path), mode), nprocs=world, join=True,
+    port = 29500 + (os.getpid() % 400) + 7 * world + (3 if mode == "replicated" else 0) + n % 5 + len(name)
+    mp.start_processes(_sharded_rank, args=(world, port, n, str(tmp_path), mode, name), nprocs=world, join=True,
                        start_method="spawn")
-    lut = A.build_lut("red6")
+    lut = A.build_lut(name)
     res, off, _ = synth_families(n, 300, family=30, seed=33)
     ref = engine.Pipeline(ctx, lut, 12)
     S = ref.step(engine.SeqBatch(ctx, res, off))
@@ -630,12 +631,17 @@ def test_sharded_pipeline_two_ranks_on_one_gpu_equals_pipeline(ctx, tmp_path, mo
         idx, val = np.load(tmp_path / f"topidx{r}.npy"), np.load(tmp_path / f"topval{r}.npy")
         blk = S[lo:hi].copy()
         blk[np.arange(hi - lo), np.arange(lo, hi)] = -1.0
-        want = -np.sort(-blk, axis=1)[:, :5]
+        want = np.full((hi - lo, 5), -1.0)
+        top = -np.sort(-blk, axis=1)[:, :5]
+        want[:, : top.shape[1]] = top
         have = np.where(idx == 0xFFFFFFFF, 0.0, val)
-        assert np.abs(have - np.maximum(want, 0.0)).max() <= 1e-6
+        assert idx.shape == (hi - lo, 5)
+        if hi > lo:
+            assert np.abs(have - np.maximum(want, 0.0)).max() <= 1e-6
         ok = idx != 0xFFFFFFFF
         rr = np.repeat(np.arange(hi - lo), 5).reshape(-1, 5)
-        assert np.abs(blk[rr[ok], idx[ok].astype(np.int64)] - val[ok]).max() <= 1e-6
+        if ok.any():
+            assert np.abs(blk[rr[ok], idx[ok].astype(np.int64)] - val[ok]).max() <= 1e-6
         covered += hi - lo
     assert covered == n
 
