@@ -19,7 +19,7 @@ import numpy as np
 
 from . import engine
 from .alphabet import FULL_ALPHABETS, build_lut
-from .io import read_fasta
+from .io import read_fasta, save_npz_sparse
 from .vectorize import KmerVec, _restore_wide_chars
 
 
@@ -107,10 +107,16 @@ def vectorize_fasta(
     basis: Optional[Sequence[str]] = None,
     npz_out: Optional[str] = None,
     kmers_out: Optional[str] = None,
+    sparse_npz_out: Optional[str] = None,
 ) -> Dict[str, np.ndarray]:
     """FASTA -> the rule's outputs; optionally writes the ``.npz`` and the pickled KmerVec
-    (``.kmers``) exactly as rules/kmerize.smk:132-142 does."""
-    out = vectorize_records(read_fasta(path), alphabet, k, min_filter=min_filter, basis=basis)
+    (``.kmers``) exactly as rules/kmerize.smk:132-142 does.  `sparse_npz_out` writes the sparse
+    variant (io.save_npz_sparse: CSR counts, no dense matrix); without `npz_out` the dense
+    N x |basis| float64 matrix is then never built."""
+    out = vectorize_records(read_fasta(path), alphabet, k, min_filter=min_filter, basis=basis,
+                            dense=bool(npz_out) or not sparse_npz_out)
+    if sparse_npz_out:
+        save_npz_sparse(sparse_npz_out, out)
     if npz_out:
         np.savez_compressed(
             npz_out, kmerlist=out["kmerlist"], ids=out["ids"], seqs=out["seqs"], vecs=out["vecs"], lengths=out["lengths"]

@@ -201,6 +201,17 @@ def test_vectorize_fasta_writes_reference_formats(ctx, tmp_path):
         kv = pickle.load(f)
     assert sorted(kv.__dict__) == sorted(gjson("g6_basis.json")["kmervec_attrs"])
     assert list(kv.kmer_set.kmers) == list(kmerlist)
+    # sparse variant of the same file: CSR counts instead of the dense presence matrix
+    snpz = str(tmp_path / "TIGR03149.sparse.npz")
+    vectorize_fasta(os.path.join(GOLDEN, "data", "TIGR03149.faa"), "hydro", 14, sparse_npz_out=snpz)
+    (kl2,), df2 = skm.io.load_npz(snpz)
+    assert list(kl2) == list(kmerlist) and list(df2["sequence_id"]) == list(df["sequence_id"])
+    assert all((a == b).all() for a, b in zip(df2["sequence_vector"], df["sequence_vector"]))
+    C = skm.io.load_counts_npz(snpz)
+    # the fixture covers both demo files (this one first): same counts in this file's columns
+    gcol = {kk: i for i, kk in enumerate(g["kmerlist"].tolist())}
+    gdense = csr_to_dense(g["counts_rowptr"], g["counts_col"], g["counts_val"], len(g["kmerlist"]))
+    assert (C.toarray() == gdense[:n][:, [gcol[kk] for kk in kmerlist.tolist()]]).all()
 
 
 # ------------------------------------------------------------------ a13 / a14 cosine

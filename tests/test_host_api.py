@@ -124,3 +124,19 @@ def test_synth_is_deterministic_and_shaped():
     lens = np.diff(off)
     assert set(lens.tolist()) <= {300, 301} and (res[off[1:][lens == 301] - 1] == ord("*")).all()
     assert len(set(fam.tolist())) == 10
+
+
+def test_sparse_npz_roundtrip(tmp_path):
+    """io.save_npz_sparse / load_counts_npz / load_npz on the sparse variant (host only)."""
+    out = {
+        "kmerlist": np.array(["AAC", "ACA", "CAA"]), "ids": np.array(["s1", "s2", "s3"]), "seqs": np.array(["AACA", "CAAC", "XX"]),
+        "lengths": np.array([4, 4, 2]), "counts_rowptr": np.array([0, 2, 4, 4], dtype=np.int64),
+        "counts_col": np.array([0, 1, 0, 2], dtype=np.uint32), "counts_val": np.array([1, 1, 2, 1], dtype=np.uint32),
+    }
+    path = str(tmp_path / "x.npz")
+    skm.io.save_npz_sparse(path, out)
+    C = skm.io.load_counts_npz(path)
+    assert C.shape == (3, 3) and C.toarray().tolist() == [[1, 1, 0], [2, 0, 1], [0, 0, 0]]
+    (kl,), df = skm.io.load_npz(path)
+    assert list(kl) == ["AAC", "ACA", "CAA"] and list(df["sequence_length"]) == [4, 4, 2]
+    assert [v.tolist() for v in df["sequence_vector"]] == [[1.0, 1.0, 0.0], [1.0, 0.0, 1.0], [0.0, 0.0, 0.0]]
