@@ -340,16 +340,18 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
         }
     };
     if (GABL != 1 && boff[NBIN] > 0) {
-        if (boff[1] > boff[0])
-            run_bin(std::integral_constant<int, B0>{}, std::integral_constant<int, 1>{}, (int)boff[0], (int)boff[1]);
-        if (boff[2] > boff[1])
-            run_bin(std::integral_constant<int, B1>{}, std::integral_constant<int, 1>{}, (int)boff[1], (int)boff[2]);
-        if (boff[3] > boff[2])
-            run_bin(std::integral_constant<int, G>{}, std::integral_constant<int, U>{}, (int)boff[2], (int)boff[3]);
+        // longest lists first: they bring most of a row's distinct neighbours, so a row that will
+        // overflow the table does so early and wastes little work before the larger-table pass
         for (int tl = (int)boff[3]; tl < (int)boff[4] && !s_over; ++tl) {
             const uint32_t lv = t_liv[tl];
             walk_all(t_start[tl], t_df[tl], (int)(lv & 0x0FFFFFFFu), (int)(lv >> 28));
         }
+        if (boff[3] > boff[2])
+            run_bin(std::integral_constant<int, G>{}, std::integral_constant<int, U>{}, (int)boff[2], (int)boff[3]);
+        if (boff[2] > boff[1])
+            run_bin(std::integral_constant<int, B1>{}, std::integral_constant<int, 1>{}, (int)boff[1], (int)boff[2]);
+        if (boff[1] > boff[0])
+            run_bin(std::integral_constant<int, B0>{}, std::integral_constant<int, 1>{}, (int)boff[0], (int)boff[1]);
     }
     if (GABL != 1 && GABL != 4)
         drain();
