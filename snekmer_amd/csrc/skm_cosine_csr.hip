@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_neighbors_topk(int64_t nrows, int64_t r
                                                         const uint32_t *__restrict__ g_len,
                                                         const uint64_t *__restrict__ g_ent,
                                                         const float *__restrict__ xr, const float *__restrict__ yr, int k,
-                                                        int exclude_self, uint32_t *__restrict__ idx,
+                                                        int exclude_self, uint32_t min_len, uint32_t *__restrict__ idx,
                                                         float *__restrict__ val)
 {
     const int lane = threadIdx.x & 63;
@@ -362,6 +362,8 @@ __global__ __launch_bounds__(256) void k_neighbors_topk(int64_t nrows, int64_t r
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t r = wave; r < nrows; r += nwaves) {
         const uint32_t len = g_len[r] == G_OVERFLOW ? 0u : g_len[r];
+        if (len < min_len && len != 0u)  // rows the LDS kernel takes (empty rows are written here)
+            continue;
         const uint64_t st = g_start[r];
         const float ri = xr[row0 + r];
         const uint32_t self = (uint32_t)(row0 + r);
@@ -406,6 +408,97 @@ __global__ __launch_bounds__(256) void k_neighbors_topk(int64_t nrows, int64_t r
             pj = bj;
             first = false;
         }
+    }
+}
+
+// Rows whose list fits LDS (at most TOPK_CAP entries: nearly all): workgroup per row.  Scores are
+// computed once (one gather of the neighbour's norm per entry) and cached with their row numbers;
+// each of the k rounds is then an arg-max over LDS in (score desc, j asc) order that retires its
+// pick.  The wave-per-row kernel above re-reads the list and the norms in every round.
+constexpr int TOPK_CAP = 8192;
+
+__global__ __launch_bounds__(256) void k_neighbors_topk_lds(int64_t nrows, int64_t row0, const uint64_t *__restrict__ g_start,
+                                                            const uint32_t *__restrict__ g_len,
+                                                            const uint64_t *__restrict__ g_ent,
+                                                            const float *__restrict__ xr, const float *__restrict__ yr,
+                                                            int k, int exclude_self, uint32_t *__restrict__ idx,
+                                                            float *__restrict__ val)
+{
+    __shared__ float s_v[TOPK_CAP];
+    __shared__ uint32_t s_j[TOPK_CAP];
+    __shared__ float s_bv[4];
+    __shared__ uint32_t s_bj[4], s_bp[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const uint32_t len = g_len[r];
+        if (len == G_OVERFLOW || len == 0u || len >= (uint32_t)TOPK_CAP)
+            continue;  // uniform for the workgroup
+        const uint64_t st = g_start[r];
+        const float ri = xr[row0 + r];
+        const uint32_t self = (uint32_t)(row0 + r);
+        for (uint32_t e = (uint32_t)tid; e < len; e += 256) {
+            const uint64_t w = g_ent[st + e];
+            const uint32_t j = (uint32_t)(w >> 32);
+            s_j[e] = j;
+            s_v[e] = (exclude_self && j == self) ? -INFINITY : (float)(int)(uint32_t)w * ri * yr[j];
+        }
+        __syncthreads();
+        for (int t = 0; t < k; ++t) {
+            float bv = -INFINITY;
+            uint32_t bj = 0xFFFFFFFFu, bp = 0;
+            for (uint32_t e = (uint32_t)tid; e < len; e += 256) {
+                const float v = s_v[e];
+                const uint32_t j = s_j[e];
+                if (v > bv || (v == bv && j < bj && v != -INFINITY)) {
+                    bv = v;
+                    bj = j;
+                    bp = e;
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o);
+                const uint32_t oj = __shfl_xor(bj, o), op = __shfl_xor(bp, o);
+                if (ov > bv || (ov == bv && oj < bj)) {
+                    bv = ov;
+                    bj = oj;
+                    bp = op;
+                }
+            }
+            if (lane == 0) {
+                s_bv[wid] = bv;
+                s_bj[wid] = bj;
+                s_bp[wid] = bp;
+            }
+            __syncthreads();
+            bv = s_bv[0];
+            bj = s_bj[0];
+            bp = s_bp[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                if (s_bv[w] > bv || (s_bv[w] == bv && s_bj[w] < bj)) {
+                    bv = s_bv[w];
+                    bj = s_bj[w];
+                    bp = s_bp[w];
+                }
+            }
+            const bool none = bj == 0xFFFFFFFFu;  // fewer than k neighbours: the rest stays empty
+            if (tid == 0) {
+                idx[r * k + t] = bj;
+                val[r * k + t] = none ? 0.0f : bv;
+                if (!none)
+                    s_v[bp] = -INFINITY;  // retired
+            }
+            if (none) {
+                for (int u = t + 1 + tid; u < k; u += 256) {
+                    idx[r * k + u] = 0xFFFFFFFFu;
+                    val[r * k + u] = 0.0f;
+                }
+            }
+            __syncthreads();
+            if (none)
+                break;
+        }
+        __syncthreads();
     }
 }
 
@@ -612,9 +705,16 @@ extern "C" int skm_neighbors_topk(skm_ctx *ctx, int64_t nrows, int64_t row0, con
         return SKM_OK;
     SKM_REQUIRE(d_start && d_len && d_xrnorm && d_yrnorm && d_idx && d_val, SKM_E_BADARG, "skm_neighbors_topk: null array");
     SKM_HIP(hipSetDevice(ctx->device));
-    SKM_PROF(ctx, "k_neighbors_topk");
+    {
+        // lists that fit LDS: scores cached once
+        SKM_PROF(ctx, "k_neighbors_topk_lds");
+        k_neighbors_topk_lds<<<skm_grid_cap(ctx, nrows, 8), 256, 0, ctx->stream>>>(nrows, row0, d_start, d_len, d_ent, d_xrnorm,
+                                                                                  d_yrnorm, k, exclude_self, d_idx, d_val);
+    }
+    SKM_TRY(skm_check_launch("k_neighbors_topk_lds"));
+    SKM_PROF(ctx, "k_neighbors_topk");  // longer lists, empty and flagged rows
     k_neighbors_topk<<<skm_grid_cap(ctx, skm_ceil_div(nrows, 4), 16), 256, 0, ctx->stream>>>(
-        nrows, row0, d_start, d_len, d_ent, d_xrnorm, d_yrnorm, k, exclude_self, d_idx, d_val);
+        nrows, row0, d_start, d_len, d_ent, d_xrnorm, d_yrnorm, k, exclude_self, (uint32_t)TOPK_CAP, d_idx, d_val);
     return skm_check_launch("k_neighbors_topk");
 }
 
