@@ -141,7 +141,11 @@ def main():
         uid = [RcclExchange.new_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ex = RcclExchange(ctx, world, rank, uid[0])
-        ex.allgather_i64([rank])  # first collective: connection set-up happens here, outside the timed region
+        # first collectives: RCCL sets up its ring and its point-to-point channels here, outside the timed region
+        ex.allgather_i64([rank])
+        warm_s, warm_r = ctx.zeros(8 * world, np.uint8), ctx.zeros(8 * world, np.uint8)
+        ex.alltoallv(warm_s, [8] * world, warm_r, [8] * world)
+        ctx.sync()
         bounds = shard_bounds(n_total, world)
         lo, hi = bounds[rank]
         shard = engine.SeqBatch(ctx, res[off[lo] : off[hi]], off[lo : hi + 1] - off[lo])
