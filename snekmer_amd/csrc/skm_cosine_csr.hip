@@ -665,15 +665,21 @@ extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrow
     }
     SKM_TRY(skm_check_launch("k_gram_sparse"));
     {
+        // Rows the 2048-slot tables cannot hold, one row per workgroup at a time, smallest shape that
+        // fits first (the lists ping-pong): 8192 slots with 256 threads and 512 non-zeros (74 KB of LDS:
+        // two workgroups per CU), then 16384 slots / 1024 non-zeros, then 8192 slots / 4096 non-zeros.
         SKM_PROF(ctx, "k_gram_sparse_big");
-        k_gram_sparse_big<8192, 512, 8, 16, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
+        k_gram_sparse_big<8192, 256, 2, 16, 4><<<skm_grid_cap(ctx, nrows, 2), 256, 0, st>>>(
             d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, d_ent, cap, g_counter, d_start, d_len,
             list1, cnt1, list2, cnt2);
-        // largest table that fits LDS: 16384 slots (8192 neighbours), up to 1024 distinct k-mers
         SKM_HIP(hipMemsetAsync(cnt1, 0, 4, st));
         k_gram_sparse_big<16384, 512, 2, 16, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
             d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, d_ent, cap, g_counter, d_start, d_len,
             list2, cnt2, list1, cnt1);
+        SKM_HIP(hipMemsetAsync(cnt2, 0, 4, st));
+        k_gram_sparse_big<8192, 512, 8, 16, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
+            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, d_ent, cap, g_counter, d_start, d_len,
+            list1, cnt1, list2, cnt2);
     }
     SKM_TRY(skm_check_launch("k_gram_sparse_big"));
     {
@@ -682,7 +688,7 @@ extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrow
         SKM_TRY(skm_ws(ctx, WS_G, sizeof(uint32_t) * 2 * (size_t)HS * (size_t)huge_grid, &p));
         SKM_PROF(ctx, "k_gram_sparse_huge");
         k_gram_sparse_huge<<<huge_grid, 1024, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, d_ent, cap,
-                                                       g_counter, d_start, d_len, list1, cnt1, (uint32_t *)p);
+                                                       g_counter, d_start, d_len, list2, cnt2, (uint32_t *)p);
     }
     SKM_TRY(skm_check_launch("k_gram_sparse_huge"));
     k_count_overflow<<<(unsigned)skm_ceil_div(nrows, 256), 256, 0, st>>>(nrows, d_len, novf);
