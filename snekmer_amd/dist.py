@@ -21,7 +21,7 @@ Two forms of the exchange (`ShardedPipeline(basis=...)`):
 `RcclExchange` is the device implementation over skm_allgatherv / skm_alltoallv.
 """
 import ctypes as C
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -164,9 +164,13 @@ class ShardedPipeline:
     """vectorize the local shard, exchange, then cosine (or top-k) for the local row block."""
 
     def __init__(self, ctx, lut, k: int, exchange, bounds: Sequence[Tuple[int, int]], total_residues: int,
-                 basis: str = "distributed"):
+                 basis: Optional[str] = None):
+        import os
+
         from . import engine
 
+        if basis is None:  # SKM_DIST_BASIS=replicated selects the all-gather-only exchange without a code change
+            basis = os.environ.get("SKM_DIST_BASIS", "distributed")
         if basis not in ("distributed", "replicated"):
             raise ValueError("basis must be 'distributed' or 'replicated'")
         self.engine = engine
