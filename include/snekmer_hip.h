@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SKM_ABI_VERSION 1
+#define SKM_ABI_VERSION 2
 
 #define SKM_OK 0
 #define SKM_E_BADARG (-1)
@@ -254,6 +254,53 @@ int skm_count_dense(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, const 
 int skm_cosine_dense_i8(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim, const int8_t *d_x,
                         const int8_t *d_y, const float *d_xrnorm, const float *d_yrnorm, int mode,
                         float *d_out, int64_t ld);
+
+/* Sparse view of a dense count matrix, the inverse of skm_count_dense / skm_csr_to_dense: per row the
+ * non-zero columns in ascending order with their values, i.e. the (code, count) rows skm_count_csr
+ * gives when column id == k-mer code (rules/learn.smk:359-383 keeps exactly these pairs in its
+ * per-sequence dict).  dtype: 0 = uint16, 1 = uint32, 2 = int8 cells; d_in is [n x ld] row-major.
+ * d_rowptr[n+1]; d_col / d_val need cap_entries slots (SKM_E_OVERFLOW if the matrix holds more
+ * non-zeros); *h_nnz is host-synchronous. */
+int skm_dense_to_csr(skm_ctx *ctx, int64_t n, int64_t ncols, int dtype, const void *d_in, int64_t ld,
+                     int64_t cap_entries, int64_t *d_rowptr, uint32_t *d_col, uint32_t *d_val, int64_t *h_nnz);
+
+/* 1/||row|| (float32; 1.0 for an all-zero row) and optionally the exact squared norms of an int8
+ * matrix [n x kdim] (kdim a multiple of 64, rows zero padded): the norms skm_cosine_dense_i8 takes. */
+int skm_row_norms_i8(skm_ctx *ctx, int64_t n, int64_t kdim, const int8_t *d_in, float *d_rnorm, uint64_t *d_normsq);
+
+/* float64 cosine of real-valued dense feature matrices on the f64 matrix cores, with sklearn's exact
+ * order of operations (rows L2-normalised in float64, zero norms replaced by 1, then the dot products):
+ * sklearn.metrics.pairwise.cosine_similarity / pairwise_distances(metric="cosine") for inputs that are
+ * not counts, e.g. the length-normalised rows of snekmer/utils.py:183-203 fed to
+ * snekmer/score.py:149-172.  X [n x k] (row stride ldx), Y [m x k] (row stride ldy; pass X for the
+ * square case); out [n x ld] float64.  mode as in skm_cosine_csr (the exact-zero diagonal of mode 1
+ * applies only when Y is X). */
+int skm_cosine_dense_f64(skm_ctx *ctx, int64_t n, int64_t m, int64_t k, const double *d_x, int64_t ldx,
+                         const double *d_y, int64_t ldy, int mode, double *d_out, int64_t ld);
+
+/* Checksums of a float32 result block too large to read back (the 40 GB matrix of BASELINE
+ * configs[2]): d_sum[i] = float64 sum of row i, d_nnz[i] = number of its non-zero entries. */
+int skm_matrix_row_stats(skm_ctx *ctx, int64_t n, int64_t m, const float *d_in, int64_t ld, double *d_sum,
+                         uint32_t *d_nnz);
+
+/* ---- apply epilogue fused with the cosine ---------------------------------------------------- */
+/* Replaces rules/apply.smk:278-328 and rules/learn.smk:811-849: cosine_similarity(totals, counts).T
+ * followed by np.argsort(-S, axis=1)[:, :2], without ever storing the N x A score block.
+ * X: CSR rows [row0,row1) of the n query sequences; Y: postings of the m family-total rows over the
+ * same columns (an X entry whose colidx is 0xFFFFFFFF is a column Y does not have and contributes
+ * nothing).  d_xnormsq[n] / d_ynormsq[m]: exact squared norms (skm_row_norms_csr).
+ * Per query row r = i - row0:
+ *   d_idx[2r+{0,1}]    the two best families (score descending, ties towards the lower index;
+ *                      0xFFFFFFFF in the second slot when m == 1)
+ *   d_score[2r+{0,1}]  their cosine in float64: (double)dot / (sqrt(|x|^2) * sqrt(|y|^2)), a zero norm
+ *                      counting as 1 (sklearn's rule), formed from the EXACT integer dot and norms
+ *   d_dot[2r+{0,1}]    those exact dot products (int64)
+ * so Score = d_score[2r], delta = round(d_score[2r] - d_score[2r+1], 2) and the confidence lookup of
+ * rules/apply.smk:325-326 are reproducible on the host from integers alone. */
+int skm_apply_top2(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
+                   const uint32_t *d_xcounts, const uint64_t *d_xnormsq, int64_t m, int64_t ncols,
+                   const uint32_t *d_ycolptr, const uint64_t *d_ypost, const uint64_t *d_ynormsq, int64_t row0,
+                   int64_t row1, uint32_t *d_idx, double *d_score, int64_t *d_dot);
 
 /* ---- multi-GPU (RCCL over xGMI; one context per rank) --------------------------------------- */
 #define SKM_COMM_ID_BYTES 128

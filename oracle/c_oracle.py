@@ -26,6 +26,10 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.orc_count_csr.restype = C.c_int64
         _LIB.orc_basis.restype = C.c_int64
+        _LIB.orc_count_csr_mt.restype = C.c_int64
+        _LIB.orc_basis_mt.restype = C.c_int64
+        _LIB.orc_cosine_all_mt.restype = C.c_double
+        _LIB.orc_max_threads.restype = C.c_int
     return _LIB
 
 
@@ -49,31 +53,95 @@ def kmer_codes(rank, nsym, k, seq, off):
     return codes[: len(seq)], nwin
 
 
-def count_csr(rank, nsym, k, seq, off):
+def host_threads() -> int:
+    """Threads the multi-threaded forms use by default: the OpenMP maximum capped by the CPUs this
+    process may run on (cgroup-limited boxes report all host cores to OpenMP)."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        avail = os.cpu_count() or 1
+    try:  # cgroup v2 quota, if any
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            avail = min(avail, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(avail, int(lib().orc_max_threads())))
+
+
+def count_csr(rank, nsym, k, seq, off, threads=1):
+    """threads=1: the single-threaded restatement; threads=N or 0 (= host_threads()): the OpenMP form
+    (row-parallel, same per-row code, identical output)."""
     n = len(off) - 1
     cap = len(seq) + 1
     rowptr = np.zeros(n + 1, dtype=np.int64)
     codes = np.zeros(cap, dtype=np.uint64)
     counts = np.zeros(cap, dtype=np.uint32)
     first = np.zeros(cap, dtype=np.uint32)
-    nnz = lib().orc_count_csr(
-        _p(rank), nsym, k, _p(seq), _p(off), C.c_int64(n), _p(rowptr), _p(codes), _p(counts), _p(first)
-    )
+    if threads == 1:
+        nnz = lib().orc_count_csr(
+            _p(rank), nsym, k, _p(seq), _p(off), C.c_int64(n), _p(rowptr), _p(codes), _p(counts), _p(first)
+        )
+    else:
+        nnz = lib().orc_count_csr_mt(
+            _p(rank), nsym, k, _p(seq), _p(off), C.c_int64(n), _p(rowptr), _p(codes), _p(counts), _p(first),
+            C.c_int(threads or host_threads()),
+        )
     return rowptr, codes[:nnz].copy(), counts[:nnz].copy(), first[:nnz].copy()
 
 
-def basis(rowptr, codes, counts, first):
+def basis(rowptr, codes, counts, first, threads=1):
     n, nnz = len(rowptr) - 1, len(codes)
     b = np.zeros(nnz + 1, dtype=np.uint64)
     df = np.zeros(nnz + 1, dtype=np.uint32)
     tot = np.zeros(nnz + 1, dtype=np.uint64)
     fk = np.zeros(nnz + 1, dtype=np.uint64)
     col = np.zeros(nnz + 1, dtype=np.uint32)
-    B = lib().orc_basis(
-        _p(codes), _p(counts), _p(first), _p(rowptr), C.c_int64(n), C.c_int64(nnz),
-        _p(b), _p(df), _p(tot), _p(fk), _p(col),
-    )
+    if threads == 1:
+        B = lib().orc_basis(
+            _p(codes), _p(counts), _p(first), _p(rowptr), C.c_int64(n), C.c_int64(nnz),
+            _p(b), _p(df), _p(tot), _p(fk), _p(col),
+        )
+    else:
+        B = lib().orc_basis_mt(
+            _p(codes), _p(counts), _p(first), _p(rowptr), C.c_int64(n), C.c_int64(nnz),
+            _p(b), _p(df), _p(tot), _p(fk), _p(col), C.c_int(threads or host_threads()),
+        )
     return b[:B].copy(), df[:B].copy(), tot[:B].copy(), fk[:B].copy(), col[:nnz].copy()
+
+
+def cosine_all(rowptr, col, val, ncols, threads=0, keep=False, stats=False):
+    """N x N float32 cosine of a CSR count matrix with itself on `threads` threads (0 = host_threads()).
+    keep=False: every row is produced in a per-thread buffer and only the sum of all entries is returned
+    (the timed cpu_baseline form); keep=True also returns the matrix (tests, small n); stats=True
+    returns (total, row sums float64[n], row non-zero counts uint32[n])."""
+    n = len(rowptr) - 1
+    out = np.zeros((n, n), dtype=np.float32) if keep else None
+    rowsum = np.zeros(n, dtype=np.float64) if stats else None
+    rownnz = np.zeros(n, dtype=np.uint32) if stats else None
+    total = lib().orc_cosine_all_mt(
+        C.c_int64(n), _p(np.ascontiguousarray(rowptr, dtype=np.int64)), _p(np.ascontiguousarray(col, dtype=np.uint32)),
+        _p(np.ascontiguousarray(val, dtype=np.uint32)), C.c_int64(ncols), _p(out), _p(rowsum), _p(rownnz),
+        C.c_int(threads or host_threads()),
+    )
+    if stats:
+        return float(total), rowsum, rownnz
+    return (float(total), out) if keep else float(total)
+
+
+def sampled_gram(rowptr, codes, counts, sample_rows, threads=0):
+    """int32 [len(sample_rows), n]: exact dot products of the sampled rows with every row, joined on the
+    k-mer codes themselves (no basis needed)."""
+    n = len(rowptr) - 1
+    sample = np.ascontiguousarray(sample_rows, dtype=np.int64)
+    out = np.zeros((len(sample), n), dtype=np.int32)
+    lib().orc_sampled_gram_mt(
+        C.c_int64(n), _p(np.ascontiguousarray(rowptr, dtype=np.int64)), _p(np.ascontiguousarray(codes, dtype=np.uint64)),
+        _p(np.ascontiguousarray(counts, dtype=np.uint32)), _p(sample), C.c_int64(len(sample)), _p(out),
+        C.c_int(threads or host_threads()),
+    )
+    return out
 
 
 def cosine_rows(xrowptr, xcol, xval, ncols, rows, yrowptr=None, ycol=None, yval=None):

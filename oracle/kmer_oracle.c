@@ -233,3 +233,333 @@ void orc_cosine_rows(int64_t n, const int64_t *xrowptr, const uint32_t *xcol, co
     free(prow);
     free(colptr);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-threaded forms (OpenMP) of the same restatements.  They exist for two reasons only:
+ *   - bench.py's cpu_baseline leg: "sparse CPU baseline on all host cores" (BASELINE.md section 3,
+ *     baseline 2) next to the single-threaded figure;
+ *   - parity tests at BASELINE configs[3] (1 M sequences), which a single thread cannot check in
+ *     the time a test may take.
+ * Results are identical to the single-threaded functions above (tests/test_oracle_golden.py checks
+ * that), because every row / bucket is processed by exactly one thread with the same code.
+ * ---------------------------------------------------------------------------------------------- */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+static int orc_threads(int want)
+{
+    int mx = orc_max_threads();
+    if (want <= 0 || want > mx)
+        want = mx;
+    return want;
+}
+
+/* windows of one sequence -> sorted (code, first position) runs; returns the number of distinct codes.
+ * With codes == NULL only counts. */
+static int64_t orc_row_runs(const uint8_t *rank, int nsym, int k, const uint8_t *seq, int64_t b, int64_t e,
+                            orc_win *buf, uint64_t *codes, uint32_t *counts, uint32_t *firstpos)
+{
+    while (e > b && seq[e - 1] == '*')
+        --e;
+    int64_t w = (e - b) - k + 1, m = 0, nruns = 0;
+    for (int64_t p = 0; p < w; ++p) {
+        uint64_t c = 0;
+        int ok = 1;
+        for (int j = 0; j < k; ++j) {
+            uint8_t r = rank[seq[b + p + j]];
+            if (r == ORC_INVALID) {
+                ok = 0;
+                break;
+            }
+            c = c * (uint64_t)nsym + r;
+        }
+        if (ok) {
+            buf[m].code = c;
+            buf[m].pos = (uint32_t)p;
+            ++m;
+        }
+    }
+    qsort(buf, (size_t)m, sizeof(orc_win), cmp_win);
+    for (int64_t t = 0; t < m;) {
+        int64_t u = t;
+        while (u < m && buf[u].code == buf[t].code)
+            ++u;
+        if (codes) {
+            codes[nruns] = buf[t].code;
+            counts[nruns] = (uint32_t)(u - t);
+            if (firstpos)
+                firstpos[nruns] = buf[t].pos;
+        }
+        ++nruns;
+        t = u;
+    }
+    return nruns;
+}
+
+/* orc_count_csr on `threads` threads (<= 0: all): pass 1 counts the distinct codes of every row, a
+ * serial prefix sum gives rowptr, pass 2 recomputes each row into its final place. */
+int64_t orc_count_csr_mt(const uint8_t *rank, int nsym, int k, const uint8_t *seq, const int64_t *off, int64_t n,
+                         int64_t *rowptr, uint64_t *codes, uint32_t *counts, uint32_t *firstpos, int threads)
+{
+    int64_t maxlen = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (off[i + 1] - off[i] > maxlen)
+            maxlen = off[i + 1] - off[i];
+    threads = orc_threads(threads);
+    (void)threads;
+#pragma omp parallel num_threads(threads)
+    {
+        orc_win *buf = (orc_win *)malloc(sizeof(orc_win) * (size_t)(maxlen + 1));
+#pragma omp for schedule(dynamic, 256)
+        for (int64_t i = 0; i < n; ++i)
+            rowptr[i + 1] = orc_row_runs(rank, nsym, k, seq, off[i], off[i + 1], buf, NULL, NULL, NULL);
+        free(buf);
+    }
+    rowptr[0] = 0;
+    for (int64_t i = 0; i < n; ++i)
+        rowptr[i + 1] += rowptr[i];
+#pragma omp parallel num_threads(threads)
+    {
+        orc_win *buf = (orc_win *)malloc(sizeof(orc_win) * (size_t)(maxlen + 1));
+#pragma omp for schedule(dynamic, 256)
+        for (int64_t i = 0; i < n; ++i)
+            orc_row_runs(rank, nsym, k, seq, off[i], off[i + 1], buf, codes + rowptr[i], counts + rowptr[i],
+                         firstpos ? firstpos + rowptr[i] : NULL);
+        free(buf);
+    }
+    return rowptr[n];
+}
+
+/* orc_basis on `threads` threads: entries are partitioned by the leading bits of the code (stable,
+ * so entry indices stay ascending inside a bucket), every bucket is sorted and numbered by one
+ * thread, and bucket b's columns follow those of buckets < b: the same ascending-code numbering. */
+int64_t orc_basis_mt(const uint64_t *codes, const uint32_t *counts, const uint32_t *firstpos, const int64_t *rowptr,
+                     int64_t n, int64_t nnz, uint64_t *basis, uint32_t *df, uint64_t *total, uint64_t *firstkey,
+                     uint32_t *colidx, int threads)
+{
+    enum { NB = 4096 };
+    threads = orc_threads(threads);
+    (void)threads;
+    uint64_t maxc = 0;
+    for (int64_t e = 0; e < nnz; ++e)
+        if (codes[e] > maxc)
+            maxc = codes[e];
+    int shift = 0;
+    while ((maxc >> shift) >= NB)
+        ++shift;
+    int64_t *bstart = (int64_t *)calloc(NB + 1, sizeof(int64_t));
+    for (int64_t e = 0; e < nnz; ++e)
+        bstart[(codes[e] >> shift) + 1]++;
+    for (int b = 0; b < NB; ++b)
+        bstart[b + 1] += bstart[b];
+    orc_ent *ent = (orc_ent *)malloc(sizeof(orc_ent) * (size_t)(nnz + 1));
+    uint32_t *rowof = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nnz + 1));
+    {
+        int64_t *fill = (int64_t *)malloc(sizeof(int64_t) * NB);
+        memcpy(fill, bstart, sizeof(int64_t) * NB);
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+                rowof[e] = (uint32_t)i;
+                int64_t slot = fill[codes[e] >> shift]++;
+                ent[slot].code = codes[e];
+                ent[slot].idx = e;
+            }
+        free(fill);
+    }
+    int64_t *bcols = (int64_t *)calloc(NB + 1, sizeof(int64_t));
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
+    for (int b = 0; b < NB; ++b) {
+        orc_ent *p = ent + bstart[b];
+        int64_t cnt = bstart[b + 1] - bstart[b], d = 0;
+        qsort(p, (size_t)cnt, sizeof(orc_ent), cmp_ent);
+        for (int64_t t = 0; t < cnt; ++t)
+            d += (t == 0 || p[t].code != p[t - 1].code);
+        bcols[b + 1] = d;
+    }
+    for (int b = 0; b < NB; ++b)
+        bcols[b + 1] += bcols[b];
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
+    for (int b = 0; b < NB; ++b) {
+        const orc_ent *p = ent + bstart[b];
+        int64_t cnt = bstart[b + 1] - bstart[b], B = bcols[b];
+        for (int64_t t = 0; t < cnt;) {
+            int64_t u = t;
+            uint64_t tot = 0;
+            while (u < cnt && p[u].code == p[t].code) {
+                tot += counts[p[u].idx];
+                colidx[p[u].idx] = (uint32_t)B;
+                ++u;
+            }
+            basis[B] = p[t].code;
+            df[B] = (uint32_t)(u - t);
+            total[B] = tot;
+            firstkey[B] = ((uint64_t)rowof[p[t].idx] << 32) | (firstpos ? firstpos[p[t].idx] : 0);
+            ++B;
+            t = u;
+        }
+    }
+    int64_t B = bcols[NB];
+    free(bcols);
+    free(rowof);
+    free(ent);
+    free(bstart);
+    return B;
+}
+
+/* The N x N float32 cosine of a CSR count matrix with itself over `ncols` columns, all rows, on
+ * `threads` threads: the sparse restatement of sklearn's cosine_similarity (exact integer Gram row by
+ * row through the column-major copy, then scaling).  Every output row is PRODUCED in full (zero
+ * background + scaled non-zeros) in a per-thread buffer of m floats; with out == NULL the rows are
+ * not kept (a 100 k x 100 k float32 matrix is 40 GB), only their sum is returned, which is what the
+ * cpu_baseline leg of bench.py times.  With out != NULL row i is stored at out[i * m]; rowsum / rownnz
+ * (optional) receive every row's float64 sum and number of non-zero entries, the checksums the GPU
+ * parity test compares at full size. */
+double orc_cosine_all_mt(int64_t n, const int64_t *rowptr, const uint32_t *col, const uint32_t *val, int64_t ncols,
+                         float *out, double *rowsum, uint32_t *rownnz, int threads)
+{
+    threads = orc_threads(threads);
+    (void)threads;
+    const int64_t nnz = rowptr[n];
+    int64_t *colptr = (int64_t *)calloc((size_t)(ncols + 2), sizeof(int64_t));
+    uint32_t *prow = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nnz + 1));
+    uint32_t *pval = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nnz + 1));
+    double *rnorm = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+    for (int64_t e = 0; e < nnz; ++e)
+        colptr[col[e] + 2]++;
+    for (int64_t c = 0; c < ncols; ++c)
+        colptr[c + 2] += colptr[c + 1];
+    for (int64_t j = 0; j < n; ++j) {
+        double s = 0;
+        for (int64_t e = rowptr[j]; e < rowptr[j + 1]; ++e) {
+            int64_t slot = colptr[col[e] + 1]++;
+            prow[slot] = (uint32_t)j;
+            pval[slot] = val[e];
+            s += (double)val[e] * (double)val[e];
+        }
+        rnorm[j] = s > 0 ? 1.0 / sqrt(s) : 1.0;
+    }
+    double checksum = 0;
+#pragma omp parallel num_threads(threads) reduction(+ : checksum)
+    {
+        int64_t *acc = (int64_t *)calloc((size_t)(n + 1), sizeof(int64_t));
+        uint32_t *touched = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1));
+        float *rowbuf = (float *)malloc(sizeof(float) * (size_t)(n + 1));
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t i = 0; i < n; ++i) {
+            float *dst = out ? out + i * n : rowbuf;
+            memset(dst, 0, sizeof(float) * (size_t)n);
+            int64_t nt = 0;
+            for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+                const int64_t v = val[e];
+                for (int64_t t = colptr[col[e]]; t < colptr[col[e] + 1]; ++t) {
+                    if (acc[prow[t]] == 0)
+                        touched[nt++] = prow[t];
+                    acc[prow[t]] += v * (int64_t)pval[t];
+                }
+            }
+            double s = 0;
+            for (int64_t q = 0; q < nt; ++q) {
+                const uint32_t j = touched[q];
+                const float o = (float)((double)acc[j] * rnorm[i] * rnorm[j]);
+                dst[j] = o;
+                s += o;
+                acc[j] = 0;
+            }
+            if (rowsum)
+                rowsum[i] = s;
+            if (rownnz)
+                rownnz[i] = (uint32_t)nt;
+            checksum += s;
+        }
+        free(rowbuf);
+        free(touched);
+        free(acc);
+    }
+    free(rnorm);
+    free(pval);
+    free(prow);
+    free(colptr);
+    return checksum;
+}
+
+typedef struct {
+    uint64_t code;
+    uint32_t s, v;
+} orc_sent;
+
+static int cmp_sent(const void *x, const void *y)
+{
+    const orc_sent *p = (const orc_sent *)x, *r = (const orc_sent *)y;
+    if (p->code != r->code)
+        return p->code < r->code ? -1 : 1;
+    return p->s < r->s ? -1 : (p->s > r->s);
+}
+
+/* Exact Gram rows of a few sampled rows against ALL rows of a large CSR keyed by CODE (no basis
+ * needed): out[s * n + j] = sum over shared codes of count_s * count_j.  A hash table over the sample
+ * rows' codes is probed once per CSR entry; rows are spread over `threads` threads.  Used by the
+ * parity test of BASELINE configs[3], where building the full basis on the host would take minutes. */
+void orc_sampled_gram_mt(int64_t n, const int64_t *rowptr, const uint64_t *codes, const uint32_t *counts,
+                         const int64_t *sample, int64_t ns, int32_t *out, int threads)
+{
+    threads = orc_threads(threads);
+    (void)threads;
+    int64_t ne = 0;
+    for (int64_t s = 0; s < ns; ++s)
+        ne += rowptr[sample[s] + 1] - rowptr[sample[s]];
+    /* (code, sample, count) entries sorted by code; the table maps a code to its first entry */
+    orc_sent *se = (orc_sent *)malloc(sizeof(orc_sent) * (size_t)(ne + 1));
+    int64_t q = 0;
+    for (int64_t s = 0; s < ns; ++s)
+        for (int64_t e = rowptr[sample[s]]; e < rowptr[sample[s] + 1]; ++e) {
+            se[q].code = codes[e];
+            se[q].s = (uint32_t)s;
+            se[q].v = counts[e];
+            ++q;
+        }
+    qsort(se, (size_t)ne, sizeof(orc_sent), cmp_sent);
+    int64_t tsize = 64;
+    while (tsize < 4 * ne)
+        tsize <<= 1;
+    int64_t *tab = (int64_t *)malloc(sizeof(int64_t) * (size_t)tsize);
+    for (int64_t t = 0; t < tsize; ++t)
+        tab[t] = -1;
+    for (int64_t t = 0; t < ne; ++t) {
+        if (t && se[t].code == se[t - 1].code)
+            continue;
+        uint64_t h = (se[t].code * 0x9E3779B97F4A7C15ull) >> 20;
+        while (tab[h & (uint64_t)(tsize - 1)] >= 0)
+            ++h;
+        tab[h & (uint64_t)(tsize - 1)] = t;
+    }
+    memset(out, 0, sizeof(int32_t) * (size_t)ns * (size_t)n);
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
+    for (int64_t j = 0; j < n; ++j)
+        for (int64_t e = rowptr[j]; e < rowptr[j + 1]; ++e) {
+            const uint64_t c = codes[e];
+            uint64_t h = (c * 0x9E3779B97F4A7C15ull) >> 20;
+            for (;;) {
+                const int64_t t = tab[h & (uint64_t)(tsize - 1)];
+                if (t < 0)
+                    break;
+                if (se[t].code == c) {
+                    for (int64_t u = t; u < ne && se[u].code == c; ++u)
+                        out[(int64_t)se[u].s * n + j] += (int32_t)(se[u].v * counts[e]);
+                    break;
+                }
+                ++h;
+            }
+        }
+    free(tab);
+    free(se);
+}

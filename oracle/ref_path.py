@@ -171,6 +171,28 @@ def hamming_similarity(X) -> np.ndarray:
     return out
 
 
+def apply_epilogue(totals, counts, names: Sequence[str], confidence: Optional[Dict[float, float]] = None):
+    """rules/apply.smk:278-328 (same logic at rules/learn.smk:811-849): cosine of the family totals
+    against the query counts, the two best families per query by ``np.argsort(-S)``, Score = top1,
+    delta = round(top1 - top2, 2) and Confidence = the global table's entry for that delta (NaN when
+    the table has no such key, as ``Series.map`` gives)."""
+    S = cosine_similarity(np.asarray(totals, dtype=np.float64), np.asarray(counts, dtype=np.float64)).T
+    sorted_vals = np.argsort(-S, axis=1)[:, :2]
+    score_rank = np.take_along_axis(S, sorted_vals, axis=1)
+    delta = np.round(score_rank[:, 0] - score_rank[:, 1], 2)
+    out = {
+        "sorted_vals": sorted_vals,
+        "score_rank": score_rank,
+        "Score": score_rank[:, 0],
+        "delta": delta,
+        "Prediction": np.asarray([str(names[i]) for i in sorted_vals[:, 0]]),
+    }
+    if confidence is not None:
+        table = {float(k): float(v) for k, v in confidence.items()}
+        out["Confidence"] = np.asarray([table.get(float(d), np.nan) for d in delta], dtype=np.float64)
+    return out
+
+
 # ----------------------------------------------------------------------------- basis ops
 def basis_transform(basis: Sequence[str], vector, vector_basis: Sequence[str]) -> np.ndarray:
     """snekmer/vectorize.py:54-119 — re-index the columns of `vector` (given in

@@ -85,6 +85,11 @@ _SIGNATURES = {
     "skm_pair_work": (C.c_int, [_p, _i64, _p, C.POINTER(C.c_uint64)]),
     "skm_count_dense": (C.c_int, [_p, _p, C.c_int, C.c_int, _p, _p, _i64, C.c_int, _p, _i64]),
     "skm_cosine_dense_i8": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, C.c_int, _p, _i64]),
+    "skm_dense_to_csr": (C.c_int, [_p, _i64, _i64, C.c_int, _p, _i64, _i64, _p, _p, _p, C.POINTER(_i64)]),
+    "skm_row_norms_i8": (C.c_int, [_p, _i64, _i64, _p, _p, _p]),
+    "skm_cosine_dense_f64": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, C.c_int, _p, _i64]),
+    "skm_matrix_row_stats": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p]),
+    "skm_apply_top2": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p]),
     "skm_comm_unique_id": (C.c_int, [_p]),
     "skm_comm_init": (C.c_int, [_p, C.c_int, C.c_int, _p]),
     "skm_comm_destroy": (C.c_int, [_p]),

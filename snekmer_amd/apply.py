@@ -61,11 +61,64 @@ def row_top2(ctx, scores, n: int, m: int, ld: int) -> Tuple[np.ndarray, np.ndarr
     return idx.download(2 * n).reshape(n, 2), val.download(2 * n).reshape(n, 2)
 
 
-def learn_apply(ctx, csr: engine.CountsCSR, ncols: int, groups: Sequence[int], ngroups: int):
+def apply_top2(ctx, csr: engine.CountsCSR, ncols: int, totals: engine.CountsCSR,
+               row0: int = 0, row1: Optional[int] = None):
+    """The apply epilogue fused with the cosine (skm_apply_top2): for every query row the two
+    best-scoring rows of `totals`, without materialising the N x A score block of
+    rules/apply.smk:282-289.  Returns (idx uint32[rows,2], score float64[rows,2], dot int64[rows,2]);
+    scores are formed in float64 from the exact integer dot products and squared norms, so
+    ``round(score[:,0] - score[:,1], 2)`` is the reference's ``delta`` (apply.smk:320-325)."""
+    row1 = csr.n if row1 is None else row1
+    rows = row1 - row0
+    xsq = engine.row_normsq(ctx, csr.n, csr.rowptr, csr.counts)
+    ysq = engine.row_normsq(ctx, totals.n, totals.rowptr, totals.counts)
+    colptr, post = engine.transpose(ctx, totals.n, totals.nnz, ncols, totals.rowptr, totals.colidx, totals.counts)
+    idx = ctx.empty(max(2 * rows, 1), np.uint32)
+    score = ctx.empty(max(2 * rows, 1), np.float64)
+    dot = ctx.empty(max(2 * rows, 1), np.int64)
+    ctx.call("skm_apply_top2", _i64(csr.n), _p(csr.rowptr.ptr), _p(csr.colidx.ptr), _p(csr.counts.ptr), _p(xsq.ptr),
+             _i64(totals.n), _i64(ncols), _p(colptr.ptr), _p(post.ptr), _p(ysq.ptr), _i64(row0), _i64(row1),
+             _p(idx.ptr), _p(score.ptr), _p(dot.ptr))
+    return (idx.download(2 * rows).reshape(rows, 2), score.download(2 * rows).reshape(rows, 2),
+            dot.download(2 * rows).reshape(rows, 2))
+
+
+def confidence_lookup(delta: np.ndarray, table) -> np.ndarray:
+    """``vals["delta"].map(global_confidence_scores)`` of rules/apply.smk:325-326: the confidence of
+    every (already rounded) delta from the global confidence table, NaN where the table has no such
+    key.  `table` is a mapping or a pandas Series {delta value -> confidence}; keys match by float
+    equality, exactly as ``Series.map`` does."""
+    if hasattr(table, "to_dict"):
+        table = table.to_dict()
+    keys = {float(k): float(v) for k, v in dict(table).items()}
+    return np.asarray([keys.get(float(d), np.nan) for d in np.asarray(delta, dtype=np.float64)], dtype=np.float64)
+
+
+def predict(ctx, csr: engine.CountsCSR, ncols: int, totals: engine.CountsCSR, labels: Optional[Sequence] = None,
+            confidence=None):
+    """rules/apply.smk:312-328 for a batch: Prediction (label of the best family), Score (its cosine),
+    delta = round(top1 - top2, 2) and, given the global confidence table, Confidence."""
+    idx, score, dot = apply_top2(ctx, csr, ncols, totals)
+    top, second = score[:, 0], score[:, 1]
+    delta = np.round(top - second, 2)
+    out = {"top2_index": idx, "top2_score": score, "top2_dot": dot, "Score": top, "delta": delta}
+    if labels is not None:
+        lab = np.asarray(labels, dtype=object)
+        out["Prediction"] = np.asarray([str(lab[i]) for i in idx[:, 0]], dtype=object)
+    if confidence is not None:
+        out["Confidence"] = confidence_lookup(delta, confidence)
+    return out
+
+
+def learn_apply(ctx, csr: engine.CountsCSR, ncols: int, groups: Sequence[int], ngroups: int, materialize: bool = False):
     """Self-evaluation chain of rules/learn.smk: totals per annotation, cosine of every sequence
-    against every annotation, top-2 and delta (rounded to 2 decimals as learn.smk:842/apply.smk:325)."""
+    against every annotation, top-2 and delta (rounded to 2 decimals as learn.smk:842/apply.smk:325).
+    The N x A score block is only produced when `materialize` is set (the save_apply_associations
+    branch of apply.smk:298-301 writes it out)."""
     totals = group_sum(ctx, csr, groups, ngroups)
-    scores, ld = cosine_rows_vs_totals(ctx, csr, ncols, totals)
-    idx, val = row_top2(ctx, scores, csr.n, ngroups, ld)
-    delta = np.round(val[:, 0].astype(np.float64) - val[:, 1].astype(np.float64), 2)
-    return {"totals": totals, "scores": scores, "ld": ld, "top2_index": idx, "top2_score": val, "delta": delta}
+    idx, score, dot = apply_top2(ctx, csr, ncols, totals)
+    out = {"totals": totals, "top2_index": idx, "top2_score": score, "top2_dot": dot,
+           "delta": np.round(score[:, 0] - score[:, 1], 2)}
+    if materialize:
+        out["scores"], out["ld"] = cosine_rows_vs_totals(ctx, csr, ncols, totals)
+    return out

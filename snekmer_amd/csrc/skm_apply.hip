@@ -1,0 +1,365 @@
+// Consumers of the cosine stage that never need the score block itself, and the real-valued form of
+// the cosine.
+//
+// Reference behaviour being replaced:
+//   cosine_similarity(totals, counts).T -> np.argsort(-S, axis=1)[:, :2] -> Score / delta / Prediction
+//                                          snekmer/rules/apply.smk:278-328, rules/learn.smk:811-849
+//   sklearn cosine_similarity / pairwise_distances(metric="cosine") on arbitrary float matrices
+//                                          snekmer/score.py:149-172 (e.g. length-normalised rows of
+//                                          snekmer/utils.py:183-203)
+//
+//   k_apply_top2          workgroup per query row: the row's exact integer dot products with every
+//                         family (row of Y) are accumulated in LDS straight from Y's posting lists, the
+//                         float64 scores dot / (|x| |y|) are formed from those exact integers, and only
+//                         the two best (score desc, column asc) leave the kernel: the N x A block of
+//                         rules/apply.smk:282-289 is never stored.
+//   k_cosine_dense_f64    dense float64 GEMM of row-normalised operands on the f64 matrix cores
+//                         (v_mfma_f64_16x16x4_f64): sklearn semantics (normalise in float64, zero
+//                         norms -> 1, then dot) for feature matrices that are not counts.
+#include "skm_common.h"
+
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+// ------------------------------------------------------------------------------- apply epilogue
+constexpr int ACH = 8192;  // families per LDS pass (64 KiB of int64 accumulators)
+constexpr int ATB = 256;
+
+struct top2 {
+    double v1, v2;
+    long long d1, d2;
+    uint32_t i1, i2;
+};
+
+__device__ __forceinline__ bool better(double a, uint32_t ia, double b, uint32_t ib)
+{
+    return a > b || (a == b && ia < ib);
+}
+
+__device__ __forceinline__ void top2_push(top2 &t, double v, uint32_t i, long long d)
+{
+    if (better(v, i, t.v1, t.i1)) {
+        t.v2 = t.v1, t.i2 = t.i1, t.d2 = t.d1;
+        t.v1 = v, t.i1 = i, t.d1 = d;
+    } else if (better(v, i, t.v2, t.i2)) {
+        t.v2 = v, t.i2 = i, t.d2 = d;
+    }
+}
+
+// d_ynorm[j] = sqrt(normsq) (1 for an all-zero row: sklearn's zero-norm rule), float64
+__global__ void k_norms_f64(int64_t m, const uint64_t *__restrict__ normsq, double *__restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m)
+        out[j] = normsq[j] ? sqrt((double)normsq[j]) : 1.0;
+}
+
+__global__ __launch_bounds__(ATB) void k_apply_top2(const int64_t *__restrict__ xrowptr,
+                                                    const uint32_t *__restrict__ xcolidx,
+                                                    const uint32_t *__restrict__ xcounts,
+                                                    const uint64_t *__restrict__ xnormsq, int64_t m,
+                                                    const uint32_t *__restrict__ ycolptr,
+                                                    const uint64_t *__restrict__ ypost,
+                                                    const double *__restrict__ ynorm, int64_t row0, int64_t nrows,
+                                                    uint32_t *__restrict__ out_idx, double *__restrict__ out_score,
+                                                    long long *__restrict__ out_dot)
+{
+    __shared__ unsigned long long s_acc[ACH];
+    __shared__ top2 s_t[ATB / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int GL = 16;  // lanes sharing one posting list
+    const int grp = tid / GL, gl = tid % GL;
+    for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const int64_t i = row0 + r;
+        const int64_t b = xrowptr[i], e = xrowptr[i + 1];
+        const uint64_t nx = xnormsq[i];
+        const double sx = nx ? sqrt((double)nx) : 1.0;
+        top2 t = {-INFINITY, -INFINITY, 0, 0, NONE, NONE};
+        for (int64_t a0 = 0; a0 < m; a0 += ACH) {
+            const int span = (int)min((int64_t)ACH, m - a0);
+            for (int z = tid; z < span; z += ATB)
+                s_acc[z] = 0ull;
+            __syncthreads();
+            for (int64_t q = b + grp; q < e; q += ATB / GL) {
+                const uint32_t c = xcolidx[q];
+                if (c == NONE)  // a column Y does not have
+                    continue;
+                const unsigned long long v = xcounts[q];
+                const uint32_t pb = ycolptr[c], pe = ycolptr[c + 1];
+                for (uint32_t p = pb + gl; p < pe; p += GL) {
+                    const uint64_t pw = ypost[p];
+                    const int64_t a = (int64_t)(uint32_t)pw - a0;
+                    if (a >= 0 && a < span)
+                        atomicAdd(&s_acc[a], v * (unsigned long long)(pw >> 32));
+                }
+            }
+            __syncthreads();
+            for (int a = tid; a < span; a += ATB) {
+                const long long d = (long long)s_acc[a];
+                const double s = d ? (double)d / (sx * ynorm[a0 + a]) : 0.0;
+                top2_push(t, s, (uint32_t)(a0 + a), d);
+            }
+            __syncthreads();
+        }
+        // wave merge, then the workgroup's four waves
+        for (int o = 32; o > 0; o >>= 1) {
+            top2 u;
+            u.v1 = __shfl_down(t.v1, o), u.v2 = __shfl_down(t.v2, o);
+            u.d1 = __shfl_down(t.d1, o), u.d2 = __shfl_down(t.d2, o);
+            u.i1 = __shfl_down(t.i1, o), u.i2 = __shfl_down(t.i2, o);
+            if (u.i1 != NONE)
+                top2_push(t, u.v1, u.i1, u.d1);
+            if (u.i2 != NONE)
+                top2_push(t, u.v2, u.i2, u.d2);
+        }
+        if (lane == 0)
+            s_t[wid] = t;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < ATB / 64; ++w) {
+                const top2 u = s_t[w];
+                if (u.i1 != NONE)
+                    top2_push(t, u.v1, u.i1, u.d1);
+                if (u.i2 != NONE)
+                    top2_push(t, u.v2, u.i2, u.d2);
+            }
+            out_idx[2 * r] = t.i1;
+            out_idx[2 * r + 1] = t.i2;
+            out_score[2 * r] = t.i1 == NONE ? 0.0 : t.v1;
+            out_score[2 * r + 1] = t.i2 == NONE ? 0.0 : t.v2;
+            out_dot[2 * r] = t.i1 == NONE ? 0 : t.d1;
+            out_dot[2 * r + 1] = t.i2 == NONE ? 0 : t.d2;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------- f64 dense cosine
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// rows scaled to unit L2 norm in float64 (zero norm -> divide by 1), as sklearn.preprocessing.normalize
+__global__ __launch_bounds__(256) void k_normalize_rows_f64(int64_t n, int64_t k, const double *__restrict__ in,
+                                                            int64_t ld_in, double *__restrict__ out, int64_t ld_out)
+{
+    __shared__ double s_part[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const double *src = in + i * ld_in;
+        double s = 0.0;
+        for (int64_t c = tid; c < k; c += 256)
+            s += src[c] * src[c];
+        for (int o = 32; o > 0; o >>= 1)
+            s += __shfl_down(s, o);
+        if (lane == 0)
+            s_part[wid] = s;
+        __syncthreads();
+        const double tot = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        double nrm = sqrt(tot);
+        if (nrm == 0.0)
+            nrm = 1.0;
+        double *dst = out + i * ld_out;
+        for (int64_t c = tid; c < ld_out; c += 256)
+            dst[c] = c < k ? src[c] / nrm : 0.0;
+        __syncthreads();
+    }
+}
+
+// out[i][j] = sum_c X[i][c] * Y[j][c]; X [n x kp], Y [m x kp] row-major, kp a multiple of FK (zero padded).
+// 64 x 64 tile per workgroup, 4 waves of 32 x 32 (2 x 2 tiles of v_mfma_f64_16x16x4_f64).
+constexpr int FM = 64, FN = 64, FK = 16, FROW = FK + 1;  // 17-double rows: conflict-free ds_read_b64 of 16 rows
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cosine_dense_f64(int64_t n, int64_t m, int64_t kp, const double *__restrict__ X,
+                                                          const double *__restrict__ Y, double *__restrict__ out,
+                                                          int64_t ld, int square)
+{
+    __shared__ double s_a[FM * FROW];
+    __shared__ double s_b[FN * FROW];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int64_t row0 = (int64_t)blockIdx.y * FM, col0 = (int64_t)blockIdx.x * FN;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const int sr = tid >> 2, sc = (tid & 3) * 4;  // staging: 64 rows x 16 doubles, 4 doubles per thread
+    const int fr = lane & 15, fk = lane >> 4;
+    for (int64_t k0 = 0; k0 < kp; k0 += FK) {
+        double va[4], vb[4];
+        const int64_t gi = row0 + sr, gj = col0 + sr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            va[u] = gi < n ? X[gi * kp + k0 + sc + u] : 0.0;
+            vb[u] = gj < m ? Y[gj * kp + k0 + sc + u] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s_a[sr * FROW + sc + u] = va[u];
+            s_b[sr * FROW + sc + u] = vb[u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < FK / 4; ++ks) {
+            double fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = s_a[(wr * 32 + t * 16 + fr) * FROW + ks * 4 + fk];
+                fb[t] = s_b[(wc * 32 + t * 16 + fr) * FROW + ks * 4 + fk];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // C/D layout of the f64 shape: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int64_t j = col0 + wc * 32 + b * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = row0 + wr * 32 + a * 16 + (lane >> 4) + 4 * r;
+                if (i < n && j < m) {
+                    double o = acc[a][b][r];
+                    if (MODE == 1) {
+                        o = fmin(fmax(1.0 - o, 0.0), 2.0);
+                        if (square && i == j)  // sklearn zeroes the diagonal only for cosine_distances(X) / (X, X)
+                            o = 0.0;
+                    }
+                    out[i * ld + j] = o;
+                }
+            }
+        }
+}
+
+// Per-row float64 sum and non-zero count of a float32 block: a checksum of a result too large to read
+// back (40 GB at BASELINE configs[2]).  Workgroup per row, 16-byte loads.
+__global__ __launch_bounds__(256) void k_matrix_row_stats(int64_t n, int64_t m, const float *__restrict__ in, int64_t ld,
+                                                          int vec_ok, double *__restrict__ out_sum,
+                                                          uint32_t *__restrict__ out_nnz)
+{
+    __shared__ double s_sum[4];
+    __shared__ uint32_t s_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const float *row = in + i * ld;
+        double s = 0.0;
+        uint32_t c = 0;
+        if (vec_ok) {
+            const int64_t nv = m >> 2;
+            for (int64_t v = tid; v < nv; v += 256) {
+                const float4 w = *reinterpret_cast<const float4 *>(row + 4 * v);
+                s += ((double)w.x + (double)w.y) + ((double)w.z + (double)w.w);
+                c += (w.x != 0.0f) + (w.y != 0.0f) + (w.z != 0.0f) + (w.w != 0.0f);
+            }
+            for (int64_t j = (nv << 2) + tid; j < m; j += 256) {
+                s += (double)row[j];
+                c += row[j] != 0.0f;
+            }
+        } else {
+            for (int64_t j = tid; j < m; j += 256) {
+                s += (double)row[j];
+                c += row[j] != 0.0f;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_down(s, o);
+            c += __shfl_down(c, o);
+        }
+        if (lane == 0) {
+            s_sum[wid] = s;
+            s_cnt[wid] = c;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            out_sum[i] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+            out_nnz[i] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int skm_matrix_row_stats(skm_ctx *ctx, int64_t n, int64_t m, const float *d_in, int64_t ld, double *d_sum,
+                                    uint32_t *d_nnz)
+{
+    SKM_REQUIRE(ctx && n >= 0 && m >= 0 && ld >= m, SKM_E_BADARG, "skm_matrix_row_stats: bad argument");
+    if (n == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_sum && d_nnz && (m == 0 || d_in), SKM_E_BADARG, "skm_matrix_row_stats: null array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    const int vec_ok = (((uintptr_t)d_in & 15) == 0 && ld % 4 == 0) ? 1 : 0;
+    SKM_PROF(ctx, "k_matrix_row_stats");
+    k_matrix_row_stats<<<skm_grid_cap(ctx, n, 16), 256, 0, ctx->stream>>>(n, m, d_in, ld, vec_ok, d_sum, d_nnz);
+    return skm_check_launch("k_matrix_row_stats");
+}
+
+extern "C" int skm_apply_top2(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
+                              const uint32_t *d_xcounts, const uint64_t *d_xnormsq, int64_t m, int64_t ncols,
+                              const uint32_t *d_ycolptr, const uint64_t *d_ypost, const uint64_t *d_ynormsq, int64_t row0,
+                              int64_t row1, uint32_t *d_idx, double *d_score, int64_t *d_dot)
+{
+    SKM_REQUIRE(ctx && n >= 0 && m >= 0 && ncols >= 0, SKM_E_BADARG, "skm_apply_top2: bad argument");
+    SKM_REQUIRE(row0 >= 0 && row0 <= row1 && row1 <= n, SKM_E_BADARG, "skm_apply_top2: bad row range");
+    SKM_REQUIRE(m < ((int64_t)1 << 32) - 1, SKM_E_OVERFLOW, "skm_apply_top2: m >= 2^32");
+    const int64_t nrows = row1 - row0;
+    if (nrows == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_xrowptr && d_xnormsq && d_idx && d_score && d_dot, SKM_E_BADARG, "skm_apply_top2: null array");
+    SKM_REQUIRE(m == 0 || (d_ycolptr && d_ynormsq), SKM_E_BADARG, "skm_apply_top2: null Y array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_J, sizeof(double) * (size_t)(m + 1), &p));
+    double *ynorm = (double *)p;
+    if (m) {
+        k_norms_f64<<<(unsigned)skm_ceil_div(m, 256), 256, 0, ctx->stream>>>(m, d_ynormsq, ynorm);
+        SKM_TRY(skm_check_launch("k_norms_f64"));
+    }
+    SKM_PROF(ctx, "k_apply_top2");
+    k_apply_top2<<<skm_grid_cap(ctx, nrows, 16), ATB, 0, ctx->stream>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xnormsq, m,
+                                                                        d_ycolptr, d_ypost, ynorm, row0, nrows, d_idx,
+                                                                        d_score, (long long *)d_dot);
+    return skm_check_launch("k_apply_top2");
+}
+
+extern "C" int skm_cosine_dense_f64(skm_ctx *ctx, int64_t n, int64_t m, int64_t k, const double *d_x, int64_t ldx,
+                                    const double *d_y, int64_t ldy, int mode, double *d_out, int64_t ld)
+{
+    SKM_REQUIRE(ctx && n >= 0 && m >= 0 && k >= 0 && ldx >= k && ldy >= k, SKM_E_BADARG, "skm_cosine_dense_f64: bad argument");
+    SKM_REQUIRE(ld >= m, SKM_E_BADARG, "skm_cosine_dense_f64: ld < m");
+    SKM_REQUIRE(mode == 0 || mode == 1, SKM_E_BADARG, "skm_cosine_dense_f64: mode must be 0 or 1");
+    if (n == 0 || m == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_x && d_y && d_out, SKM_E_BADARG, "skm_cosine_dense_f64: null array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    const int64_t kp = skm_ceil_div(k > 0 ? k : 1, FK) * FK;
+    const bool same = d_x == d_y && ldx == ldy && n == m;
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_A, sizeof(double) * (size_t)n * (size_t)kp, &p));
+    double *xn = (double *)p, *yn = xn;
+    {
+        SKM_PROF(ctx, "k_normalize_rows_f64");
+        k_normalize_rows_f64<<<skm_grid_cap(ctx, n, 16), 256, 0, ctx->stream>>>(n, k, d_x, ldx, xn, kp);
+        if (!same) {
+            SKM_TRY(skm_ws(ctx, WS_B, sizeof(double) * (size_t)m * (size_t)kp, &p));
+            yn = (double *)p;
+            k_normalize_rows_f64<<<skm_grid_cap(ctx, m, 16), 256, 0, ctx->stream>>>(m, k, d_y, ldy, yn, kp);
+        }
+    }
+    SKM_TRY(skm_check_launch("k_normalize_rows_f64"));
+    dim3 grid((unsigned)skm_ceil_div(m, FN), (unsigned)skm_ceil_div(n, FM));
+    SKM_PROF(ctx, "k_cosine_dense_f64");
+    if (mode == 0)
+        k_cosine_dense_f64<0><<<grid, 256, 0, ctx->stream>>>(n, m, kp, xn, yn, d_out, ld, same ? 1 : 0);
+    else
+        k_cosine_dense_f64<1><<<grid, 256, 0, ctx->stream>>>(n, m, kp, xn, yn, d_out, ld, same ? 1 : 0);
+    return skm_check_launch("k_cosine_dense_f64");
+}

@@ -27,9 +27,12 @@
 //                      (sorted) posting list and adds v*v' for the postings that fall into the
 //                      chunk.  One dependent memory round trip per posting: slow, but general.
 //
-// Environment knobs (diagnostics only): SKM_COSINE_PATH=cursor forces the fallback everywhere;
-// SKM_COSINE_ABLATE / SKM_GRAM_ABLATE select timing-only builds whose RESULTS ARE INVALID
-// (tools/ablate_cosine.py).  Shapes that were measured and rejected are listed in DESIGN.md.
+// Environment knobs of the shipped library select between EXACT kernels only: SKM_COSINE_PATH=cursor
+// forces the fallback everywhere, SKM_COSINE_OVERLAP=1 the blocked two-stream schedule.  The
+// timing-only ablations (SKM_COSINE_ABLATE / SKM_GRAM_ABLATE, results invalid by construction) and
+// the phase stamps exist only in the -DSKM_DIAG build (libsnekmer_hip_diag.so, `make diag`), which
+// tools/ablate_cosine.py loads; the product library does not read those variables.
+// Shapes that were measured and rejected are listed in DESIGN.md.
 //
 // The dense small-basis case (a true dense GEMM) is served by the i8 MFMA kernels in
 // skm_dense.hip instead.
@@ -797,10 +800,11 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     k_cosine_strip<MODE, VEC, 0><<<(unsigned)strips, TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, \
                                                                    d_ypost, d_yrnorm, row0, row1, d_out, ld, fb_list, fb_count)
 
+    uint32_t *fb_list = nullptr, *fb_count = nullptr;
+#ifdef SKM_DIAG
     // Diagnostic builds of the cursor kernel (tools/ablate_cosine.py): results are NOT valid.
     const char *abl_env = getenv("SKM_COSINE_ABLATE");
     const int abl = abl_env ? atoi(abl_env) : 0;
-    uint32_t *fb_list = nullptr, *fb_count = nullptr;
     if (abl >= 1 && abl <= 3 && mode == 0 && vec) {
         SKM_PROF(ctx, "k_cosine_strip");
 #define SKM_CURSOR_ABL(ABL)                                                                                          \
@@ -815,6 +819,7 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
 #undef SKM_CURSOR_ABL
         return skm_check_launch("k_cosine_strip");
     }
+#endif
     const char *path_env = getenv("SKM_COSINE_PATH");  // "cursor" forces the fallback kernel everywhere
     if (path_env && strcmp(path_env, "cursor") == 0) {
         SKM_PROF(ctx, "k_cosine_strip");
@@ -849,8 +854,12 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     constexpr int MAXB = 16;  // row blocks of the overlapped schedule (one overflow counter each)
     SKM_HIP(hipMemsetAsync(g_counter, 0, 16 + 4 * MAXB, st));
     k_set_u64<<<1, 1, 0, st>>>(g_counter, fixed_ent);
+#ifdef SKM_DIAG
     const char *gabl_env = getenv("SKM_GRAM_ABLATE");  // diagnostic builds of k_gram_sparse (1, 2, 4: results NOT valid)
     const int gabl = gabl_env ? atoi(gabl_env) : 0;
+#else
+    constexpr int gabl = 0;
+#endif
 
     // Schedule.  By default the three kernels run back to back on the context's stream.
     // SKM_COSINE_OVERLAP=1 selects a blocked schedule for large outputs: the rows are cut into 8
@@ -886,6 +895,7 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     k_gram_sparse<GABL, 1, 2048, 256, 2, 32, 2><<<(unsigned)bn, 256, 0, gs>>>(                                       \
         d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0 + b0, row0 + b1, SLOT, b0, g_ent, cap_ent, g_counter, \
         g_start + b0, g_len + b0, b_over_list, b_over_count)
+#ifdef SKM_DIAG
             if (gabl == 1)
                 SKM_GRAM(1);
             else if (gabl == 2)
@@ -897,6 +907,7 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
                 SKM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gram_phase_ticks), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice, st));
                 SKM_GRAM(3);
             } else
+#endif
                 SKM_GRAM(0);
 #undef SKM_GRAM
         }
@@ -946,8 +957,9 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     return skm_check_launch("k_cosine_strip");
 }
 
+#ifdef SKM_DIAG
 // Diagnostic: per-phase shader-clock ticks summed over the workgroups of the last k_gram_sparse
-// launch made with SKM_GRAM_ABLATE=3 (tools/ablate_cosine.py).  Not part of the public header.
+// launch made with SKM_GRAM_ABLATE=3 (tools/ablate_cosine.py).  Diagnostic library only.
 extern "C" int skm_debug_gram_phases(skm_ctx *ctx, unsigned long long *h_ticks8)
 {
     SKM_REQUIRE(ctx && h_ticks8, SKM_E_BADARG, "skm_debug_gram_phases: bad argument");
@@ -955,3 +967,4 @@ extern "C" int skm_debug_gram_phases(skm_ctx *ctx, unsigned long long *h_ticks8)
     SKM_HIP(hipMemcpyFromSymbol(h_ticks8, HIP_SYMBOL(g_gram_phase_ticks), 8 * sizeof(unsigned long long)));
     return SKM_OK;
 }
+#endif

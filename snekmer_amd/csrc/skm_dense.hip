@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <rocprim/rocprim.hpp>
+
 #include "skm_common.h"
 
 namespace {
@@ -387,6 +389,123 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v3(int64_t n, int64_t m
     }
 }
 
+
+// ------------------------------------------------------------------------------- dense -> CSR
+// Sparse view of a dense count matrix (the inverse of k_count_dense / k_csr_to_dense).  A workgroup of
+// four waves owns a row; wave w owns the contiguous quarter [w * seg, (w + 1) * seg) of its columns, so
+// the non-zeros of a row come out in ascending column order without any cross-wave ordering step:
+// pass 1 counts the non-zeros of every (row, quarter), a scan over those counts gives every quarter's
+// position in the output, pass 2 writes (column, value) pairs, each wave numbering its own with a
+// ballot prefix.  Rows are read with 16-byte loads when the layout allows it.
+template <typename CELL>
+__device__ __forceinline__ uint32_t cell_value(CELL c)
+{
+    return (uint32_t)c;
+}
+
+template <typename CELL, bool WRITE>
+__global__ __launch_bounds__(256) void k_dense_to_csr(int64_t n, int64_t ncols, const CELL *__restrict__ in, int64_t ld,
+                                                      int vec_ok, int64_t *__restrict__ seg_pos,
+                                                      uint32_t *__restrict__ out_col, uint32_t *__restrict__ out_val)
+{
+    constexpr int PER = 16 / (int)sizeof(CELL);  // cells per 16-byte load
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // quarter boundaries on multiples of PER so that vector loads stay aligned
+    const int64_t seg = ((ncols + 3) / 4 + PER - 1) / PER * PER;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const CELL *row = in + i * ld;
+        const int64_t c0 = min((int64_t)wid * seg, ncols), c1 = min(c0 + seg, ncols);
+        int64_t pos = WRITE ? seg_pos[i * 4 + wid] : 0;
+        uint32_t count = 0;
+        for (int64_t base = c0; base < c1; base += 64 * PER) {
+            const int64_t c = base + (int64_t)lane * PER;
+            CELL v[PER];
+            if (vec_ok && c + PER <= c1) {
+                const uint4 w = *reinterpret_cast<const uint4 *>(row + c);
+                *reinterpret_cast<uint4 *>(v) = w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < PER; ++u)
+                    v[u] = c + u < c1 ? row[c + u] : CELL(0);
+            }
+            uint32_t mine = 0;
+#pragma unroll
+            for (int u = 0; u < PER; ++u)
+                mine += v[u] != CELL(0);
+            if (!WRITE) {
+                count += mine;
+            } else if (__any(mine != 0)) {
+                // exclusive wave scan of the per-lane counts
+                uint32_t incl = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = __shfl_up(incl, o);
+                    if (lane >= o)
+                        incl += up;
+                }
+                int64_t at = pos + (incl - mine);
+#pragma unroll
+                for (int u = 0; u < PER; ++u)
+                    if (v[u] != CELL(0)) {
+                        out_col[at] = (uint32_t)(c + u);
+                        out_val[at] = cell_value(v[u]);
+                        ++at;
+                    }
+                pos += __shfl(incl, 63);
+            }
+        }
+        if (!WRITE) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                count += __shfl_down(count, o);
+            if (lane == 0)
+                seg_pos[i * 4 + wid] = (int64_t)count;
+        }
+    }
+}
+
+__global__ void k_rowptr_from_segments(int64_t n, const int64_t *__restrict__ seg_pos, int64_t *__restrict__ rowptr)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n)
+        rowptr[i] = seg_pos[i * 4];
+}
+
+// 1/||row|| of an int8 matrix (and optionally the exact squared norms): wave per row, 16 bytes per lane.
+__global__ __launch_bounds__(256) void k_row_norms_i8(int64_t n, int64_t kdim, const int8_t *__restrict__ in,
+                                                      float *__restrict__ rnorm, uint64_t *__restrict__ normsq)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const int8_t *row = in + i * kdim;
+        unsigned long long s = 0;
+        for (int64_t c = (int64_t)lane * 16; c < kdim; c += 64 * 16) {  // kdim is a multiple of 64
+            const uint4 w = *reinterpret_cast<const uint4 *>(row + c);
+            const uint32_t q[4] = {w.x, w.y, w.z, w.w};
+            uint32_t acc = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int v = (int)(int8_t)(q[u] >> (8 * bb));
+                    acc += (uint32_t)(v * v);
+                }
+            s += acc;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            s += __shfl_down(s, o);
+        if (lane == 0) {
+            if (normsq)
+                normsq[i] = s;
+            if (rnorm)
+                rnorm[i] = s ? (float)(1.0 / sqrt((double)s)) : 1.0f;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int skm_count_dense(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, const uint8_t *d_seq,
@@ -476,4 +595,80 @@ extern "C" int skm_cosine_dense_i8(skm_ctx *ctx, int64_t n, int64_t m, int64_t k
             k_cosine_dense_i8<1><<<grid, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
     }
     return skm_check_launch("k_cosine_dense_i8");
+}
+
+extern "C" int skm_dense_to_csr(skm_ctx *ctx, int64_t n, int64_t ncols, int dtype, const void *d_in, int64_t ld,
+                                int64_t cap_entries, int64_t *d_rowptr, uint32_t *d_col, uint32_t *d_val, int64_t *h_nnz)
+{
+    SKM_REQUIRE(ctx && n >= 0 && ncols >= 0 && ld >= ncols && cap_entries >= 0 && d_rowptr && h_nnz, SKM_E_BADARG,
+                "skm_dense_to_csr: bad argument");
+    SKM_REQUIRE(dtype >= 0 && dtype <= 2, SKM_E_BADARG, "skm_dense_to_csr: dtype must be 0 (uint16), 1 (uint32) or 2 (int8)");
+    SKM_REQUIRE(ncols < ((int64_t)1 << 32) - 1, SKM_E_OVERFLOW, "skm_dense_to_csr: ncols >= 2^32");
+    SKM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    *h_nnz = 0;
+    if (n == 0 || ncols == 0) {
+        SKM_HIP(hipMemsetAsync(d_rowptr, 0, sizeof(int64_t) * (size_t)(n + 1), st));
+        return SKM_OK;
+    }
+    SKM_REQUIRE(d_in, SKM_E_BADARG, "skm_dense_to_csr: null matrix");
+    const size_t cell = dtype == 0 ? 2 : (dtype == 1 ? 4 : 1);
+    const int vec_ok = (((uintptr_t)d_in & 15) == 0 && ((size_t)ld * cell) % 16 == 0) ? 1 : 0;
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_H, sizeof(int64_t) * (size_t)(4 * n + 1), &p));
+    int64_t *seg = (int64_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_I, sizeof(int64_t) * (size_t)(4 * n + 1), &p));
+    int64_t *seg_pos = (int64_t *)p;
+    SKM_HIP(hipMemsetAsync(seg + 4 * n, 0, sizeof(int64_t), st));
+    const int grid = skm_grid_cap(ctx, n, 16);
+#define SKM_D2C(WRITE, SEG)                                                                                              \
+    do {                                                                                                                 \
+        if (dtype == 0)                                                                                                  \
+            k_dense_to_csr<uint16_t, WRITE><<<grid, 256, 0, st>>>(n, ncols, (const uint16_t *)d_in, ld, vec_ok, SEG, d_col, d_val); \
+        else if (dtype == 1)                                                                                             \
+            k_dense_to_csr<uint32_t, WRITE><<<grid, 256, 0, st>>>(n, ncols, (const uint32_t *)d_in, ld, vec_ok, SEG, d_col, d_val); \
+        else                                                                                                             \
+            k_dense_to_csr<uint8_t, WRITE><<<grid, 256, 0, st>>>(n, ncols, (const uint8_t *)d_in, ld, vec_ok, SEG, d_col, d_val);   \
+    } while (0)
+    {
+        SKM_PROF(ctx, "k_dense_to_csr_count");
+        SKM_D2C(false, seg);
+    }
+    SKM_TRY(skm_check_launch("k_dense_to_csr_count"));
+    {
+        size_t tmp = 0;
+        SKM_HIP(rocprim::exclusive_scan(nullptr, tmp, seg, seg_pos, (int64_t)0, (size_t)(4 * n + 1), rocprim::plus<int64_t>(), st));
+        void *t;
+        SKM_TRY(skm_ws(ctx, WS_ROCPRIM, tmp, &t));
+        SKM_HIP(rocprim::exclusive_scan(t, tmp, seg, seg_pos, (int64_t)0, (size_t)(4 * n + 1), rocprim::plus<int64_t>(), st));
+    }
+    k_rowptr_from_segments<<<(unsigned)skm_ceil_div(n + 1, 256), 256, 0, st>>>(n, seg_pos, d_rowptr);
+    SKM_TRY(skm_check_launch("k_rowptr_from_segments"));
+    int64_t *h = (int64_t *)ctx->h_pinned;
+    SKM_HIP(hipMemcpyAsync(h, seg_pos + 4 * n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    SKM_HIP(hipStreamSynchronize(st));
+    *h_nnz = *h;
+    SKM_REQUIRE(*h <= cap_entries, SKM_E_OVERFLOW, "skm_dense_to_csr: %lld non-zeros exceed cap_entries %lld", (long long)*h,
+                (long long)cap_entries);
+    if (*h == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_col && d_val, SKM_E_BADARG, "skm_dense_to_csr: null output arrays");
+    {
+        SKM_PROF(ctx, "k_dense_to_csr_write");
+        SKM_D2C(true, seg_pos);
+    }
+#undef SKM_D2C
+    return skm_check_launch("k_dense_to_csr_write");
+}
+
+extern "C" int skm_row_norms_i8(skm_ctx *ctx, int64_t n, int64_t kdim, const int8_t *d_in, float *d_rnorm, uint64_t *d_normsq)
+{
+    SKM_REQUIRE(ctx && n >= 0 && kdim >= 0 && kdim % 64 == 0, SKM_E_BADARG, "skm_row_norms_i8: bad argument (kdim must be a multiple of 64)");
+    if (n == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_in && ((uintptr_t)d_in & 15) == 0, SKM_E_BADARG, "skm_row_norms_i8: matrix must be 16-byte aligned");
+    SKM_HIP(hipSetDevice(ctx->device));
+    SKM_PROF(ctx, "k_row_norms_i8");
+    k_row_norms_i8<<<skm_grid_cap(ctx, skm_ceil_div(n, 4), 16), 256, 0, ctx->stream>>>(n, kdim, d_in, d_rnorm, d_normsq);
+    return skm_check_launch("k_row_norms_i8");
 }

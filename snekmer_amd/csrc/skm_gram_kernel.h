@@ -19,8 +19,10 @@
 #pragma once
 #include <type_traits>
 
-// diagnostic only (GABL == 3): summed shader-clock ticks per phase over all workgroups
+#ifdef SKM_DIAG
+// diagnostic build only (GABL == 3): summed shader-clock ticks per phase over all workgroups
 __device__ unsigned long long g_gram_phase_ticks[8];
+#endif
 
 constexpr uint32_t G_OVERFLOW = 0xFFFFFFFFu;
 constexpr uint32_t G_SINGLETON = 0xFFFFFFFFu;  // colidx of a k-mer that occurs in one row only
@@ -66,12 +68,17 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     const int rows = (int)min((int64_t)GR, row1 - i0);
     unsigned long long stamp = 0;
     auto phase = [&](int idx) {
+#ifdef SKM_DIAG
         if (GABL == 3 && tid == 0) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             if (idx >= 0)
                 atomicAdd(&g_gram_phase_ticks[idx], now - stamp);
             stamp = now;
         }
+#else
+        (void)idx;
+        (void)stamp;
+#endif
     };
     phase(-1);
     // rows this kernel cannot hold are flagged (and listed for the large-table pass)

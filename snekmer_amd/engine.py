@@ -188,6 +188,33 @@ def row_norms(ctx, n: int, rowptr, counts, out=None) -> _hip.DeviceArray:
     return rn
 
 
+def row_normsq(ctx, n: int, rowptr, counts) -> _hip.DeviceArray:
+    """Exact squared row norms (uint64) of a CSR count matrix."""
+    nsq = ctx.empty(max(n, 1), np.uint64)
+    ctx.call("skm_row_norms_csr", _i64(n), _ptr(rowptr), _ptr(counts), _ptr(None), _ptr(nsq))
+    return nsq
+
+
+def row_norms_i8(ctx, n: int, kdim: int, mat, out=None) -> _hip.DeviceArray:
+    """1/||row|| of an int8 matrix [n x kdim] (the operand layout of cosine_dense_i8)."""
+    rn = out if out is not None and out.size >= max(n, 1) else ctx.empty(max(n, 1) + 4, np.float32)
+    ctx.call("skm_row_norms_i8", _i64(n), _i64(kdim), _ptr(mat), _ptr(rn), _ptr(None))
+    return rn
+
+
+def dense_to_csr(ctx, dense, n: int, ncols: int, ld: int, cap_entries: int) -> CountsCSR:
+    """Sparse view of a dense count matrix (uint16 / uint32 / int8 cells): CountsCSR whose `codes` are
+    the non-zero column ids (ascending per row) and `counts` their values (skm_dense_to_csr)."""
+    code = {np.dtype(np.uint16): 0, np.dtype(np.uint32): 1, np.dtype(np.int8): 2}[np.dtype(dense.dtype)]
+    rowptr = ctx.empty(n + 1, np.int64)
+    col = ctx.empty(max(cap_entries, 1), np.uint32)
+    val = ctx.empty(max(cap_entries, 1), np.uint32)
+    nnz = _i64(0)
+    ctx.call("skm_dense_to_csr", _i64(n), _i64(ncols), code, _ptr(dense), _i64(ld), _i64(cap_entries), _ptr(rowptr),
+             _ptr(col), _ptr(val), C.byref(nnz))
+    return CountsCSR(ctx, n, int(nnz.value), 32, rowptr, col, val, None)
+
+
 def transpose(ctx, n: int, nnz: int, ncols: int, rowptr, colidx, counts):
     colptr = ctx.empty(ncols + 1, np.uint32)
     post = ctx.empty(max(nnz, 1), np.uint64)
@@ -230,6 +257,14 @@ def count_dense(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int, dtype=np.uint16,
     ctx.call("skm_count_dense", _ptr(lut.rank), lut.nsym, k, _ptr(batch.d_seq), _ptr(batch.d_off), _i64(batch.n), code,
              _ptr(out), _i64(ld))
     return out
+
+
+def matrix_row_stats(ctx, mat, n: int, m: int, ld: int):
+    """(float64 row sums, uint32 non-zero counts) of a float32 block resident on the device."""
+    d_sum = ctx.empty(max(n, 1), np.float64)
+    d_nnz = ctx.empty(max(n, 1), np.uint32)
+    ctx.call("skm_matrix_row_stats", _i64(n), _i64(m), _ptr(mat), _i64(ld), _ptr(d_sum), _ptr(d_nnz))
+    return d_sum.download(n), d_nnz.download(n)
 
 
 def csr_max_count(ctx, csr: CountsCSR) -> int:

@@ -2,9 +2,14 @@
 
 ``connection_matrix_from_features`` keeps the reference signature (snekmer/score.py:149-172);
 ``cosine_similarity`` is the drop-in for the ``sklearn.metrics.pairwise.cosine_similarity`` calls
-at rules/apply.smk:282-284, rules/learn.smk:821-823 and rules/evaluate.smk:434-436.  Both take
-count matrices (non-negative integers), which is what those call sites pass; other inputs are
-rejected loudly rather than routed to a CPU path.
+at rules/apply.smk:282-284, rules/learn.smk:821-823 and rules/evaluate.smk:434-436 (ndarrays,
+DataFrames or scipy sparse matrices in, float64 ndarray out, as sklearn).
+
+Three device paths, all exact in the sense the reference needs (|error| <= 1e-5, in practice far less):
+count matrices (non-negative integers, what the rule call sites pass) take the exact-integer sparse
+Gram or, for small dense bases, the i8 MFMA GEMM, both with float32 scaling; any other real-valued
+matrix (e.g. the length-normalised rows of snekmer/utils.py:183-203) takes a float64 GEMM on the
+f64 matrix cores with sklearn's own order of operations.  There is no CPU path.
 """
 from typing import Optional
 
@@ -34,10 +39,7 @@ def _as_count_csr(ctx, X):
         shape = A.shape
     data = np.asarray(data)
     if data.size and (np.any(data < 0) or np.any(data != np.floor(data))):
-        raise NotImplementedError(
-            "snekmer_amd cosine kernels take k-mer count matrices (non-negative integers); "
-            "got non-integer or negative features"
-        )
+        raise ValueError("internal: real-valued features must take the float64 path")
     if data.size and data.max() >= 2**28:
         raise OverflowError("counts >= 2^28 are unsupported")
     csr = engine.CountsCSR(
@@ -82,39 +84,109 @@ def _try_dense_i8(ctx, X, Y, mode, force=False):
 
     dx, _ = upload(X)
     n = X.shape[0]
-    xr = _dense_row_norms(ctx, dx, n, kdim)
+    xr = engine.row_norms_i8(ctx, n, kdim, dx)  # straight from the int8 operand (skm_row_norms_i8)
     if Y is None:
         dy, yr, m = dx, xr, n
     else:
         dy, _ = upload(Y)
         m = Y.shape[0]
-        yr = _dense_row_norms(ctx, dy, m, kdim)
+        yr = engine.row_norms_i8(ctx, m, kdim, dy)
     ld = (m + 3) // 4 * 4
     out = engine.cosine_dense_i8(ctx, n, m, kdim, dx, dy, xr, yr, mode=mode, ld=ld)
     return out.download().reshape(max(n, 1), max(ld, 1))[:n, :m]
 
 
-def _dense_row_norms(ctx, d_mat, n, kdim):
-    """1/||row|| of an int8 matrix: the Gram kernel itself gives the exact squared norms on its
-    diagonal blocks, but a CSR view is cheaper: reuse skm_row_norms_csr on a one-entry-per-cell CSR."""
+def _plain(M):
+    """DataFrame -> ndarray (the rule call sites pass DataFrames, rules/apply.smk:282-284); scipy sparse
+    and ndarrays pass through."""
+    try:
+        import scipy.sparse as sp
+
+        if sp.issparse(M):
+            return M
+    except Exception:  # pragma: no cover
+        pass
+    if hasattr(M, "to_numpy"):
+        return M.to_numpy()
+    return np.asarray(M)
+
+
+def _values(M):
+    return M.data if hasattr(M, "tocsr") else M
+
+
+def _is_count_matrix(M) -> bool:
+    v = np.asarray(_values(M))
+    if v.dtype == bool or v.size == 0:
+        return True
+    if v.dtype.kind in "ui":
+        return bool(v.min() >= 0)
+    if v.dtype.kind != "f":
+        return False
+    return bool(np.all(np.isfinite(v)) and v.min() >= 0 and np.all(v == np.floor(v)))
+
+
+F64_MAX_ELEMS = 1 << 31  # dense float64 operands above 16 GiB are refused rather than silently densified
+
+
+def _cosine_f64(ctx, X, Y, mode):
+    """Real-valued features: float64 GEMM of row-normalised operands (skm_cosine_dense_f64)."""
     import ctypes as C
 
-    rowptr = ctx.to_device(np.arange(n + 1, dtype=np.int64) * kdim)
-    counts = ctx.empty(max(n * kdim, 1), np.uint32)
-    ctx.call("skm_widen_i8_u32", C.c_int64(n * kdim), C.c_void_p(d_mat.ptr), C.c_void_p(counts.ptr))
-    return engine.row_norms(ctx, n, rowptr, counts)
+    def dense(M):
+        if hasattr(M, "toarray"):
+            if M.shape[0] * M.shape[1] > F64_MAX_ELEMS:
+                raise NotImplementedError("real-valued sparse features this large are not supported: densify in blocks")
+            M = M.toarray()
+        A = np.ascontiguousarray(M, dtype=np.float64)
+        if A.ndim != 2:
+            raise ValueError("expected a 2-D feature matrix")
+        if not np.all(np.isfinite(A)):
+            raise ValueError("Input contains NaN or infinity.")
+        return A
+
+    A = dense(X)
+    B = A if Y is None else dense(Y)
+    if A.shape[1] != B.shape[1]:
+        raise ValueError(
+            f"Incompatible dimension for X and Y matrices: X.shape[1] == {A.shape[1]} while Y.shape[1] == {B.shape[1]}"
+        )
+    n, k = A.shape
+    m = B.shape[0]
+    if n == 0 or m == 0:
+        return np.zeros((n, m), dtype=np.float64)
+    dx = ctx.to_device(A if A.size else np.zeros(1))
+    dy = dx if B is A else ctx.to_device(B if B.size else np.zeros(1))
+    out = ctx.empty((n, max(m, 1)), np.float64)
+    ctx.call("skm_cosine_dense_f64", C.c_int64(n), C.c_int64(m), C.c_int64(k), C.c_void_p(dx.ptr), C.c_int64(k),
+             C.c_void_p(dy.ptr), C.c_int64(k), mode, C.c_void_p(out.ptr), C.c_int64(m))
+    return out.download().reshape(n, m)
 
 
-def cosine_similarity(X, Y=None, mode: int = 0, ctx=None, path: str = "auto") -> np.ndarray:
-    """Cosine similarity between the rows of X and the rows of Y (Y=None: X with itself).
-    float32 result [n_x, n_y]; exact integer dot products scaled in float32 (|err| <= ~3e-7).
-    `path`: "auto" picks the i8 MFMA GEMM for dense ndarrays over a small basis with counts <= 127
-    and the sparse kernels otherwise; "sparse" / "dense" force one."""
+def cosine_similarity(X, Y=None, mode: int = 0, ctx=None, path: str = "auto", dtype=np.float64) -> np.ndarray:
+    """Cosine similarity between the rows of X and the rows of Y (Y=None: X with itself), [n_x, n_y],
+    float64 like sklearn's (pass dtype=np.float32 to keep the device's float32 block of the count
+    paths without the widening copy).
+    Count matrices: exact integer dot products scaled in float32 (|err| <= ~3e-7); `path` "auto" picks
+    the i8 MFMA GEMM for dense ndarrays over a small basis with counts <= 127 and the sparse kernels
+    otherwise, "sparse" / "dense" force one.  Any other real-valued input: float64 on the f64 matrix
+    cores (path "f64"; |err| ~1e-15)."""
     from . import _hip
 
     ctx = ctx or _hip.default_context()
-    if path not in ("auto", "sparse", "dense"):
-        raise ValueError("path must be 'auto', 'sparse' or 'dense'")
+    if path not in ("auto", "sparse", "dense", "f64"):
+        raise ValueError("path must be 'auto', 'sparse', 'dense' or 'f64'")
+    X = _plain(X)
+    Y = None if Y is None else _plain(Y)
+    counts = _is_count_matrix(X) and (Y is None or _is_count_matrix(Y))
+    if path == "f64" or (path == "auto" and not counts):
+        return _cosine_f64(ctx, X, Y, mode).astype(dtype, copy=False)
+    if not counts:
+        raise ValueError(f"path={path!r} takes count matrices (non-negative integers); use path='f64' or 'auto'")
+    return _cosine_counts(ctx, X, Y, mode, path).astype(dtype, copy=False)
+
+
+def _cosine_counts(ctx, X, Y, mode, path):
     if path != "sparse":
         dense = _try_dense_i8(ctx, X, Y, mode, force=path == "dense")
         if dense is not None:

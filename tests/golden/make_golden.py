@@ -385,7 +385,118 @@ def main(ref_root):
         tfm_default=U.to_feature_matrix([list(r) for r in X]),
     )
     print(json.dumps(summary, indent=1))
+    extra(ref_root)
+
+
+def apply_rule(pd, cosine_similarity, totals_df, counts_df, conf_csv_path):
+    """rules/apply.smk:278-328 around the real sklearn / pandas calls: cosine of the family totals
+    against the query counts, top-2 by argsort, Score / delta / Prediction / Confidence."""
+    cosine_df = cosine_similarity(totals_df, counts_df).T
+    kct = pd.DataFrame(cosine_df, columns=totals_df.index, index=counts_df.index)
+    gcs = pd.read_csv(str(conf_csv_path))
+    gcs.index = gcs[gcs.columns[0]]
+    gcs = gcs.iloc[:, 1:]
+    gcs = gcs[gcs.columns[0]].squeeze()
+    score_rank = []
+    sorted_vals = np.argsort(-kct.values, axis=1)[:, :2]
+    for i, item in enumerate(sorted_vals):
+        # apply.smk:315-319 writes columns[[item]] (a 1 x 2 index, rejected by pandas >= 2): the two
+        # columns `item` of row i
+        score_rank.append((kct[kct.columns[item]][i : i + 1]).values.tolist()[0])
+    delta = [score[0] - score[1] for score in score_rank]
+    top_score = [score[0] for score in score_rank]
+    vals = pd.DataFrame({"delta": delta})
+    # apply.smk:318 indexes the column Index with the 2-D array, which pandas >= 2 rejects; older
+    # pandas returned the 2-D label array that indexing the labels as an ndarray gives
+    predictions = pd.DataFrame(np.asarray(kct.columns)[sorted_vals][:, :1])
+    predictions.columns = ["Prediction"]
+    predictions = predictions.astype(str)
+    vals = vals.round(decimals=2)
+    vals["Confidence"] = vals["delta"].map(gcs)
+    return dict(
+        sorted_vals=sorted_vals.astype(np.int64),
+        score_rank=np.asarray(score_rank, dtype=np.float64),
+        Score=np.asarray(top_score, dtype=np.float64),
+        delta=vals["delta"].to_numpy(dtype=np.float64),
+        Confidence=vals["Confidence"].to_numpy(dtype=np.float64),
+        Prediction=predictions["Prediction"].to_numpy(dtype=str),
+    )
+
+
+def extra(ref_root):
+    """G12 (apply epilogue incl. the confidence lookup) and G13 (real-valued feature matrices)."""
+    import tempfile
+
+    import pandas as pd
+    from sklearn.metrics.pairwise import cosine_similarity
+
+    A, V, S, U = import_reference(ref_root)
+    if "red6" not in A.ALPHABETS:
+        A.ALPHABETS["red6"] = dict(RED6)
+        A.FULL_ALPHABETS["red6"] = {r: c for grp, c in RED6.items() if grp != "_keys" for r in grp}
+    from snekmer_amd.synth import synth_families, to_records
+
+    # the global confidence table in the format rules/learn.smk's evaluate step writes
+    # (index "Difference" 0.00 .. 1.00, columns confidence / weight / sum)
+    diffs = [round(x * 0.01, 2) for x in range(0, 101)]
+    conf = pd.DataFrame(
+        {"confidence": [round(0.35 + 0.65 * (1 - np.exp(-6 * d)), 6) for d in diffs], "weight": [5000] * 101,
+         "sum": [int(400 * np.exp(-3 * d)) for d in diffs]},
+        index=pd.Index(diffs, name="Difference"),
+    )
+    conf = conf.drop(index=[0.57, 0.93])  # holes: Series.map then yields NaN
+    tmp = tempfile.mkdtemp()
+    conf_path = os.path.join(tmp, "global-confidence-scores.csv")
+    conf.to_csv(conf_path)
+    conf_text = open(conf_path).read()
+
+    for alphabet, k, idx, fam_size in (("standard", 12, 2, 16), ("hydro", 14, 7, 8), ("solvacc", 8, 8, 16)):
+        res, off, fam = synth_families(256, 300, family=fam_size, seed=20250523 + idx)
+        recs = to_records(res, off)
+        out = run_rule(V, A, recs, alphabet, k)
+        counts = run_counts(out["seqs"], out["kmerlist"])
+        nfam = int(fam.max()) + 1
+        # learn on the even-numbered sequences (family totals, learn.smk:385-408), apply to all of them
+        train = np.arange(len(recs)) % 2 == 0
+        totals = np.vstack([counts[train & (fam == f)].sum(axis=0) for f in range(nfam)])
+        names = [f"FAM{f:03d}" for f in range(nfam)]
+        totals_df = pd.DataFrame(totals, index=names, columns=list(out["kmerlist"]))
+        counts_df = pd.DataFrame(counts, index=list(out["ids"]), columns=list(out["kmerlist"]))
+        r = apply_rule(pd, cosine_similarity, totals_df, counts_df, conf_path)
+        np.savez_compressed(
+            os.path.join(HERE, f"g12_apply_{alphabet}_k{k}.npz"),
+            residues=res, offsets=off, family=fam, train=train, names=np.asarray(names),
+            kmerlist=out["kmerlist"], confidence_csv=np.asarray(conf_text), **r,
+        )
+
+    # ---- G13: real-valued features ------------------------------------------------------
+    rng = np.random.default_rng(13)
+    X = rng.normal(size=(37, 53))
+    X[5] = 0.0
+    Y = rng.normal(size=(11, 53)) * rng.uniform(0.1, 30.0, size=(11, 1))
+    demo_dir = os.path.join(ref_root, "resources", "tutorial", "demo_example", "input")
+    records = []
+    for f in sorted(x for x in os.listdir(demo_dir) if x.endswith(".faa")):
+        records += read_fasta(os.path.join(demo_dir, f))
+    out = run_rule(V, A, records, "hydro", 14)
+    counts = run_counts(out["seqs"], out["kmerlist"])
+    F = U.to_feature_matrix([list(r) for r in counts], length_array=out["lengths"])  # utils.py:183-203
+    np.savez_compressed(
+        os.path.join(HERE, "g13_float_features.npz"),
+        X=X, Y=Y,
+        cos_xx=cosine_similarity(X, X), cos_xy=cosine_similarity(X, Y),
+        conn_cosine_x=S.connection_matrix_from_features(X, metric="cosine"),
+        demo_lengths=out["lengths"],
+        demo_conn_cosine=S.connection_matrix_from_features(F, metric="cosine"),
+        demo_cos=cosine_similarity(F, F),
+    )
+    print("extra fixtures written: g12_apply_*.npz, g13_float_features.npz")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    root = args[0] if args else "/root/reference"
+    if "--extra-only" in sys.argv:
+        extra(root)
+    else:
+        main(root)

@@ -299,8 +299,13 @@ def test_connection_matrix_and_feature_matrix_goldens(ctx):
     g = gnpz("g9_connection.npz")
     D = skm.score.connection_matrix_from_features(g["X"], metric="cosine")
     assert np.abs(D - g["cosine"]).max() <= COS_TOL
-    with pytest.raises(NotImplementedError):
-        skm.score.connection_matrix_from_features(g["X"] + 0.5, metric="cosine")
+    # real-valued features take the float64 matrix-core path (sklearn order of operations)
+    Xf = g["X"] + 0.5
+    Df = skm.score.connection_matrix_from_features(Xf, metric="cosine")
+    Xn = Xf / np.sqrt((Xf * Xf).sum(axis=1))[:, None]
+    exp = np.clip(1.0 - Xn @ Xn.T, 0, 2)
+    np.fill_diagonal(exp, 0.0)
+    assert Df.dtype == np.float64 and np.abs(Df - exp).max() <= 1e-12
     J = skm.score.connection_matrix_from_features(g["X"] > 0)  # default metric="jaccard" (= 1 - hamming upstream)
     assert np.abs(J - g["jaccard"]).max() <= 1e-6
     J2 = skm.score.connection_matrix_from_features((g["X"] > 0).astype(float), metric="jaccard")
@@ -682,7 +687,7 @@ def test_overlapped_cosine_schedule_equals_default(ctx, monkeypatch):
 
 
 # ------------------------------------------------------------------ BASELINE full sizes
-def _sampled_row_check(ctx, name, k, n, seed_idx, nsample=48, family=100):
+def _sampled_row_check(ctx, name, k, n, seed_idx, nsample=48, family=100, full_stats=False):
     from snekmer_amd import alphabet as A
     from snekmer_amd import engine
     from snekmer_amd.synth import synth_families
@@ -712,12 +717,20 @@ def _sampled_row_check(ctx, name, k, n, seed_idx, nsample=48, family=100):
     assert np.abs(np.diag(sub)[nz] - 1.0).max() <= 1e-6
     # checksum of checksums: total of the sampled rows equals the oracle's to float32 accumulation error
     assert abs(float(got.sum(dtype=np.float64)) - float(ref.sum())) <= 1e-3 * max(1.0, float(ref.sum()))
+    if full_stats:
+        # the WHOLE n x n block, reduced on the device: every row's non-zero count must equal the oracle's
+        # (no stray non-zero anywhere in 1e10 cells) and every row sum must agree to float32 rounding
+        rowsum, rownnz = engine.matrix_row_stats(ctx, out, n, n, ld)
+        _, o_sum, o_nnz = orc.cosine_all(o_rowptr, ocol, o_counts, len(ob), stats=True)
+        assert (rownnz == o_nnz).all()
+        assert np.abs(rowsum - o_sum).max() <= 2e-6 * max(1.0, float(o_sum.max()))
+        assert abs(float(rowsum.sum()) - float(o_sum.sum())) <= 1e-6 * float(o_sum.sum())
     return pipe
 
 
 def test_config3_full_size_100k_red6_k12(ctx):
     """BASELINE configs[2], the benchmarked workload, at full size (40 GB result in HBM)."""
-    _sampled_row_check(ctx, "red6", 12, 100000, seed_idx=2)
+    _sampled_row_check(ctx, "red6", 12, 100000, seed_idx=2, full_stats=True)
 
 
 def test_config3_real_alphabet_standard_k12_u64_codes(ctx):
@@ -748,7 +761,7 @@ def test_group_sum_cosine_vs_totals_and_top2(ctx, tag):
     csr = engine.count_csr(ctx, batch, lut, k, with_firstpos=True)
     basis = engine.build_basis(ctx, csr, lut.nsym, k, first_seen=True, postings=False)
     groups = g["file_of"]
-    out = skm_apply.learn_apply(ctx, csr, basis.ncols, groups, 2)
+    out = skm_apply.learn_apply(ctx, csr, basis.ncols, groups, 2, materialize=True)
     # totals: compare in first-seen column order against the golden per-file sums
     fs = basis.fs_order.download(basis.ncols).astype(np.int64)
     rank = np.empty(basis.ncols, dtype=np.int64)
@@ -768,8 +781,12 @@ def test_group_sum_cosine_vs_totals_and_top2(ctx, tag):
     order = np.argsort(-g["cosine_rect"], axis=1, kind="stable")[:, :2]
     assert (out["top2_index"] == order).all()
     ref_val = np.take_along_axis(g["cosine_rect"], order, axis=1)
-    assert np.abs(out["top2_score"] - ref_val).max() <= COS_TOL
-    assert np.abs(out["delta"] - np.round(ref_val[:, 0] - ref_val[:, 1], 2)).max() <= 0.01 + 1e-9
+    # fused epilogue: float64 scores from exact integers -> sklearn's values to rounding, delta EQUAL
+    assert out["top2_score"].dtype == np.float64 and np.abs(out["top2_score"] - ref_val).max() <= 1e-12
+    assert (out["delta"] == np.round(ref_val[:, 0] - ref_val[:, 1], 2)).all()
+    # ... and identical to reducing the materialised block (the unfused round-1 path)
+    idx2, val2 = skm_apply.row_top2(ctx, out["scores"], n, 2, out["ld"])
+    assert (idx2 == out["top2_index"]).all() and np.abs(val2 - out["top2_score"]).max() <= COS_TOL
 
 
 def test_row_top2_ties_and_edges(ctx):
@@ -1057,3 +1074,264 @@ def test_c_abi_error_codes_and_messages(ctx):
     assert e.value.code == -1 and "row range" in str(e.value)
     out = C.c_void_p()
     assert lib.skm_create(99, C.byref(out)) == -1 and b"out of range" in lib.skm_last_error()
+
+
+# ------------------------------------------------------------------ f1: fused apply epilogue vs the reference rule body
+@pytest.mark.parametrize("tag,name,k", [("standard_k12", "standard", 12), ("hydro_k14", "hydro", 14), ("solvacc_k8", "solvacc", 8)])
+def test_apply_epilogue_matches_reference_rule_golden(ctx, tag, name, k):
+    """G12: rules/apply.smk:278-328 run with the real sklearn / pandas (tests/golden/make_golden.py) on
+    synthetic families: Prediction, Score, delta and Confidence.  The device never stores the N x A
+    block; delta and Confidence must be EQUAL, not close (delta is the lookup key of the table)."""
+    import io
+
+    import pandas as pd
+
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import apply as skm_apply
+    from snekmer_amd import engine
+
+    g = gnpz(f"g12_apply_{tag}.npz")
+    lut = A.build_lut(name)
+    batch = engine.SeqBatch(ctx, g["residues"], g["offsets"])
+    csr = engine.count_csr(ctx, batch, lut, k)
+    basis = engine.build_basis(ctx, csr, lut.nsym, k, postings=False)
+    fam, train = g["family"], g["train"]
+    nfam = int(fam.max()) + 1
+    # learn.smk:385-408: totals of the training sequences per annotation; rows outside the training
+    # set go to a spare group that is dropped again
+    groups = np.where(train, fam, nfam).astype(np.uint32)
+    tot_all = skm_apply.group_sum(ctx, csr, groups, nfam + 1)
+    rp = tot_all.rowptr.download(nfam + 2)
+    keep = int(rp[nfam])
+    totals = engine.CountsCSR(ctx, nfam, keep, 32, tot_all.rowptr, tot_all.codes, tot_all.counts, None)
+    totals.colidx = tot_all.colidx
+    # the table as an integrator reads it (apply.smk:302-311)
+    gcs = pd.read_csv(io.StringIO(str(g["confidence_csv"])))
+    gcs.index = gcs[gcs.columns[0]]
+    gcs = gcs.iloc[:, 1:]
+    gcs = gcs[gcs.columns[0]].squeeze()
+    out = skm_apply.predict(ctx, csr, basis.ncols, totals, labels=g["names"], confidence=gcs)
+    assert (out["top2_index"] == g["sorted_vals"]).all()
+    assert (out["Prediction"].astype(str) == g["Prediction"]).all()
+    assert np.abs(out["top2_score"] - g["score_rank"]).max() <= 1e-12
+    assert (out["delta"] == g["delta"]).all()
+    both_nan = np.isnan(out["Confidence"]) & np.isnan(g["Confidence"])
+    assert ((out["Confidence"] == g["Confidence"]) | both_nan).all() and both_nan.sum() == np.isnan(g["Confidence"]).sum()
+    # the device's float64 scores are exactly what the exact integers give on the host
+    xsq = engine.row_normsq(ctx, csr.n, csr.rowptr, csr.counts).download(csr.n).astype(np.float64)
+    ysq = engine.row_normsq(ctx, nfam, totals.rowptr, totals.counts).download(nfam).astype(np.float64)
+    xs = np.sqrt(np.where(xsq > 0, xsq, 1.0))[:, None]
+    ys = np.sqrt(np.where(ysq > 0, ysq, 1.0))[out["top2_index"].astype(np.int64)]
+    host = np.where(out["top2_dot"] != 0, out["top2_dot"].astype(np.float64) / (xs * ys), 0.0)
+    assert (host == out["top2_score"]).all()
+
+
+def test_apply_top2_many_families_ties_and_missing_columns(ctx):
+    """More families than one LDS pass holds (8192), all-zero query rows (ties -> columns 0, 1), a single
+    family (second slot empty), and query columns the totals do not have."""
+    from snekmer_amd import apply as skm_apply
+    from snekmer_amd import engine
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(5)
+    n, A_, K = 300, 9000, 700
+    X = sp.random(n, K, density=0.05, random_state=1, data_rvs=lambda s: rng.integers(1, 9, size=s)).tocsr()
+    X.data = X.data.astype(np.int64)
+    T = sp.random(A_, K, density=0.01, random_state=2, data_rvs=lambda s: rng.integers(1, 4000, size=s)).tocsr()
+    T.data = T.data.astype(np.int64)
+    X = X.tolil()
+    X[7] = 0
+    X = X.tocsr()
+
+    def dev(M):
+        M = M.tocsr()
+        M.sort_indices()
+        c = engine.CountsCSR(ctx, M.shape[0], M.nnz, 32, ctx.to_device(M.indptr.astype(np.int64)),
+                             ctx.to_device(np.zeros(max(M.nnz, 1), np.uint32)), ctx.to_device(M.data.astype(np.uint32)), None)
+        c.colidx = ctx.to_device(M.indices.astype(np.uint32))
+        return c
+
+    x, t = dev(X), dev(T)
+    idx, score, dot = skm_apply.apply_top2(ctx, x, K, t)
+    G = (X @ T.T).toarray().astype(np.int64)
+    xs = np.sqrt(np.maximum(np.asarray(X.multiply(X).sum(axis=1)).ravel(), 0).astype(np.float64))
+    ts = np.sqrt(np.asarray(T.multiply(T).sum(axis=1)).ravel().astype(np.float64))
+    xs[xs == 0] = 1.0
+    ts[ts == 0] = 1.0
+    S = np.where(G != 0, G / (xs[:, None] * ts[None, :]), 0.0)
+    order = np.argsort(-S, axis=1, kind="stable")[:, :2]
+    assert (idx == order).all()
+    assert (score == np.take_along_axis(S, order, axis=1)).all()
+    assert (dot == np.take_along_axis(G, order, axis=1)).all()
+    assert (idx[7] == [0, 1]).all() and (score[7] == 0).all()
+    # one family only
+    t1 = dev(T[:1])
+    idx1, score1, _ = skm_apply.apply_top2(ctx, x, K, t1)
+    assert (idx1[:, 0] == 0).all() and (idx1[:, 1] == 0xFFFFFFFF).all() and (score1[:, 1] == 0).all()
+    # query entries on columns Y does not have (0xFFFFFFFF) contribute nothing
+    x2 = dev(X)
+    col = X.indices.astype(np.uint32).copy()
+    drop = col % 5 == 0
+    col[drop] = 0xFFFFFFFF
+    x2.colidx = ctx.to_device(col)
+    Xd = X.copy()
+    Xd.data = np.where(drop, 0, X.data)
+    G2 = (Xd @ T.T).toarray().astype(np.int64)
+    S2 = np.where(G2 != 0, G2 / (xs[:, None] * ts[None, :]), 0.0)  # norms still those of the full rows
+    idx2, score2, dot2 = skm_apply.apply_top2(ctx, x2, K, t)
+    order2 = np.argsort(-S2, axis=1, kind="stable")[:, :2]
+    assert (idx2 == order2).all() and (dot2 == np.take_along_axis(G2, order2, axis=1)).all()
+
+
+# ------------------------------------------------------------------ a14: real-valued feature matrices
+def test_float_feature_matrices_match_sklearn_golden(ctx):
+    """G13: sklearn cosine_similarity / connection_matrix_from_features on matrices that are not counts
+    (negative, fractional, length-normalised rows of utils.to_feature_matrix): float64 on the device."""
+    import pandas as pd
+
+    import snekmer_amd as skm
+
+    g = gnpz("g13_float_features.npz")
+    X, Y = g["X"], g["Y"]
+    S = skm.score.cosine_similarity(X)
+    assert S.dtype == np.float64 and np.abs(S - g["cos_xx"]).max() <= 1e-12
+    assert (S[5] == 0).all() and (S[:, 5] == 0).all()  # the all-zero row: sklearn's zero-norm rule
+    Sxy = skm.score.cosine_similarity(pd.DataFrame(X), pd.DataFrame(Y))  # DataFrames, as rules/apply.smk:282 passes
+    assert np.abs(Sxy - g["cos_xy"]).max() <= 1e-12
+    D = skm.score.connection_matrix_from_features(X, metric="cosine")
+    assert np.abs(D - g["conn_cosine_x"]).max() <= 1e-12 and (np.diag(D) == 0).all()
+    # length-normalised demo counts (utils.to_feature_matrix, snekmer/utils.py:183-203)
+    g3 = gnpz("g3_demo_hydro_k14_mf0.npz")
+    counts = csr_to_dense(g3["counts_rowptr"], g3["counts_col"], g3["counts_val"], len(g3["kmerlist"]))
+    F = skm.utils.to_feature_matrix([list(r) for r in counts], length_array=g["demo_lengths"])
+    assert np.abs(skm.score.connection_matrix_from_features(F, metric="cosine") - g["demo_conn_cosine"]).max() <= 1e-12
+    assert np.abs(skm.score.cosine_similarity(F) - g["demo_cos"]).max() <= 1e-12
+    # count matrices still return float64 (sklearn's dtype), from the exact-integer path
+    C = skm.score.cosine_similarity(counts)
+    assert C.dtype == np.float64 and np.abs(C - g3["cosine"]).max() <= COS_TOL
+    with pytest.raises(ValueError):
+        skm.score.cosine_similarity(X, Y[:, :-1])
+
+
+# ------------------------------------------------------------------ N1: dense count scatter at BASELINE configs[4]
+def test_dense_to_csr_all_cell_types_and_layouts(ctx):
+    from snekmer_amd import engine
+
+    rng = np.random.default_rng(11)
+    for dtype, hi in ((np.uint16, 60000), (np.uint32, 2**31), (np.int8, 127)):
+        for n, ncols, ld in ((1, 1, 2), (5, 1000, 1000), (7, 1003, 1006), (3, 70000, 70000), (4, 64, 80)):
+            M = np.zeros((n, ld), dtype=np.int64)
+            mask = rng.random((n, ncols)) < 0.03
+            M[:, :ncols][mask] = rng.integers(1, hi, size=int(mask.sum()))
+            if n > 2:
+                M[1] = 0
+            d = ctx.to_device(M.astype(dtype))
+            c = engine.dense_to_csr(ctx, d, n, ncols, ld, cap_entries=int(mask.sum()) + 1)
+            rp = c.rowptr.download(n + 1)
+            col, val = c.codes.download(c.nnz), c.counts.download(c.nnz)
+            r, cc = np.nonzero(M[:, :ncols])
+            assert c.nnz == len(r) and (rp == np.r_[0, np.cumsum(np.bincount(r, minlength=n))]).all()
+            assert (col == cc).all() and (val == M[r, cc]).all()
+    from snekmer_amd import _hip
+
+    with pytest.raises(_hip.HipError):  # capacity is checked, not overrun
+        engine.dense_to_csr(ctx, ctx.to_device(np.ones((4, 8), np.uint16)), 4, 8, 8, cap_entries=5)
+
+
+def _count_dense_vs_oracle(ctx, n, seed_idx):
+    """skm_count_dense at hydro k=20 (2^20 columns, uint16 cells), then EVERY cell against the C oracle:
+    the dense matrix is turned back into (code, count) rows on the device (skm_dense_to_csr) and those
+    must equal the oracle's CSR bit for bit - no cell may be non-zero outside the oracle's columns and
+    every count must match."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+
+    orc = _oracle()
+    lut = A.build_lut("hydro")
+    k = 20
+    res, off, _ = synth_families(n, 300, family=100, seed=20250523 + seed_idx)
+    batch = engine.SeqBatch(ctx, res, off)
+    dense = engine.count_dense(ctx, batch, lut, k, dtype=np.uint16)
+    space = lut.nsym**k
+    assert dense.shape == (n, space)
+    csr = engine.dense_to_csr(ctx, dense, n, space, dense.shape[1], cap_entries=int(off[-1]))
+    o_rowptr, o_codes, o_counts, _ = orc.count_csr(lut.rank, lut.nsym, k, res, off, threads=0)
+    assert csr.nnz == len(o_codes)
+    assert (csr.rowptr.download(n + 1) == o_rowptr).all()
+    assert (csr.codes.download(csr.nnz).astype(np.uint64) == o_codes).all()
+    assert (csr.counts.download(csr.nnz) == o_counts).all()
+    # and the sparse product path agrees with the scatter on the same input
+    sp_csr = engine.count_csr(ctx, batch, lut, k)
+    assert (sp_csr.codes.download(sp_csr.nnz) == csr.codes.download(csr.nnz)).all()
+    # row sums == valid windows (1 % of the sequences carry an X: fewer windows)
+    stripped = np.diff(off) - (res[off[1:] - 1] == ord("*"))
+    sums = np.add.reduceat(o_counts.astype(np.int64), o_rowptr[:-1])
+    assert (sums <= np.maximum(stripped - k + 1, 0)).all() and (sums == np.maximum(stripped - k + 1, 0)).mean() > 0.98
+    del dense
+    return csr.nnz
+
+
+def test_config5_count_dense_hydro_k20_20k_rows_bit_exact(ctx):
+    """BASELINE configs[4] kernel and basis (hydro k=20: 2^20 columns) at N = 20 000 (42 GB)."""
+    _count_dense_vs_oracle(ctx, 20000, seed_idx=4)
+
+
+def test_config5_count_dense_full_size_100k_by_2pow20(ctx):
+    """BASELINE configs[4] as stated: 100 k x 2^20 uint16 cells = 210 GB in HBM, every cell checked."""
+    _, _, mem = ctx.device_info()
+    if mem < 250 * 2**30:
+        pytest.skip("needs ~215 GB of HBM")
+    nnz = _count_dense_vs_oracle(ctx, 100000, seed_idx=4)
+    assert nnz > 25_000_000
+
+
+# ------------------------------------------------------------------ N3: BASELINE configs[3], one rank's share at full size
+def test_config4_one_rank_share_125k_rows_vs_1m(ctx):
+    """BASELINE configs[3]: 1 M x 300 aa sharded 8 ways.  One rank's share on one GPU: all 1 M sequences
+    vectorized, exact neighbour lists + top-10 for rows [0, 125 000) against all 1 M columns.  Checked
+    against the C oracle: the full 1 M-row CSR bit for bit, and for sampled rows of the block the
+    neighbour SETS, the exact integer dots and the top-10 scores (oracle joined on the k-mer codes)."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+
+    orc = _oracle()
+    lut = A.build_lut("red6")
+    k, n, block, topk = 12, 1_000_000, 125_000, 10
+    res, off, fam = synth_families(n, 300, family=100, seed=20250523 + 3)
+    batch = engine.SeqBatch(ctx, res, off)
+    pipe = engine.Pipeline(ctx, lut, k)
+    pipe.vectorize(batch)
+    b = pipe.basis
+    nb = engine.gram_neighbors(ctx, pipe.csr, n, b.ncols, b.colptr, b.post, row0=0, row1=block, cap_entries=block * 6000)
+    assert nb.overflow_rows == 0
+    idx, val = engine.neighbors_topk(ctx, nb, pipe.rnorm, pipe.rnorm, topk, exclude_self=True)
+    # ---- oracle, all host cores
+    o_rowptr, o_codes, o_counts, _ = orc.count_csr(lut.rank, lut.nsym, k, res, off, threads=0)
+    rowptr, codes, counts, _ = pipe.csr.host()
+    assert (rowptr == o_rowptr).all() and (counts == o_counts).all() and (codes.astype(np.uint64) == o_codes).all()
+    del codes, counts
+    rows = np.sort(np.random.default_rng(4).choice(block, size=48, replace=False))
+    G = orc.sampled_gram(o_rowptr, o_codes, o_counts, rows)  # int32 [48, 1M]
+    nsq = np.add.reduceat(o_counts.astype(np.float64) ** 2, o_rowptr[:-1])
+    nsq[np.diff(o_rowptr) == 0] = 0.0
+    norms = np.sqrt(np.where(nsq > 0, nsq, 1.0))
+    start, length, jj, dot = nb.host()
+    for s, r in enumerate(rows):
+        js = jj[int(start[r]) : int(start[r]) + int(length[r])].astype(np.int64)
+        ds = dot[int(start[r]) : int(start[r]) + int(length[r])]
+        exp = np.nonzero(G[s])[0]
+        order = np.argsort(js)
+        assert (js[order] == exp).all()          # the neighbour set, exactly
+        assert (ds[order] == G[s, exp]).all()    # exact integer dots
+        cosr = G[s].astype(np.float64) / (norms[r] * norms)
+        cosr[r] = -1.0
+        cand = np.nonzero(cosr > 0)[0]
+        best = cand[np.lexsort((cand, -np.round(cosr[cand], 12)))][:topk]
+        got = idx[r][idx[r] != 0xFFFFFFFF].astype(np.int64)
+        assert len(got) == min(topk, len(cand))
+        assert np.abs(val[r][: len(got)] - cosr[got]).max() <= COS_TOL
+        assert np.abs(np.sort(cosr[got])[::-1] - cosr[best][: len(got)]).max() <= COS_TOL
+        assert (fam[got[:3]] == fam[r]).all()
+    assert int((length == 0xFFFFFFFF).sum()) == 0  # no row of the block was left out

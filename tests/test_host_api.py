@@ -26,7 +26,18 @@ def test_library_loads_and_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert set(_hip.EXPORTED_SYMBOLS) == declared
-    assert lib.skm_abi_version() == 1
+    assert lib.skm_abi_version() == 2
+
+
+def test_product_library_carries_no_result_invalidating_switches():
+    """The timing-only ablations live in the -DSKM_DIAG build (libsnekmer_hip_diag.so) alone."""
+    blob = open(_hip.LIB_PATH, "rb").read()
+    for needle in (b"SKM_COSINE_ABLATE", b"SKM_GRAM_ABLATE", b"skm_debug_gram_phases"):
+        assert needle not in blob
+    src = open(os.path.join(ROOT, "snekmer_amd", "csrc", "skm_cosine_csr.hip")).read()
+    for m in re.finditer(r"getenv\(\"(SKM_[A-Z_]+ABLATE)\"\)", src):
+        before = src[: m.start()]
+        assert before.rfind("#ifdef SKM_DIAG") > before.rfind("#endif"), m.group(1)
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

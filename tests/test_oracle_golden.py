@@ -189,3 +189,67 @@ def test_g11_jaccard_distance_formula():
     uni = sizes[:, None] + sizes[None, :] - inter
     D = np.where(uni > 0, (uni - inter) / np.maximum(uni, 1), 0.0)
     np.testing.assert_allclose(D, gnpz("g11_jaccard_demo_hydro_k14.npz")["jaccard_distance"], atol=1e-12)
+
+
+@pytest.mark.parametrize("tag,name,k", [("standard_k12", "standard", 12), ("hydro_k14", "hydro", 14), ("solvacc_k8", "solvacc", 8)])
+def test_g12_apply_epilogue(tag, name, k):
+    """The apply epilogue restatement (oracle/ref_path.py) against rules/apply.smk:278-328 run with the
+    real sklearn / pandas in the build container."""
+    import io
+
+    import pandas as pd
+
+    g = gnpz(f"g12_apply_{tag}.npz")
+    lut = A.build_lut(name)
+    res, off, fam, train = g["residues"], g["offsets"], g["family"], g["train"]
+    rowptr, codes, cnt, first = c_oracle.count_csr(lut.rank, lut.nsym, k, res, off)
+    basis, df, tot, fk, col = c_oracle.basis(rowptr, codes, cnt, first)
+    counts = csr_to_dense(rowptr, col, cnt, len(basis))
+    nfam = int(fam.max()) + 1
+    totals = np.vstack([counts[train & (fam == f)].sum(axis=0) for f in range(nfam)])
+    conf = pd.read_csv(io.StringIO(str(g["confidence_csv"])))
+    table = dict(zip(conf.iloc[:, 0].to_numpy(), conf.iloc[:, 1].to_numpy()))
+    out = ref_path.apply_epilogue(totals, counts, list(g["names"]), table)
+    assert (out["sorted_vals"] == g["sorted_vals"]).all()
+    np.testing.assert_allclose(out["score_rank"], g["score_rank"], atol=1e-13)
+    assert (out["delta"] == g["delta"]).all()
+    assert (out["Prediction"] == g["Prediction"]).all()
+    nan = np.isnan(g["Confidence"])
+    assert (np.isnan(out["Confidence"]) == nan).all() and (out["Confidence"][~nan] == g["Confidence"][~nan]).all()
+    assert nan.sum() > 0  # the table has holes on purpose
+
+
+def test_g13_float_features_restatement():
+    g = gnpz("g13_float_features.npz")
+    np.testing.assert_allclose(ref_path.cosine_similarity(g["X"]), g["cos_xx"], atol=1e-14)
+    np.testing.assert_allclose(ref_path.cosine_similarity(g["X"], g["Y"]), g["cos_xy"], atol=1e-14)
+    np.testing.assert_allclose(ref_path.cosine_distances(g["X"]), g["conn_cosine_x"], atol=1e-14)
+
+
+def test_multithreaded_oracle_forms_equal_the_pinned_single_threaded_ones():
+    """orc_*_mt (OpenMP) are the same restatements spread over rows / code buckets: identical output."""
+    from snekmer_amd.synth import synth_families
+
+    for name, k, seed in (("red6", 12, 3), ("standard", 12, 4), ("hydro", 20, 5)):
+        lut = A.build_lut(name)
+        res, off, _ = synth_families(700, 300, family=25, seed=seed)
+        one = c_oracle.count_csr(lut.rank, lut.nsym, k, res, off)
+        many = c_oracle.count_csr(lut.rank, lut.nsym, k, res, off, threads=0)
+        assert all((a == b).all() for a, b in zip(one, many))
+        b1 = c_oracle.basis(*one)
+        bm = c_oracle.basis(*one, threads=0)
+        assert all((a == b).all() for a, b in zip(b1, bm))
+        rowptr, codes, cnt, _ = one
+        col = b1[4]
+        n = len(off) - 1
+        ref = c_oracle.cosine_rows(rowptr, col, cnt, len(b1[0]), np.arange(n))
+        total, S = c_oracle.cosine_all(rowptr, col, cnt, len(b1[0]), keep=True)
+        assert np.abs(S - ref).max() <= 1e-6 and abs(total - float(S.sum(dtype=np.float64))) <= 1e-6 * max(1.0, total)
+        total2, rowsum, rownnz = c_oracle.cosine_all(rowptr, col, cnt, len(b1[0]), stats=True)
+        assert np.abs(rowsum - S.sum(axis=1, dtype=np.float64)).max() <= 1e-9 and (rownnz == (S != 0).sum(axis=1)).all()
+        rows = np.arange(0, n, 37)
+        G = c_oracle.sampled_gram(rowptr, codes, cnt, rows)
+        nsq = np.add.reduceat(cnt.astype(np.float64) ** 2, rowptr[:-1])
+        nsq[np.diff(rowptr) == 0] = 1.0
+        nr = np.sqrt(nsq)
+        assert np.abs(G / nr[rows][:, None] / nr[None, :] - ref[rows]).max() <= 1e-12

@@ -6,13 +6,19 @@
   SKM_COSINE_ABLATE (cursor kernel) 1 no accumulate   2 no global stores   3 plain (not nt) stores
   SKM_COSINE_PATH=cursor  the general fallback kernel for every strip
 
-Results of ablated builds are invalid by construction; only their times are of interest."""
+Results of ablated builds are invalid by construction; only their times are of interest.  The
+ablations exist only in the diagnostic library (`make -C snekmer_amd/csrc diag` ->
+libsnekmer_hip_diag.so, built with -DSKM_DIAG), which this script loads instead of the product."""
 import ctypes as C
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from snekmer_amd import _hip, alphabet, engine
+
+_hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "libsnekmer_hip_diag.so")
+if not os.path.exists(_hip.LIB_PATH):
+    sys.exit("build the diagnostic library first: make -C snekmer_amd/csrc diag")
 from snekmer_amd.synth import BASE_SEED, synth_families
 
 KNOBS = ("SKM_GRAM_ABLATE", "SKM_COSINE_ABLATE", "SKM_COSINE_PATH")
