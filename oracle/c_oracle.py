@@ -67,7 +67,9 @@ def host_threads() -> int:
             avail = min(avail, max(1, int(int(quota) / int(period))))
     except Exception:
         pass
-    return max(1, min(avail, int(lib().orc_max_threads())))
+    # a one-GPU share of a GPU host is 16 CPUs (the pool's guidance); SKM_HOST_THREADS overrides the cap
+    cap = int(os.environ.get("SKM_HOST_THREADS", "16"))
+    return max(1, min(avail, cap, int(lib().orc_max_threads())))
 
 
 def count_csr(rank, nsym, k, seq, off, threads=1):

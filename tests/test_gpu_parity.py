@@ -226,7 +226,7 @@ def test_cosine_matches_sklearn_goldens(ctx, tag):
     counts = csr_to_dense(g["counts_rowptr"], g["counts_col"], g["counts_val"], ncols)
     for path in ("auto", "sparse", "dense"):
         S = cosine_similarity(counts, ctx=ctx, path=path)
-        assert S.dtype == np.float32 and S.shape == g["cosine"].shape
+        assert S.dtype == np.float64 and S.shape == g["cosine"].shape  # sklearn's dtype
         assert np.abs(S - g["cosine"]).max() <= COS_TOL, path
     Rd = cosine_similarity(g["totals"], counts, ctx=ctx, path="dense").T if g["totals"].max() <= 127 else None
     if Rd is not None:
