@@ -10,10 +10,21 @@ matrix together (RCCL all-to-all by k-mer owner, all-gather of the postings; sne
 then each rank computes its row block of the matrix.
 
 Prints ONE JSON line on rank 0 (contract: see repo prompt / DESIGN.md section "Measurement").
+Besides the contract keys the line carries, all measured in this same run after the timed region:
+  stage_rooflines        every stage of the step with its algorithmic bytes and fraction of HBM peak
+  config2                BASELINE configs[1] (10k sequences) ms/step
+  host_to_result_ms      H2D of the packed batch + one step (the PCIe-inclusive figure; never `value`)
+  reference_alphabet_check   the nearest reference alphabet (standard k=12, uint64 codes)
+  config5_count_dense    BASELINE configs[4]: 100k x 2^20 uint16 dense count scatter (210 GB)
+  dense_mfma             the i8 MFMA cosine GEMM at hydro k=14, N = 32768
+  cpu_baseline           reference-equivalent numpy path at several N with a quadratic fit, and the
+                         sparse C restatement on one core and on all cores of this GPU's host share
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,41 +35,108 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+I8_PEAK_TOPS = 5000.0  # same guide: i8 MFMA = 2x the bf16 rate per clock -> ~5 POPS dense
 
 
-def cpu_baseline(alphabet_name, k, seed, n_sample):
-    """The reference-equivalent numpy path (oracle/ref_path.py: np.isin basis pass, O(N*B) count
-    projection, float64 normalise+dot) timed on one host core over a bounded sample of the same
-    synthetic workload.  The oracle is only the reported baseline here, never the measured path."""
-    from oracle import c_oracle, ref_path
+# --------------------------------------------------------------------------------- CPU baselines
+def cpu_point_child(n, k, alphabet_name, seed):
+    """Child-process mode (--cpu-point N): time oracle/ref_path.py, the reference-equivalent numpy path
+    (np.isin basis pass, O(N*B) count projection, float64 normalise+dot), on N synthetic sequences with
+    one thread.  Never touches the GPU."""
+    from oracle import ref_path
     from snekmer_amd import alphabet
     from snekmer_amd.synth import synth_families, to_records
 
-    res, off, _ = synth_families(n_sample, 300, family=100, seed=seed)
+    if "red6" not in alphabet.ALPHABETS:
+        alphabet.register_alphabet("red6", alphabet.RED6_GROUPS)
+    res, off, _ = synth_families(n, 300, family=100, seed=seed)
     recs = to_records(res, off)
     table = alphabet.FULL_ALPHABETS[alphabet_name]
     t0 = time.perf_counter()
-    ref_path.vectorize_and_cosine(recs, k, table)
+    out, counts, S = ref_path.vectorize_and_cosine(recs, k, table)
     dt = time.perf_counter() - t0
-    # sparse C restatement on a larger sample, for scale (still one core)
-    n_c = 4000
-    res, off, _ = synth_families(n_c, 300, family=100, seed=seed)
+    print(json.dumps({"n": n, "seconds": dt, "basis": int(counts.shape[1]), "checksum": float(S.sum())}))
+
+
+def cpu_baseline(alphabet_name, k, seed, points, budget_s, n_sparse):
+    """(1) oracle/ref_path.py at every N of `points`, one single-threaded process per point (run side by
+    side to bound the wall time), with a least-squares fit t = a*N^2 + b*N; (2) the sparse C restatement
+    (oracle/kmer_oracle.c: CSR counts, sort-unique basis, exact sparse Gram + float32 scaling, every row of
+    the N x N result produced) on one core and, with OpenMP, on all cores of this GPU's share of the host.
+    The oracle is only the reported baseline here, never the measured path."""
+    from oracle import c_oracle
+    from snekmer_amd import alphabet
+    from snekmer_amd.synth import synth_families
+
+    env = dict(os.environ)
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        env[var] = "1"
+    env["HIP_VISIBLE_DEVICES"] = ""  # the children have no business on the GPU
+    t_start = time.perf_counter()
+    procs = [
+        (n, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-point", str(n), "--k", str(k),
+                              "--alphabet", alphabet_name], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL))
+        for n in points
+    ]
+
+    # sparse C restatement while the children run (it uses other cores)
     lut = alphabet.build_lut(alphabet_name)
-    t1 = time.perf_counter()
-    rowptr, codes, counts, first = c_oracle.count_csr(lut.rank, lut.nsym, k, res, off)
-    b, _, _, _, col = c_oracle.basis(rowptr, codes, counts, first)
-    c_oracle.cosine_rows(rowptr, col, counts, len(b), np.arange(n_c))
-    dt_c = time.perf_counter() - t1
+    threads = c_oracle.host_threads()
+
+    def sparse(n, nthreads):
+        res, off, _ = synth_families(n, 300, family=100, seed=seed)
+        t0 = time.perf_counter()
+        rowptr, codes, counts, first = c_oracle.count_csr(lut.rank, lut.nsym, k, res, off, threads=nthreads)
+        t1 = time.perf_counter()
+        b, _, _, _, col = c_oracle.basis(rowptr, codes, counts, first, threads=nthreads)
+        t2 = time.perf_counter()
+        total = c_oracle.cosine_all(rowptr, col, counts, len(b), threads=nthreads)
+        t3 = time.perf_counter()
+        return {"value": n / (t3 - t0), "unit": "sequences/s", "cores": nthreads,
+                "sample": f"{n} x 300aa, oracle/kmer_oracle.c: count {t1 - t0:.2f}s + basis {t2 - t1:.2f}s + "
+                          f"N x N cosine rows {t3 - t2:.2f}s (each float32 row produced in a per-thread buffer, not kept)",
+                "checksum": total}
+
+    sparse_all = sparse(n_sparse, threads)
+    sparse_one = sparse(min(n_sparse, 20000), 1)
+
+    measured = []
+    for n, p in procs:
+        left = budget_s - (time.perf_counter() - t_start)
+        try:
+            out, _ = p.communicate(timeout=max(left, 1.0))
+            rec = json.loads(out.decode().strip().splitlines()[-1])
+            measured.append({"n": n, "seconds": rec["seconds"], "sequences_per_s": n / rec["seconds"], "basis": rec["basis"]})
+        except Exception:
+            p.kill()
+            p.wait()
+            measured.append({"n": n, "seconds": None, "note": f"not finished within the {budget_s:.0f}s budget"})
+    good = [m for m in measured if m.get("seconds")]
+    fit = None
+    if len(good) >= 2:
+        N = np.asarray([m["n"] for m in good], dtype=np.float64)
+        T = np.asarray([m["seconds"] for m in good], dtype=np.float64)
+        A = np.stack([N * N, N], axis=1)
+        (a, b), *_ = np.linalg.lstsq(A, T, rcond=None)
+        fit = {"model": "seconds = a*N^2 + b*N (least squares through the measured points)", "a": float(a), "b": float(b),
+               "EXTRAPOLATED_seconds_at_10k": float(a * 1e8 + b * 1e4), "EXTRAPOLATED_seconds_at_100k": float(a * 1e10 + b * 1e5),
+               "EXTRAPOLATED_sequences_per_s_at_100k": float(1e5 / (a * 1e10 + b * 1e5)) if a * 1e10 + b * 1e5 > 0 else None,
+               "note": "extrapolation only: the dense float64 N x |basis| arrays of the reference "
+                       "(rules/kmerize.smk:112) need ~170 GB at N = 10k, so the path cannot run at the benchmarked size"}
+    head = good[-1] if good else {"n": 0, "sequences_per_s": 0.0, "seconds": 0.0}
     return {
-        "value": n_sample / dt,
+        "value": head["sequences_per_s"],
         "unit": "sequences/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{n_sample} x 300aa synthetic families, red6 k={k}: oracle/ref_path.py "
-        f"(reference-equivalent numpy path, cost grows ~N^2) took {dt:.1f}s",
-        "host_cores_available": os.cpu_count(),
-        "sparse_c_oracle": {"value": n_c / dt_c, "unit": "sequences/s", "cores": 1,
-                            "sample": f"{n_c} x 300aa, oracle/kmer_oracle.c took {dt_c:.2f}s"},
+        "sample": f"{head['n']} x 300aa synthetic families, {alphabet_name} k={k}: oracle/ref_path.py "
+                  f"(reference-equivalent numpy path, one thread) took {head['seconds']:.1f}s; cost grows ~N^2, see points/fit",
+        "points": measured,
+        "fit": fit,
+        "sparse_all_cores": sparse_all,
+        "sparse_one_core": sparse_one,
+        "host_cores_visible": os.cpu_count(),
+        "host_cores_used_for_all_cores": threads,
     }
 
 
@@ -72,14 +150,29 @@ def reserve_stdout() -> int:
     return real
 
 
+def kernel_source_sha() -> str:
+    """Hash of the sources of the dominant kernel: profiles/pmc_traffic.json records the hash it was
+    measured on, so a stale PMC figure is never attached to a changed kernel."""
+    h = hashlib.sha256()
+    for f in ("skm_cosine_csr.hip", "skm_gram_kernel.h"):
+        with open(os.path.join(ROOT, "snekmer_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load_pmc_traffic():
-    """Per-launch HBM bytes of the dominant kernel from the committed PMC summary, if any."""
+    """Per-launch HBM bytes of the dominant kernel from the committed PMC summary (rocprofv3 --pmc
+    WRITE_SIZE / FETCH_SIZE in separate passes, tools/profile_round.sh); None when that summary was
+    taken on different kernel sources."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
-            return json.load(fh).get("k_cosine_write_bytes_per_launch")
+            rec = json.load(fh)
     except Exception:
-        return None
+        return None, "no PMC summary committed"
+    if rec.get("source_sha16") != kernel_source_sha():
+        return None, "PMC summary in profiles/ predates the current kernel sources; re-run tools/profile_round.sh"
+    return rec.get("k_cosine_write_bytes_per_launch"), rec.get("note", "rocprofv3 --pmc, separate passes")
 
 
 def main():
@@ -91,9 +184,21 @@ def main():
     ap.add_argument("--length", type=int, default=300)
     ap.add_argument("--k", type=int, default=12)
     ap.add_argument("--alphabet", default="red6")
-    ap.add_argument("--cpu-sample", type=int, default=600)
+    ap.add_argument("--cpu-points", default="250,500,1000,2000",
+                    help="N values at which the reference-equivalent numpy path is timed (BASELINE.md section 3)")
+    ap.add_argument("--cpu-budget-s", type=float, default=210.0, help="wall-time bound of the CPU-baseline leg")
+    ap.add_argument("--cpu-sparse-n", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip config 2 / config 5 / MFMA / host-to-result extras")
+    ap.add_argument("--cpu-point", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    from snekmer_amd.synth import BASE_SEED
+
+    seed = BASE_SEED + 2
+    if args.cpu_point:
+        cpu_point_child(args.cpu_point, args.k, args.alphabet, seed)
+        return
 
     real_stdout = reserve_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,7 +210,7 @@ def main():
         args.gpus = world
 
     from snekmer_amd import _hip, alphabet, engine
-    from snekmer_amd.synth import BASE_SEED, synth_families
+    from snekmer_amd.synth import synth_families
 
     if "red6" not in alphabet.ALPHABETS:
         alphabet.register_alphabet("red6", alphabet.RED6_GROUPS)
@@ -125,7 +230,6 @@ def main():
 
     ctx = _hip.Context(local_rank)
     lut = alphabet.build_lut(args.alphabet)
-    seed = BASE_SEED + 2
     res, off, _ = synth_families(args.n, args.length, family=100, seed=seed)
     n_total = args.n
     residues_total = int(off[-1])
@@ -191,6 +295,7 @@ def main():
         # (One launch per step; written so that it stays right if a step ever splits the launch.)
         algo_bytes = rows_local * ld * 4 * args.steps / max(launches, 1)
         achieved = algo_bytes / (strip_avg_ms * 1e-3) / 1e9 if strip_avg_ms > 0 else 0.0
+        traffic, traffic_note = load_pmc_traffic()
         line = {
             "metric": "sequences/sec vectorize+pairwise-cosine, 100k x 300aa k=12",
             "value": n_total / (elapsed / args.steps),
@@ -224,36 +329,180 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_pmc_traffic(),
+                "traffic": traffic,
+                "traffic_note": traffic_note,
                 "launches": launches,
                 "avg_launch_ms": strip_avg_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
+                "whole_step_frac": rows_local * ld * 4 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
         }
-        if world == 1 and not sharded and args.alphabet == "red6":
-            # red6 is a benchmark alphabet; the nearest reference alphabet (`standard`,
-            # 7^12 needs uint64 codes) is timed next to it on the same sequences, outside the timed region
-            lut7 = alphabet.build_lut("standard")
-            pipe7 = engine.Pipeline(ctx, lut7, args.k)
-            pipe7.out = pipe.out  # share the 40 GB result buffer
-            pipe7.step(batch)
-            ctx.sync()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                pipe7.step(batch)
-            ctx.sync()
-            dt7 = (time.perf_counter() - t1) / 3
-            line["reference_alphabet_check"] = {
-                "alphabet": "standard", "k": args.k, "code_bits": 64, "ms_per_step": dt7 * 1e3,
-                "sequences_per_s": n_total / dt7, "nnz": pipe7.csr.nnz, "basis_columns": pipe7.basis.ncols,
-            }
+        if world == 1 and not sharded and not args.no_extras:
+            extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.alphabet, args.k, seed, args.cpu_sample)
+            pts = [int(x) for x in args.cpu_points.split(",") if x]
+            line["cpu_baseline"] = cpu_baseline(args.alphabet, args.k, seed, pts, args.cpu_budget_s, args.cpu_sparse_n)
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def stage_rooflines(ctx, engine, args, pipe, prof, residues_total):
+    """Every stage of the step: algorithmic bytes / measured time."""
+    import ctypes as C
+
+    csr, b = pipe.csr, pipe.basis
+    nnz, n = csr.nnz, csr.n
+    col = csr.colidx.download(nnz)
+    shared = int((col != 0xFFFFFFFF).sum())  # entries of k-mers found in >= 2 sequences
+    pairs = C.c_uint64(0)
+    ctx.call("skm_pair_work", C.c_int64(b.ncols), C.c_void_p(b.colptr.ptr), C.byref(pairs))
+    pairs = int(pairs.value) - (nnz - shared)  # single-sequence columns were counted as one pair each
+    code_b = 4 if csr.code_bits == 32 else 8
+    kb = engine.key_bits(pipe.lut.nsym, pipe.k)
+    passes = min((kb + 8) // 9, (kb + 7) // 8)  # 9-bit digits whenever they save a pass (skm_sort.h)
+    ld = (n + 3) // 4 * 4
+    table = [
+        ("k_count_short", residues_total + nnz * (code_b + 4), "1 B/residue read + (code,count) per distinct k-mer written"),
+        ("k_compact_rows", nnz * 2 * (code_b + 4), "padded rows -> tight CSR: read + write every entry"),
+        ("rocprim_radix_sort_codes", nnz * passes * 2 * (code_b + 4), f"{passes} Onesweep passes x (key + index payload) read + written"),
+        ("k_basis_scatter", nnz * (code_b + 8) + shared * 20 + b.ncols * (code_b + 4),
+         "sorted keys/indices/column ids read; per shared entry: posting word gathered, colidx + posting written; per column: code + start"),
+        ("k_gram_sparse", pairs * 8, "every (row, posting) pair reads one 8-byte posting: sum over shared columns of df^2"),
+        ("k_cosine_write", n * ld * 4, "the float32 result"),
+    ]
+    out = []
+    for name, nbytes, what in table:
+        cnt, ms = prof.get(name, (0, 0.0))
+        if not cnt:
+            continue
+        per_step = ms / args.steps
+        gbs = nbytes / (per_step * 1e-3) / 1e9
+        out.append({"kernel": name, "bound": "hbm", "algorithmic_bytes_per_step": int(nbytes), "ms_per_step": per_step,
+                    "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS, "bytes_are": what})
+    return out, {"shared_entries": shared, "pairs": pairs}
+
+
+def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed):
+    """Measurements taken after the timed region, on the same GPU in the same run."""
+    import ctypes as C
+
+    from snekmer_amd.synth import BASE_SEED, synth_families
+
+    n_total = args.n
+    line["stage_rooflines"], counts = stage_rooflines(ctx, engine, args, pipe, prof, int(off[-1]))
+    line["config"].update(counts)
+
+    # host -> result: H2D of the packed batch + one step, synchronised (FASTA parse excluded)
+    times = []
+    for _ in range(3):
+        ctx.sync()
+        t1 = time.perf_counter()
+        b2 = engine.SeqBatch(ctx, res, off)
+        pipe.step(b2)
+        ctx.sync()
+        times.append((time.perf_counter() - t1) * 1e3)
+        del b2
+    line["host_to_result_ms"] = {"value": min(times), "what": "H2D of residues + offsets (pageable host memory) + one step, result left in HBM",
+                                 "h2d_bytes": int(res.nbytes + off.nbytes)}
+
+    if args.alphabet == "red6":
+        # SURVEY 8(d): red6 is a benchmark alphabet; the nearest reference alphabet (`standard`,
+        # 7^12 needs uint64 codes) is timed next to it on the same sequences
+        lut7 = alphabet.build_lut("standard")
+        pipe7 = engine.Pipeline(ctx, lut7, args.k)
+        pipe7.out = pipe.out  # share the 40 GB result buffer
+        pipe7.step(batch)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            pipe7.step(batch)
+        ctx.sync()
+        dt7 = (time.perf_counter() - t1) / 3
+        line["reference_alphabet_check"] = {
+            "alphabet": "standard", "k": args.k, "code_bits": 64, "ms_per_step": dt7 * 1e3,
+            "sequences_per_s": n_total / dt7, "nnz": pipe7.csr.nnz, "basis_columns": pipe7.basis.ncols,
+        }
+        pipe7.out = None
+        del pipe7
+
+    # BASELINE configs[1]: 10k sequences, same alphabet and k
+    res2, off2, _ = synth_families(10000, args.length, family=100, seed=BASE_SEED + 1)
+    b2 = engine.SeqBatch(ctx, res2, off2)
+    p2 = engine.Pipeline(ctx, alphabet.build_lut(args.alphabet), args.k)
+    for _ in range(3):
+        p2.step(b2)
+    ctx.sync()
+    t1 = time.perf_counter()
+    for _ in range(50):
+        p2.step(b2)
+    ctx.sync()
+    dt2 = (time.perf_counter() - t1) / 50
+    line["config2"] = {"workload": f"BASELINE configs[1]: 10000 x {args.length}aa, {args.alphabet} k={args.k}",
+                       "ms_per_step": dt2 * 1e3, "sequences_per_s": 10000 / dt2}
+    del p2, b2
+
+    # the 40 GB result is no longer needed: make room for the 210 GB count matrix
+    pipe.out = None
+    _, _, mem = ctx.device_info()
+
+    # BASELINE configs[4]: dense count scatter, hydro k=20, uint16 cells
+    lut2 = alphabet.build_lut("hydro")
+    n5 = n_total if mem >= 250 * 2**30 else 20000
+    res5, off5, _ = synth_families(n5, args.length, family=100, seed=BASE_SEED + 4)
+    b5 = engine.SeqBatch(ctx, res5, off5)
+    dense = engine.count_dense(ctx, b5, lut2, 20, dtype=np.uint16)
+    ctx.sync()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    reps = 2
+    for _ in range(reps):
+        engine.count_dense(ctx, b5, lut2, 20, dtype=np.uint16, out=dense)
+    p5 = ctx.profile_dump()
+    ctx.profile_enable(False)
+    windows = int(np.maximum(np.diff(off5) - 20 + 1, 0).sum())
+    cells = n5 * dense.shape[1]
+    ms_fill = p5["memset_count_dense"][1] / reps
+    ms_sc = p5["k_count_dense"][1] / reps
+    bytes5 = int(res5.size + cells * 2 + windows * 4)  # SURVEY 8(d): N*L + N*B*2 (zero fill) + N*W*2*2 (RMW)
+    line["config5_count_dense"] = {
+        "workload": f"BASELINE configs[4]: {n5} x {args.length}aa, hydro k=20, dense uint16 [{n5} x {dense.shape[1]}]",
+        "matrix_bytes": int(cells * 2), "windows": windows, "memset_ms": ms_fill, "k_count_dense_ms": ms_sc,
+        "ms": ms_fill + ms_sc, "algorithmic_bytes": bytes5, "TBps": bytes5 / (ms_fill + ms_sc) / 1e9,
+        "frac": bytes5 / ((ms_fill + ms_sc) * 1e-3) / 1e9 / HBM_PEAK_GBS, "atomics_per_s": windows / ms_sc * 1e3,
+        "sequences_per_s": n5 / ((ms_fill + ms_sc) * 1e-3),
+        "parity": "tests/test_gpu_parity.py::test_config5_count_dense_full_size_100k_by_2pow20 (every cell vs the oracle)",
+    }
+    del dense, b5
+
+    # the MFMA cosine: hydro k=14 (16384 columns), N = 32768
+    nm = 32768
+    resm, offm, _ = synth_families(nm, args.length, family=100, seed=BASE_SEED + 6)
+    bm = engine.SeqBatch(ctx, resm, offm)
+    dp = engine.DensePipeline(ctx, lut2, 14)
+    dp.step(bm)
+    ctx.sync()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        dp.step(bm)
+    ctx.sync()
+    dt_pipe = (time.perf_counter() - t1) / 3
+    pm = ctx.profile_dump()
+    ctx.profile_enable(False)
+    ms_mfma = pm["k_cosine_dense_i8"][1] / pm["k_cosine_dense_i8"][0]
+    ops = 2.0 * nm * nm * dp.kdim
+    line["dense_mfma"] = {
+        "shape": f"N = M = {nm}, K = {dp.kdim} (hydro k=14 full basis), int8 x int8 -> int32 -> float32",
+        "kernel": "k_cosine_dense_i8 (v_mfma_i32_32x32x32_i8)", "ms": ms_mfma, "ops": ops,
+        "POPS": ops / (ms_mfma * 1e-3) / 1e15, "peak_POPS": I8_PEAK_TOPS / 1e3,
+        "frac": ops / (ms_mfma * 1e-3) / 1e12 / I8_PEAK_TOPS,
+        "dense_pipeline_ms_per_step": dt_pipe * 1e3, "dense_pipeline_sequences_per_s": nm / dt_pipe,
+        "stage_ms": {k: v[1] / v[0] for k, v in pm.items()},
+    }
 
 
 if __name__ == "__main__":

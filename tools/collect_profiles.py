@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def avg(path, counter):
@@ -45,6 +45,11 @@ for k in ("k_cosine_write", "k_gram_sparse", "k_basis_scatter"):
     out[k] = {"WRITE_SIZE_KiB": w[k][0], "FETCH_SIZE_KiB_raw": f[k][0], "launches_sampled": w[k][1], "write_bytes": w[k][0] * 1024,
               "fetch_bytes_raw": f[k][0] * 1024, "fetch_bytes_doubled": 2 * f[k][0] * 1024}
 out["k_cosine_write_bytes_per_launch"] = out["k_cosine_write"]["write_bytes"] + out["k_cosine_write"]["fetch_bytes_doubled"]
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (only for the hash of the kernel sources this summary belongs to)
+
+out["source_sha16"] = bench.kernel_source_sha()
+out["note"] = f"rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE (separate passes), profiles/{tag}_pmc/, kernel sources {out['source_sha16']}"
 json.dump(out, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 b = json.load(open(os.path.join(P, f"bench_{tag}.json")))
 print(f"{b['ms_per_step']:.3f} ms/step  {b['value']:.4g} {b['unit']}  roofline frac {b['roofline']['frac']:.3f}")

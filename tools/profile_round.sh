@@ -6,10 +6,9 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O && rm -rf $O/prof $O/pmc_w $O/pmc_f
-cd $R && python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log
 python bench.py > $O/bench.json 2> $O/bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/prof -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err || exit 1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o write_size -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_w.err || exit 1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o fetch_size -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_f.err || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o write_size -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_w.err || exit 1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o fetch_size -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_f.err || exit 1
 cut -c1-300 $O/bench.json
