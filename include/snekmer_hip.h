@@ -124,13 +124,19 @@ int skm_count_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code
  * flags: SKM_BASIS_ELIDE_SINGLETONS (only with postings and without df/total/first-seen outputs):
  *   k-mers found in a single sequence can only ever contribute to that row's own norm, so their
  *   CSR entries get d_colidx = 0xFFFFFFFF and no posting is written for them; skm_cosine_csr treats
- *   such an entry as "pairs with its own row only".  Saves a third of the random traffic. */
+ *   such an entry as "pairs with its own row only".  Saves a third of the random traffic.
+ *        SKM_BASIS_POST32 (n < 2^24, no d_total): d_post is written as 32-bit words
+ *   row | min(count, 255) << 24 instead of 64-bit ones, which halves the bytes the cosine kernels
+ *   gather (their dominant read).  A stored 255 is an escape: the real count of that posting is
+ *   d_postcnt[its index] (uint32[nnz], touched for such postings only: a k-mer repeated >= 255 times
+ *   within one sequence).  Without the flag d_postcnt is ignored and may be NULL. */
 #define SKM_BASIS_ELIDE_SINGLETONS 1
+#define SKM_BASIS_POST32 2
 int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int flags, int64_t n, int64_t nnz, const int64_t *d_rowptr,
                     const void *d_codes, const uint32_t *d_counts, const uint32_t *d_firstpos,
                     int64_t *h_ncols, void *d_basis, uint32_t *d_colidx, uint32_t *d_df,
                     uint64_t *d_total, uint64_t *d_firstkey, uint32_t *d_fs_order,
-                    uint32_t *d_colptr, uint64_t *d_post);
+                    uint32_t *d_colptr, void *d_post, uint32_t *d_postcnt);
 
 /* Column-major copy (postings) of any CSR with column ids < ncols; rows ascending per column. */
 int skm_csr_transpose(skm_ctx *ctx, int64_t n, int64_t nnz, int64_t ncols, const int64_t *d_rowptr,
@@ -184,10 +190,14 @@ int skm_row_norms_csr(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const ui
  *   out[(i-row0)*ld + j] = <x_i, y_j> * x_rnorm[i] * y_rnorm[j]   for i in [row0,row1), j in [0,m)
  * with the integer dot product exact (int32) and the scaling in float32.
  * mode 0 = similarity; mode 1 = cosine distance as sklearn's pairwise_distances gives it
- * (1 - s clipped to [0,2]; exact 0 where i == j, square case only). */
+ * (1 - s clipped to [0,2]; exact 0 where i == j, square case only).
+ * post_bits: 64 (d_ypost = uint64 words row | count << 32; d_ypostcnt ignored) or 32 (the
+ * SKM_BASIS_POST32 form with its d_ypostcnt side array).
+ * An X entry with d_xcolidx == 0xFFFFFFFF means "k-mer of this row only" (SKM_BASIS_ELIDE_SINGLETONS):
+ * its count squared is added to out[i][i], which is only meaningful in the square case (Y is X). */
 int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
                    const uint32_t *d_xcounts, const float *d_xrnorm, int64_t m, int64_t ncols,
-                   const uint32_t *d_ycolptr, const uint64_t *d_ypost,
+                   const uint32_t *d_ycolptr, const void *d_ypost, int post_bits, const uint32_t *d_ypostcnt,
                    const float *d_yrnorm, int64_t row0, int64_t row1, int mode, float *d_out,
                    int64_t ld);
 
@@ -229,8 +239,9 @@ int skm_csr_group_sum(skm_ctx *ctx, int64_t n, int64_t nnz, const int64_t *d_row
  *   number of entries written (both host-synchronous). */
 int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
                        const uint32_t *d_xcounts, int64_t m, int64_t ncols, const uint32_t *d_ycolptr,
-                       const uint64_t *d_ypost, int64_t row0, int64_t row1, int64_t cap_ent, uint64_t *d_start,
-                       uint32_t *d_len, uint64_t *d_ent, int64_t *h_total_entries, int64_t *h_overflow_rows);
+                       const void *d_ypost, int post_bits, const uint32_t *d_ypostcnt, int64_t row0, int64_t row1,
+                       int64_t cap_ent, uint64_t *d_start, uint32_t *d_len, uint64_t *d_ent,
+                       int64_t *h_total_entries, int64_t *h_overflow_rows);
 
 /* k best cosine neighbours per row from the lists of skm_gram_neighbors: score = dot * xrnorm[row0+r]
  * * yrnorm[j], descending, ties towards the lower j; exclude_self drops j == row0 + r.

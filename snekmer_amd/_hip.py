@@ -61,7 +61,7 @@ _SIGNATURES = {
     ),
     "skm_basis_build": (
         C.c_int,
-        [_p, C.c_int, C.c_int, C.c_int, _i64, _i64, _p, _p, _p, _p, C.POINTER(_i64), _p, _p, _p, _p, _p, _p, _p, _p],
+        [_p, C.c_int, C.c_int, C.c_int, _i64, _i64, _p, _p, _p, _p, C.POINTER(_i64), _p, _p, _p, _p, _p, _p, _p, _p, _p],
     ),
     "skm_csr_transpose": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p]),
     "skm_csr_concat_rowptr": (C.c_int, [_p, C.c_int, _p, _p, _p, _p]),
@@ -74,12 +74,12 @@ _SIGNATURES = {
     "skm_row_norms_csr": (C.c_int, [_p, _i64, _p, _p, _p, _p]),
     "skm_cosine_csr": (
         C.c_int,
-        [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, C.c_int, _p, _i64],
+        [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, C.c_int, _p, _p, _i64, _i64, C.c_int, _p, _i64],
     ),
     "skm_hamming_similarity_from_gram": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _i64]),
     "skm_row_top2": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p]),
     "skm_csr_group_sum": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _p, _p, C.POINTER(_i64)]),
-    "skm_gram_neighbors": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)]),
+    "skm_gram_neighbors": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _p, _p, C.c_int, _p, _i64, _i64, _i64, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)]),
     "skm_neighbors_topk": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p, _p]),
     "skm_jaccard_distance_from_gram": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64]),
     "skm_pair_work": (C.c_int, [_p, _i64, _p, C.POINTER(C.c_uint64)]),

@@ -23,11 +23,25 @@ constexpr int BLK = 256;
 
 __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
 
-// rowcount[e] = (row owning CSR entry e) | count << 32, i.e. the entry's posting word, so that the
-// passes over the sorted order fetch both with one gather; one wave per row.
+// rowcount[e] = the posting word of CSR entry e (row | count << 32, or the 32-bit form row |
+// min(count, 255) << 24 described in skm_gram_kernel.h), so that the pass over the sorted order fetches
+// row and count with one gather; one wave per row.
+template <typename PW>
+__device__ __forceinline__ PW make_posting(uint32_t row, uint32_t count);
+template <>
+__device__ __forceinline__ uint64_t make_posting<uint64_t>(uint32_t row, uint32_t count)
+{
+    return (uint64_t)row | ((uint64_t)count << 32);
+}
+template <>
+__device__ __forceinline__ uint32_t make_posting<uint32_t>(uint32_t row, uint32_t count)
+{
+    return row | ((count < 255u ? count : 255u) << 24);
+}
+
+template <typename PW>
 __global__ __launch_bounds__(BLK) void k_expand_rowid(const int64_t *__restrict__ rowptr, int64_t n,
-                                                      const uint32_t *__restrict__ counts,
-                                                      uint64_t *__restrict__ rowcount)
+                                                      const uint32_t *__restrict__ counts, PW *__restrict__ rowcount)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -35,7 +49,7 @@ __global__ __launch_bounds__(BLK) void k_expand_rowid(const int64_t *__restrict_
     for (int64_t i = wave; i < n; i += nwaves) {
         const int64_t b = rowptr[i], e = rowptr[i + 1];
         for (int64_t t = b + lane; t < e; t += 64)
-            rowcount[t] = (uint64_t)(uint32_t)i | ((uint64_t)counts[t] << 32);
+            rowcount[t] = make_posting<PW>((uint32_t)i, counts[t]);
     }
 }
 
@@ -47,14 +61,16 @@ struct head_flag {
 
 // One pass over the sorted order: column ids back to CSR order, postings, basis codes,
 // column starts and first-seen keys.
-template <typename K>
+template <typename K, typename PW>
 __global__ __launch_bounds__(BLK) void k_basis_scatter(int64_t nnz, const K *__restrict__ skeys,
                                                        const uint32_t *__restrict__ sidx,
                                                        const uint32_t *__restrict__ colid1,
-                                                       const uint64_t *__restrict__ rowcount,
+                                                       const PW *__restrict__ rowcount,
+                                                       const uint32_t *__restrict__ counts,
                                                        const uint32_t *__restrict__ firstpos,
                                                        K *__restrict__ basis, uint32_t *__restrict__ colidx,
-                                                       uint32_t *__restrict__ colptr, uint64_t *__restrict__ post,
+                                                       uint32_t *__restrict__ colptr, PW *__restrict__ post,
+                                                       uint32_t *__restrict__ postcnt,
                                                        uint64_t *__restrict__ firstkey, int elide)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,12 +89,15 @@ __global__ __launch_bounds__(BLK) void k_basis_scatter(int64_t nnz, const K *__r
             continue;
         }
         colidx[e] = c;
-        uint64_t rc = 0;
+        PW rc = 0;
         if (post || (head && firstkey))
             rc = rowcount[e];
-        const uint32_t row = (uint32_t)rc;
-        if (post)
+        const uint32_t row = sizeof(PW) == 8 ? (uint32_t)rc : ((uint32_t)rc & 0x00FFFFFFu);
+        if (post) {
             post[t] = rc;
+            if (sizeof(PW) == 4 && ((uint32_t)rc >> 24) == 255u)  // escape: the real count goes to the side array
+                postcnt[t] = counts[e];
+        }
         if (head) {
             if (basis)
                 basis[c] = key;
@@ -364,11 +383,11 @@ __global__ __launch_bounds__(BLK) void k_row_norms(int64_t n, const int64_t *__r
     }
 }
 
-template <typename K>
+template <typename K, typename PW>
 int basis_impl(skm_ctx *ctx, int key_bits, int flags, int64_t n, int64_t nnz, const int64_t *d_rowptr, const K *d_codes,
                const uint32_t *d_counts, const uint32_t *d_firstpos, int64_t *h_ncols, K *d_basis, uint32_t *d_colidx,
                uint32_t *d_df, uint64_t *d_total, uint64_t *d_firstkey, uint32_t *d_fs_order, uint32_t *d_colptr,
-               uint64_t *d_post)
+               PW *d_post, uint32_t *d_postcnt)
 {
     hipStream_t st = ctx->stream;
     void *p;
@@ -378,20 +397,20 @@ int basis_impl(skm_ctx *ctx, int key_bits, int flags, int64_t n, int64_t nnz, co
     uint32_t *sidx = (uint32_t *)p;
     SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)nnz, &p));
     uint32_t *colid1 = (uint32_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint64_t) * (size_t)nnz, &p));
-    uint64_t *rowcount = (uint64_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_E, sizeof(PW) * (size_t)nnz, &p));
+    PW *rowcount = (PW *)p;
 
     const bool need_stats = d_df || d_total;
     const bool need_fs = d_fs_order != nullptr;
     uint32_t *colptr = d_colptr;
-    uint64_t *post = d_post;
+    PW *post = d_post;
     if (need_stats && !colptr) {
         SKM_TRY(skm_ws(ctx, WS_F, sizeof(uint32_t) * (size_t)(nnz + 1), &p));
         colptr = (uint32_t *)p;
     }
     if (need_stats && d_total && !post) {
-        SKM_TRY(skm_ws(ctx, WS_G, sizeof(uint64_t) * (size_t)nnz, &p));
-        post = (uint64_t *)p;
+        SKM_TRY(skm_ws(ctx, WS_G, sizeof(PW) * (size_t)nnz, &p));
+        post = (PW *)p;
     }
     uint64_t *firstkey = d_firstkey;
     if (need_fs && !firstkey) {
@@ -402,7 +421,7 @@ int basis_impl(skm_ctx *ctx, int key_bits, int flags, int64_t n, int64_t nnz, co
     const int g_ent = skm_grid_cap(ctx, skm_ceil_div(nnz, BLK), 16);
     {
         SKM_PROF(ctx, "k_expand_rowid");
-        k_expand_rowid<<<skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16), BLK, 0, st>>>(d_rowptr, n, d_counts, rowcount);
+        k_expand_rowid<PW><<<skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16), BLK, 0, st>>>(d_rowptr, n, d_counts, rowcount);
     }
     SKM_TRY(skm_check_launch("k_expand_rowid"));
     SKM_TRY(sort_pairs<K>(ctx, d_codes, skeys, sidx, nnz, key_bits, "rocprim_radix_sort_codes"));
@@ -419,8 +438,8 @@ int basis_impl(skm_ctx *ctx, int key_bits, int flags, int64_t n, int64_t nnz, co
         SKM_HIP(hipMemsetAsync(d_colidx, 0xFF, sizeof(uint32_t) * (size_t)nnz, st));
     {
         SKM_PROF(ctx, "k_basis_scatter");
-        k_basis_scatter<K><<<g_ent, BLK, 0, st>>>(nnz, skeys, sidx, colid1, rowcount, d_firstpos, d_basis,
-                                                   d_colidx, colptr, post, firstkey, elide);
+        k_basis_scatter<K, PW><<<g_ent, BLK, 0, st>>>(nnz, skeys, sidx, colid1, rowcount, d_counts, d_firstpos, d_basis,
+                                                       d_colidx, colptr, post, d_postcnt, firstkey, elide);
     }
     SKM_TRY(skm_check_launch("k_basis_scatter"));
     uint32_t *h_b = (uint32_t *)ctx->h_pinned;
@@ -433,7 +452,11 @@ int basis_impl(skm_ctx *ctx, int key_bits, int flags, int64_t n, int64_t nnz, co
     }
     if (need_stats) {
         SKM_PROF(ctx, "k_col_stats");
-        k_col_stats<<<(unsigned)skm_ceil_div(B, BLK), BLK, 0, st>>>(B, colptr, post, d_df, d_total);
+        if constexpr (sizeof(PW) == 8) {
+            k_col_stats<<<(unsigned)skm_ceil_div(B, BLK), BLK, 0, st>>>(B, colptr, post, d_df, d_total);
+        } else {  // 32-bit postings saturate the count: totals are not available (rejected by the entry point)
+            k_col_stats<<<(unsigned)skm_ceil_div(B, BLK), BLK, 0, st>>>(B, colptr, nullptr, d_df, nullptr);
+        }
         SKM_TRY(skm_check_launch("k_col_stats"));
     }
     if (need_fs) {
@@ -451,7 +474,7 @@ extern "C" int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int fl
                                const int64_t *d_rowptr, const void *d_codes, const uint32_t *d_counts,
                                const uint32_t *d_firstpos, int64_t *h_ncols, void *d_basis, uint32_t *d_colidx,
                                uint32_t *d_df, uint64_t *d_total, uint64_t *d_firstkey, uint32_t *d_fs_order,
-                               uint32_t *d_colptr, uint64_t *d_post)
+                               uint32_t *d_colptr, void *d_post, uint32_t *d_postcnt)
 {
     SKM_REQUIRE(ctx && h_ncols && n >= 0 && nnz >= 0, SKM_E_BADARG, "skm_basis_build: bad argument");
     SKM_REQUIRE(code_bits == 32 || code_bits == 64, SKM_E_BADARG, "skm_basis_build: code_bits must be 32 or 64");
@@ -459,6 +482,9 @@ extern "C" int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int fl
     SKM_REQUIRE(!d_fs_order || d_firstpos, SKM_E_BADARG, "skm_basis_build: d_fs_order needs d_firstpos");
     SKM_REQUIRE(!(flags & SKM_BASIS_ELIDE_SINGLETONS) || (d_post && !d_df && !d_total && !d_firstkey && !d_fs_order),
                 SKM_E_BADARG, "skm_basis_build: ELIDE_SINGLETONS needs postings and no df/total/first-seen outputs");
+    const bool p32 = (flags & SKM_BASIS_POST32) != 0;
+    SKM_REQUIRE(!p32 || (d_post && d_postcnt && !d_total && n <= ((int64_t)1 << 24)), SKM_E_BADARG,
+                "skm_basis_build: POST32 needs d_post, d_postcnt, no d_total and fewer than 2^24 rows");
     *h_ncols = 0;
     if (nnz == 0) {
         if (d_colptr)
@@ -469,13 +495,18 @@ extern "C" int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int fl
     if (key_bits <= 0 || key_bits > code_bits)
         key_bits = code_bits;
     SKM_HIP(hipSetDevice(ctx->device));
-    if (code_bits == 32)
-        return basis_impl<uint32_t>(ctx, key_bits, flags, n, nnz, d_rowptr, (const uint32_t *)d_codes, d_counts, d_firstpos,
-                                    h_ncols, (uint32_t *)d_basis, d_colidx, d_df, d_total, d_firstkey, d_fs_order,
-                                    d_colptr, d_post);
-    return basis_impl<uint64_t>(ctx, key_bits, flags, n, nnz, d_rowptr, (const uint64_t *)d_codes, d_counts, d_firstpos,
-                                h_ncols, (uint64_t *)d_basis, d_colidx, d_df, d_total, d_firstkey, d_fs_order, d_colptr,
-                                d_post);
+#define SKM_BASIS(K, PW)                                                                                                   \
+    return basis_impl<K, PW>(ctx, key_bits, flags, n, nnz, d_rowptr, (const K *)d_codes, d_counts, d_firstpos, h_ncols,  \
+                             (K *)d_basis, d_colidx, d_df, d_total, d_firstkey, d_fs_order, d_colptr, (PW *)d_post, d_postcnt)
+    if (code_bits == 32) {
+        if (p32)
+            SKM_BASIS(uint32_t, uint32_t);
+        SKM_BASIS(uint32_t, uint64_t);
+    }
+    if (p32)
+        SKM_BASIS(uint64_t, uint32_t);
+    SKM_BASIS(uint64_t, uint64_t);
+#undef SKM_BASIS
 }
 
 extern "C" int skm_csr_transpose(skm_ctx *ctx, int64_t n, int64_t nnz, int64_t ncols, const int64_t *d_rowptr,
@@ -500,7 +531,7 @@ extern "C" int skm_csr_transpose(skm_ctx *ctx, int64_t n, int64_t nnz, int64_t n
     SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint64_t) * (size_t)nnz, &p));
     uint64_t *rowcount = (uint64_t *)p;
     const int g_ent = skm_grid_cap(ctx, skm_ceil_div(nnz, BLK), 16);
-    k_expand_rowid<<<skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16), BLK, 0, st>>>(d_rowptr, n, d_counts, rowcount);
+    k_expand_rowid<uint64_t><<<skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16), BLK, 0, st>>>(d_rowptr, n, d_counts, rowcount);
     int bits = 1;
     while (bits < 32 && ((int64_t)1 << bits) < ncols)
         ++bits;

@@ -50,13 +50,17 @@ constexpr int Q = 10;  // register-resident tasks per thread -> Q*TB = 2560 task
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE, bool VEC, int ABL>
+// ------------------------------------------------------------------------------- sparse Gram
+#include "skm_gram_kernel.h"
+
+template <int MODE, bool VEC, int ABL, typename PW>
 __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__ xrowptr,
                                                      const uint32_t *__restrict__ xcolidx,
                                                      const uint32_t *__restrict__ xcounts,
                                                      const float *__restrict__ xrnorm, int64_t m,
                                                      const uint32_t *__restrict__ ycolptr,
-                                                     const uint64_t *__restrict__ ypost,
+                                                     const PW *__restrict__ ypost,
+                                                     const uint32_t *__restrict__ ypostcnt,
                                                      const float *__restrict__ yrnorm, int64_t row0, int64_t row1,
                                                      float *__restrict__ out, int64_t ld,
                                                      const uint32_t *__restrict__ strip_list,
@@ -110,9 +114,9 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
                 cur[q] = pb;
                 rem[q] = pe - pb;
                 if (pe > pb) {
-                    const uint64_t pw = ypost[pb];
-                    nj[q] = (uint32_t)pw;
-                    nv[q] = (uint32_t)(pw >> 32);
+                    const PW pw = ypost[pb];
+                    nj[q] = posting<PW>::row(pw);
+                    nv[q] = posting<PW>::count(pw, ypostcnt, pb);
                 }
             }
         }
@@ -139,9 +143,9 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
                     --rem[q];
                     tj[q] = NONE;
                     if (rem[q]) {
-                        const uint64_t pw = ypost[cur[q]];
-                        tj[q] = (uint32_t)pw;
-                        tv[q] = (uint32_t)(pw >> 32);
+                        const PW pw = ypost[cur[q]];
+                        tj[q] = posting<PW>::row(pw);
+                        tv[q] = posting<PW>::count(pw, ypostcnt, cur[q]);
                     }
                 }
             }
@@ -172,17 +176,17 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
             const uint32_t pe = hi;
             while (lo < hi) {
                 uint32_t mid = lo + ((hi - lo) >> 1);
-                if ((uint32_t)ypost[mid] < j0u)
+                if (posting<PW>::row(ypost[mid]) < j0u)
                     lo = mid + 1;
                 else
                     hi = mid;
             }
             for (; lo < pe; ++lo) {
-                const uint64_t pw = ypost[lo];
-                const uint32_t j = (uint32_t)pw;
+                const PW pw = ypost[lo];
+                const uint32_t j = posting<PW>::row(pw);
                 if (j >= j1u)
                     break;
-                atomicAdd(&s_acc[li][j - j0u], v * (int)(uint32_t)(pw >> 32));
+                atomicAdd(&s_acc[li][j - j0u], v * (int)posting<PW>::count(pw, ypostcnt, lo));
             }
         }
         __syncthreads();
@@ -236,8 +240,6 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
     }
 }
 
-// ------------------------------------------------------------------------------- sparse Gram
-#include "skm_gram_kernel.h"
 
 // ------------------------------------------------------------------------------- streaming writer
 // One output row per workgroup, WCH columns per step, WCH/4 threads (4 columns per thread and step).
@@ -512,11 +514,13 @@ __global__ __launch_bounds__(256) void k_neighbors_topk_lds(int64_t nrows, int64
 constexpr int HS_BITS = 17;
 constexpr int HS = 1 << HS_BITS;  // 131072 slots -> up to 65536 neighbours per row
 
+template <typename PW>
 __global__ __launch_bounds__(1024) void k_gram_sparse_huge(const int64_t *__restrict__ xrowptr,
                                                            const uint32_t *__restrict__ xcolidx,
                                                            const uint32_t *__restrict__ xcounts,
                                                            const uint32_t *__restrict__ ycolptr,
-                                                           const uint64_t *__restrict__ ypost, int64_t row0,
+                                                           const PW *__restrict__ ypost,
+                                                           const uint32_t *__restrict__ ypostcnt, int64_t row0,
                                                            uint64_t *__restrict__ g_ent, unsigned long long cap_ent,
                                                            unsigned long long *__restrict__ g_counter,
                                                            uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len,
@@ -559,9 +563,9 @@ __global__ __launch_bounds__(1024) void k_gram_sparse_huge(const int64_t *__rest
                     j = (uint32_t)i;
                     prod = v * v;
                 } else {
-                    const uint64_t pw = ypost[p];
-                    j = (uint32_t)pw;
-                    prod = v * (int)(uint32_t)(pw >> 32);
+                    const PW pw = ypost[p];
+                    j = posting<PW>::row(pw);
+                    prod = v * (int)posting<PW>::count(pw, ypostcnt, p);
                 }
                 const uint32_t key = j + 1u;
                 uint32_t h = (j * 2654435761u) >> (32 - HS_BITS);
@@ -631,11 +635,12 @@ __global__ void k_count_overflow(int64_t nrows, const uint32_t *__restrict__ g_l
 
 }  // namespace
 
-extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
-                                  const uint32_t *d_xcounts, int64_t m, int64_t ncols, const uint32_t *d_ycolptr,
-                                  const uint64_t *d_ypost, int64_t row0, int64_t row1, int64_t cap_ent,
-                                  uint64_t *d_start, uint32_t *d_len, uint64_t *d_ent, int64_t *h_total_entries,
-                                  int64_t *h_overflow_rows)
+namespace {
+template <typename PW>
+int gram_neighbors_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
+                        const uint32_t *d_xcounts, int64_t m, int64_t ncols, const uint32_t *d_ycolptr, const PW *d_ypost,
+                        const uint32_t *d_ypostcnt, int64_t row0, int64_t row1, int64_t cap_ent, uint64_t *d_start,
+                        uint32_t *d_len, uint64_t *d_ent, int64_t *h_total_entries, int64_t *h_overflow_rows)
 {
     SKM_REQUIRE(ctx && n >= 0 && m >= 0 && ncols >= 0 && cap_ent >= 0 && h_total_entries && h_overflow_rows, SKM_E_BADARG,
                 "skm_gram_neighbors: bad argument");
@@ -662,9 +667,9 @@ extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrow
     const unsigned long long cap = (unsigned long long)cap_ent;
     {
         SKM_PROF(ctx, "k_gram_sparse");
-        k_gram_sparse<0, 1, 2048, 256, 2, 32, 2><<<(unsigned)nrows, 256, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr,
-                                                                              d_ypost, row0, row1, 0ull, 0, d_ent, cap,
-                                                                              g_counter, d_start, d_len, list1, cnt1);
+        k_gram_sparse<0, 1, 2048, 256, 2, 32, 2, PW><<<(unsigned)nrows, 256, 0, st>>>(
+            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0, row1, 0ull, 0, d_ent, cap, g_counter, d_start,
+            d_len, list1, cnt1);
     }
     SKM_TRY(skm_check_launch("k_gram_sparse"));
     {
@@ -672,16 +677,16 @@ extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrow
         // fits first (the lists ping-pong): 8192 slots with 256 threads and 512 non-zeros (74 KB of LDS:
         // two workgroups per CU), then 16384 slots / 1024 non-zeros, then 8192 slots / 4096 non-zeros.
         SKM_PROF(ctx, "k_gram_sparse_big");
-        k_gram_sparse_big<8192, 256, 2, 16, 4><<<skm_grid_cap(ctx, nrows, 2), 256, 0, st>>>(
-            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, d_ent, cap, g_counter, d_start, d_len,
+        k_gram_sparse_big<8192, 256, 2, 16, 4, PW><<<skm_grid_cap(ctx, nrows, 2), 256, 0, st>>>(
+            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0, row1, d_ent, cap, g_counter, d_start, d_len,
             list1, cnt1, list2, cnt2);
         SKM_HIP(hipMemsetAsync(cnt1, 0, 4, st));
-        k_gram_sparse_big<16384, 512, 2, 16, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
-            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, d_ent, cap, g_counter, d_start, d_len,
+        k_gram_sparse_big<16384, 512, 2, 16, 4, PW><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
+            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0, row1, d_ent, cap, g_counter, d_start, d_len,
             list2, cnt2, list1, cnt1);
         SKM_HIP(hipMemsetAsync(cnt2, 0, 4, st));
-        k_gram_sparse_big<8192, 512, 8, 16, 4><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
-            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, row1, d_ent, cap, g_counter, d_start, d_len,
+        k_gram_sparse_big<8192, 512, 8, 16, 4, PW><<<skm_grid_cap(ctx, nrows, 1), 512, 0, st>>>(
+            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0, row1, d_ent, cap, g_counter, d_start, d_len,
             list1, cnt1, list2, cnt2);
     }
     SKM_TRY(skm_check_launch("k_gram_sparse_big"));
@@ -690,8 +695,8 @@ extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrow
         const int huge_grid = ctx->num_cus > 0 ? ctx->num_cus : 256;
         SKM_TRY(skm_ws(ctx, WS_G, sizeof(uint32_t) * 2 * (size_t)HS * (size_t)huge_grid, &p));
         SKM_PROF(ctx, "k_gram_sparse_huge");
-        k_gram_sparse_huge<<<huge_grid, 1024, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0, d_ent, cap,
-                                                       g_counter, d_start, d_len, list2, cnt2, (uint32_t *)p);
+        k_gram_sparse_huge<PW><<<huge_grid, 1024, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0,
+                                                           d_ent, cap, g_counter, d_start, d_len, list2, cnt2, (uint32_t *)p);
     }
     SKM_TRY(skm_check_launch("k_gram_sparse_huge"));
     k_count_overflow<<<(unsigned)skm_ceil_div(nrows, 256), 256, 0, st>>>(nrows, d_len, novf);
@@ -703,6 +708,24 @@ extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrow
     *h_total_entries = (int64_t)(h[0] < cap ? h[0] : cap);
     *h_overflow_rows = (int64_t)*(uint32_t *)(h + 1);
     return SKM_OK;
+}
+}  // namespace
+
+extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
+                                  const uint32_t *d_xcounts, int64_t m, int64_t ncols, const uint32_t *d_ycolptr,
+                                  const void *d_ypost, int post_bits, const uint32_t *d_ypostcnt, int64_t row0, int64_t row1,
+                                  int64_t cap_ent, uint64_t *d_start, uint32_t *d_len, uint64_t *d_ent,
+                                  int64_t *h_total_entries, int64_t *h_overflow_rows)
+{
+    SKM_REQUIRE(post_bits == 64 || post_bits == 32, SKM_E_BADARG, "skm_gram_neighbors: post_bits must be 32 or 64");
+    if (post_bits == 32) {
+        SKM_REQUIRE(m <= ((int64_t)1 << 24), SKM_E_BADARG, "skm_gram_neighbors: 32-bit postings hold rows < 2^24");
+        return gram_neighbors_impl<uint32_t>(ctx, n, d_xrowptr, d_xcolidx, d_xcounts, m, ncols, d_ycolptr, (const uint32_t *)d_ypost,
+                                             d_ypostcnt, row0, row1, cap_ent, d_start, d_len, d_ent, h_total_entries,
+                                             h_overflow_rows);
+    }
+    return gram_neighbors_impl<uint64_t>(ctx, n, d_xrowptr, d_xcolidx, d_xcounts, m, ncols, d_ycolptr, (const uint64_t *)d_ypost,
+                                         nullptr, row0, row1, cap_ent, d_start, d_len, d_ent, h_total_entries, h_overflow_rows);
 }
 
 extern "C" int skm_neighbors_topk(skm_ctx *ctx, int64_t nrows, int64_t row0, const uint64_t *d_start, const uint32_t *d_len,
@@ -760,10 +783,12 @@ int overlap_streams(skm_ctx *ctx)
 }
 }  // namespace
 
-extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
-                              const uint32_t *d_xcounts, const float *d_xrnorm, int64_t m, int64_t ncols,
-                              const uint32_t *d_ycolptr, const uint64_t *d_ypost,
-                              const float *d_yrnorm, int64_t row0, int64_t row1, int mode, float *d_out, int64_t ld)
+namespace {
+template <typename PW>
+int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx, const uint32_t *d_xcounts,
+                    const float *d_xrnorm, int64_t m, int64_t ncols, const uint32_t *d_ycolptr, const PW *d_ypost,
+                    const uint32_t *d_ypostcnt, const float *d_yrnorm, int64_t row0, int64_t row1, int mode, float *d_out,
+                    int64_t ld)
 {
     SKM_REQUIRE(ctx && n >= 0 && m >= 0 && ncols >= 0, SKM_E_BADARG, "skm_cosine_csr: bad argument");
     SKM_REQUIRE(row0 >= 0 && row0 <= row1 && row1 <= n, SKM_E_BADARG, "skm_cosine_csr: bad row range [%lld,%lld) of %lld",
@@ -797,8 +822,9 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         }                      \
     } while (0)
 #define SKM_CURSOR(MODE, VEC)                                                                                        \
-    k_cosine_strip<MODE, VEC, 0><<<(unsigned)strips, TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, \
-                                                                   d_ypost, d_yrnorm, row0, row1, d_out, ld, fb_list, fb_count)
+    k_cosine_strip<MODE, VEC, 0, PW><<<(unsigned)strips, TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, \
+                                                                       d_ypost, d_ypostcnt, d_yrnorm, row0, row1, d_out, ld,   \
+                                                                       fb_list, fb_count)
 
     uint32_t *fb_list = nullptr, *fb_count = nullptr;
 #ifdef SKM_DIAG
@@ -808,8 +834,9 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
     if (abl >= 1 && abl <= 3 && mode == 0 && vec) {
         SKM_PROF(ctx, "k_cosine_strip");
 #define SKM_CURSOR_ABL(ABL)                                                                                          \
-    k_cosine_strip<0, true, ABL><<<(unsigned)strips, TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, \
-                                                                   d_ypost, d_yrnorm, row0, row1, d_out, ld, nullptr, nullptr)
+    k_cosine_strip<0, true, ABL, PW><<<(unsigned)strips, TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, \
+                                                                       d_ypost, d_ypostcnt, d_yrnorm, row0, row1, d_out, ld,   \
+                                                                       nullptr, nullptr)
         if (abl == 1)
             SKM_CURSOR_ABL(1);
         else if (abl == 2)
@@ -892,9 +919,9 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
             // one row per workgroup, 2048 slots: 26 KB of LDS -> 6 workgroups per CU
             SKM_PROF_ON(ctx, "k_gram_sparse", gs);
 #define SKM_GRAM(GABL)                                                                                               \
-    k_gram_sparse<GABL, 1, 2048, 256, 2, 32, 2><<<(unsigned)bn, 256, 0, gs>>>(                                       \
-        d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0 + b0, row0 + b1, SLOT, b0, g_ent, cap_ent, g_counter, \
-        g_start + b0, g_len + b0, b_over_list, b_over_count)
+    k_gram_sparse<GABL, 1, 2048, 256, 2, 32, 2, PW><<<(unsigned)bn, 256, 0, gs>>>(                                   \
+        d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0 + b0, row0 + b1, SLOT, b0, g_ent, cap_ent, \
+        g_counter, g_start + b0, g_len + b0, b_over_list, b_over_count)
 #ifdef SKM_DIAG
             if (gabl == 1)
                 SKM_GRAM(1);
@@ -915,8 +942,8 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         {
             // rows the small tables cannot hold: 8192 slots and up to 4096 non-zeros, one row per workgroup
             SKM_PROF_ON(ctx, "k_gram_sparse_big", gs);
-            k_gram_sparse_big<8192, 512, 8, 16, 4><<<skm_grid_cap(ctx, bn, 1), 512, 0, gs>>>(
-                d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, row0 + b0, row0 + b1, g_ent, cap_ent, g_counter,
+            k_gram_sparse_big<8192, 512, 8, 16, 4, PW><<<skm_grid_cap(ctx, bn, 1), 512, 0, gs>>>(
+                d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0 + b0, row0 + b1, g_ent, cap_ent, g_counter,
                 g_start + b0, g_len + b0, b_over_list, b_over_count, nullptr, nullptr);
         }
         SKM_TRY(skm_check_launch("k_gram_sparse_big"));
@@ -955,6 +982,22 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
 #undef SKM_CURSOR
 #undef SKM_BY_MODE_VEC
     return skm_check_launch("k_cosine_strip");
+}
+}  // namespace
+
+extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
+                              const uint32_t *d_xcounts, const float *d_xrnorm, int64_t m, int64_t ncols,
+                              const uint32_t *d_ycolptr, const void *d_ypost, int post_bits, const uint32_t *d_ypostcnt,
+                              const float *d_yrnorm, int64_t row0, int64_t row1, int mode, float *d_out, int64_t ld)
+{
+    SKM_REQUIRE(post_bits == 64 || post_bits == 32, SKM_E_BADARG, "skm_cosine_csr: post_bits must be 32 or 64");
+    if (post_bits == 32) {
+        SKM_REQUIRE(m <= ((int64_t)1 << 24), SKM_E_BADARG, "skm_cosine_csr: 32-bit postings hold rows < 2^24");
+        return cosine_csr_impl<uint32_t>(ctx, n, d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, ncols, d_ycolptr,
+                                         (const uint32_t *)d_ypost, d_ypostcnt, d_yrnorm, row0, row1, mode, d_out, ld);
+    }
+    return cosine_csr_impl<uint64_t>(ctx, n, d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, ncols, d_ycolptr,
+                                     (const uint64_t *)d_ypost, nullptr, d_yrnorm, row0, row1, mode, d_out, ld);
 }
 
 #ifdef SKM_DIAG

@@ -24,6 +24,28 @@
 __device__ unsigned long long g_gram_phase_ticks[8];
 #endif
 
+// Posting words.  64-bit form: row | count << 32.  32-bit form (half the gather bytes; rows < 2^24):
+// row | min(count, 255) << 24, where 255 is an escape: the real count is postcnt[position], a side
+// array that is written and read for such postings only (a k-mer repeated >= 255 times in one row).
+template <typename PW>
+struct posting;
+template <>
+struct posting<uint64_t> {
+    static __device__ __forceinline__ uint32_t row(uint64_t w) { return (uint32_t)w; }
+    static __device__ __forceinline__ uint32_t count(uint64_t w, const uint32_t *, uint32_t) { return (uint32_t)(w >> 32); }
+};
+template <>
+struct posting<uint32_t> {
+    static __device__ __forceinline__ uint32_t row(uint32_t w) { return w & 0x00FFFFFFu; }
+    static __device__ __forceinline__ uint32_t count(uint32_t w, const uint32_t *postcnt, uint32_t at)
+    {
+        uint32_t c = w >> 24;
+        if (__builtin_expect(c == 255u, 0))
+            c = postcnt[at];
+        return c;
+    }
+};
+
 constexpr uint32_t G_OVERFLOW = 0xFFFFFFFFu;
 constexpr uint32_t G_SINGLETON = 0xFFFFFFFFu;  // colidx of a k-mer that occurs in one row only
 
@@ -31,12 +53,13 @@ constexpr uint32_t G_SINGLETON = 0xFFFFFFFFu;  // colidx of a k-mer that occurs 
 // GR    rows per workgroup           GH  hash slots per row (at most 3/4 GH distinct neighbours)
 // GT    threads per workgroup        GQ  non-zeros per thread (GQ*GT non-zeros per strip)
 // G     lanes that share one posting list          U  posting loads a lane issues before it inserts
-template <int GABL, int GR, int GH, int GT, int GQ, int G, int U>
+template <int GABL, int GR, int GH, int GT, int GQ, int G, int U, typename PW>
 __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__restrict__ xrowptr,
                                                     const uint32_t *__restrict__ xcolidx,
                                                     const uint32_t *__restrict__ xcounts,
                                                     const uint32_t *__restrict__ ycolptr,
-                                                    const uint64_t *__restrict__ ypost, int64_t row0, int64_t row1,
+                                                    const PW *__restrict__ ypost,
+                                                    const uint32_t *__restrict__ ypostcnt, int64_t row0, int64_t row1,
                                                     unsigned long long fixed_stride, int64_t slot0,
                                                     uint64_t *__restrict__ g_ent, unsigned long long cap_ent,
                                                     unsigned long long *__restrict__ g_counter,
@@ -254,25 +277,26 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     // all first-probe key reads, then the adds
     // `uniform`: every lane of the wave makes this call together (the queue counter is wave-uniform);
     // elsewhere misses take the general insert directly.
-    auto insert_batch = [&](const auto &pw, uint32_t df, int v, int li, uint32_t first, uint32_t stride, auto uniform) {
+    auto insert_batch = [&](const auto &pw, uint32_t start, uint32_t df, int v, int li, uint32_t first, uint32_t stride,
+                            auto uniform) {
         constexpr int UU = (int)(sizeof(pw) / sizeof(pw[0]));
         if (GABL == 4) {  // diagnostic: loads only, no hash insert
 #pragma unroll
             for (int u = 0; u < UU; ++u)
-                asm volatile("" ::"v"((uint32_t)pw[u]), "v"((uint32_t)(pw[u] >> 32)));
+                asm volatile("" ::"v"((uint32_t)pw[u]), "v"((uint32_t)((uint64_t)pw[u] >> 16)));
             return;
         }
         uint32_t hh[UU], seen[UU];
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
-            hh[u] = ((uint32_t)pw[u] * 2654435761u) >> (32 - HBITS);
+            hh[u] = (posting<PW>::row(pw[u]) * 2654435761u) >> (32 - HBITS);
             seen[u] = __atomic_load_n(&hkeys[li][hh[u]], __ATOMIC_RELAXED);
         }
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
             const bool valid = first + u * stride < df;
-            const uint32_t j = (uint32_t)pw[u];
-            const uint32_t prod = (uint32_t)v * (uint32_t)(pw[u] >> 32);
+            const uint32_t j = posting<PW>::row(pw[u]);
+            const uint32_t prod = (uint32_t)v * posting<PW>::count(pw[u], ypostcnt, valid ? start + first + u * stride : 0u);
             const bool hit = valid && seen[u] == j + 1u;
             if (hit)
                 atomicAdd(&hvals[li][hh[u]], (int)prod);
@@ -294,9 +318,9 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     // workgroup walk of one list: every wave runs the same number of steps with all lanes
     auto walk_all = [&](uint32_t start, uint32_t df, int v, int li) {
         for (uint32_t p0 = 0; p0 < df && !s_over; p0 += GT * U) {
-            uint64_t pw[U];
+            PW pw[U];
             load_batch(pw, start, df, p0 + (uint32_t)tid, GT);
-            insert_batch(pw, df, v, li, p0 + (uint32_t)tid, GT, std::true_type{});
+            insert_batch(pw, start, df, v, li, p0 + (uint32_t)tid, GT, std::true_type{});
         }
     };
     // Bins 0-2: GC consecutive lanes walk one list, UC postings per lane and step, software
@@ -309,27 +333,27 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     auto run_bin = [&](auto gc_, auto uc_, int tb, int te) {
         constexpr int GC = decltype(gc_)::value, UC = decltype(uc_)::value, NGC = GT / GC;
         const uint32_t gl = (uint32_t)(tid % GC);
-        auto fetch = [&](uint64_t (&pw)[UC], int t) -> hdr {
+        auto fetch = [&](PW (&pw)[UC], int t) -> hdr {
             hdr h = {0u, 0u, 0u};
             if (t < te)
                 h = {t_start[t], t_df[t], t_liv[t]};
             load_batch(pw, h.start, h.df, gl, GC);
             return h;
         };
-        auto consume = [&](const uint64_t (&pw)[UC], const hdr &h) {
+        auto consume = [&](const PW (&pw)[UC], const hdr &h) {
             const int v = (int)(h.lv & 0x0FFFFFFFu), li = (int)(h.lv >> 28);
-            insert_batch(pw, h.df, v, li, gl, GC, std::true_type{});
+            insert_batch(pw, h.start, h.df, v, li, gl, GC, std::true_type{});
             if (h.df > (uint32_t)(GC * UC)) {  // the rest of a list longer than one batch (bin 2 only)
                 for (uint32_t p = gl + GC * UC; p < h.df && !s_over; p += GC * UC) {
-                    uint64_t more[UC];  // lanes of one wave may be in different lists here:
+                    PW more[UC];  // lanes of one wave may be in different lists here:
                     load_batch(more, h.start, h.df, p, GC);  // misses are inserted directly
-                    insert_batch(more, h.df, v, li, p, GC, std::false_type{});
+                    insert_batch(more, h.start, h.df, v, li, p, GC, std::false_type{});
                 }
             }
         };
         // D register sets used in turn (no copies: a copy would wait for the load)
         constexpr int D = 2;
-        uint64_t buf[D][UC];
+        PW buf[D][UC];
         hdr hd[D];
         int t = tb + tid / GC;
         int tw = tb + (tid >> 6) * (64 / GC);  // the wave's first list: every lane of a wave runs the
@@ -412,30 +436,33 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
 }
 
 // One strip of GR consecutive rows per workgroup.
-template <int GABL, int GR, int GH, int GT, int GQ, int G, int U>
+template <int GABL, int GR, int GH, int GT, int GQ, int G, int U, typename PW>
 __global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ xrowptr,
                                                     const uint32_t *__restrict__ xcolidx,
                                                     const uint32_t *__restrict__ xcounts,
                                                     const uint32_t *__restrict__ ycolptr,
-                                                    const uint64_t *__restrict__ ypost, int64_t row0, int64_t row1,
+                                                    const PW *__restrict__ ypost,
+                                                    const uint32_t *__restrict__ ypostcnt, int64_t row0, int64_t row1,
                                                     unsigned long long fixed_stride, int64_t slot0,
                                                     uint64_t *__restrict__ g_ent, unsigned long long cap_ent,
                                                     unsigned long long *__restrict__ g_counter,
                                                     uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len,
                                                     uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_count)
 {
-    gram_strip<GABL, GR, GH, GT, GQ, G, U>(row0 + (int64_t)blockIdx.x * GR, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0,
-                                         row1, fixed_stride, slot0, g_ent, cap_ent, g_counter, g_start, g_len, over_list, over_count);
+    gram_strip<GABL, GR, GH, GT, GQ, G, U, PW>(row0 + (int64_t)blockIdx.x * GR, xrowptr, xcolidx, xcounts, ycolptr, ypost,
+                                             ypostcnt, row0, row1, fixed_stride, slot0, g_ent, cap_ent, g_counter, g_start,
+                                             g_len, over_list, over_count);
 }
 
 // Second pass with a large table (one row per workgroup) over the rows the first pass listed.
 // The grid is fixed; workgroups stride over the list, whose length is only known on the device.
-template <int GH, int GT, int GQ, int G, int U>
+template <int GH, int GT, int GQ, int G, int U, typename PW>
 __global__ __launch_bounds__(GT) void k_gram_sparse_big(const int64_t *__restrict__ xrowptr,
                                                         const uint32_t *__restrict__ xcolidx,
                                                         const uint32_t *__restrict__ xcounts,
                                                         const uint32_t *__restrict__ ycolptr,
-                                                        const uint64_t *__restrict__ ypost, int64_t row0, int64_t row1,
+                                                        const PW *__restrict__ ypost,
+                                                        const uint32_t *__restrict__ ypostcnt, int64_t row0, int64_t row1,
                                                         uint64_t *__restrict__ g_ent,
                                                         unsigned long long cap_ent,
                                                         unsigned long long *__restrict__ g_counter,
@@ -449,8 +476,8 @@ __global__ __launch_bounds__(GT) void k_gram_sparse_big(const int64_t *__restric
     for (uint32_t idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
         const int64_t i0 = row0 + row_list[idx];
         // a one-row strip: clamp row1 so that the strip never spills into the next row
-        gram_strip<0, 1, GH, GT, GQ, G, U>(i0, xrowptr, xcolidx, xcounts, ycolptr, ypost, row0, i0 + 1, 0ull, 0, g_ent, cap_ent,
-                                         g_counter, g_start, g_len, over_list, over_count);
+        gram_strip<0, 1, GH, GT, GQ, G, U, PW>(i0, xrowptr, xcolidx, xcounts, ycolptr, ypost, ypostcnt, row0, i0 + 1, 0ull, 0,
+                                             g_ent, cap_ent, g_counter, g_start, g_len, over_list, over_count);
         __syncthreads();
     }
 }

@@ -94,6 +94,10 @@ class Basis:
         self.ncols = 0
         self.codes = self.df = self.total = self.firstkey = self.fs_order = None
         self.colptr = self.post = None
+        # posting words: 64 = row | count << 32; 32 = row | min(count, 255) << 24 with the real counts of
+        # saturated postings in `postcnt` (include/snekmer_hip.h, SKM_BASIS_POST32)
+        self.post_bits = 64
+        self.postcnt = None
 
 
 def recode(ctx: _hip.Context, batch: SeqBatch, lut: AlphabetLUT) -> Tuple[np.ndarray, np.ndarray]:
@@ -143,10 +147,12 @@ def count_csr(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int, with_firstpos: boo
 
 
 def build_basis(ctx, csr: CountsCSR, nsym: int, k: int, stats: bool = False, first_seen: bool = False,
-                postings: bool = True, out: Optional[Basis] = None, elide_singletons: bool = False) -> Basis:
+                postings: bool = True, out: Optional[Basis] = None, elide_singletons: bool = False,
+                post32: bool = False) -> Basis:
     """a11: observed basis (ascending codes), column ids for `csr`, optional stats / first-seen
     order / postings.  With `elide_singletons` (cosine-only use) entries of k-mers that occur in a
-    single sequence get colidx 0xFFFFFFFF and no posting (see include/snekmer_hip.h)."""
+    single sequence get colidx 0xFFFFFFFF and no posting (see include/snekmer_hip.h).  `post32` asks
+    for 4-byte posting words (fewer than 2^24 rows, no stats): half the bytes the cosine kernels gather."""
     nnz = csr.nnz
     b = out or Basis()
     cap = max(nnz, 1)
@@ -167,16 +173,20 @@ def build_basis(ctx, csr: CountsCSR, nsym: int, k: int, stats: bool = False, fir
             raise ValueError("first_seen=True needs count_csr(..., with_firstpos=True)")
         b.firstkey = need(b.firstkey, cap, np.uint64)
         b.fs_order = need(b.fs_order, cap, np.uint32)
+    post32 = bool(post32 and postings and not stats and csr.n < (1 << 24))
     if postings:
         b.colptr = need(b.colptr, cap + 1, np.uint32)
-        b.post = need(b.post, cap, np.uint64)
+        b.post = need(b.post, cap, np.uint32 if post32 else np.uint64)
+        b.postcnt = need(b.postcnt, cap, np.uint32) if post32 else None
+    b.post_bits = 32 if post32 else 64
     ncols = _i64(0)
+    flags = (1 if elide_singletons else 0) | (2 if post32 else 0)
     ctx.call(
-        "skm_basis_build", csr.code_bits, key_bits(nsym, k), 1 if elide_singletons else 0, _i64(csr.n), _i64(nnz), _ptr(csr.rowptr), _ptr(csr.codes),
+        "skm_basis_build", csr.code_bits, key_bits(nsym, k), flags, _i64(csr.n), _i64(nnz), _ptr(csr.rowptr), _ptr(csr.codes),
         _ptr(csr.counts), _ptr(csr.firstpos if first_seen else None), C.byref(ncols), _ptr(b.codes), _ptr(csr.colidx),
         _ptr(b.df if stats else None), _ptr(b.total if stats else None), _ptr(b.firstkey if first_seen else None),
         _ptr(b.fs_order if first_seen else None), _ptr(b.colptr if postings else None),
-        _ptr(b.post if postings else None),
+        _ptr(b.post if postings else None), _ptr(b.postcnt if post32 else None),
     )
     b.ncols = int(ncols.value)
     return b
@@ -224,8 +234,10 @@ def transpose(ctx, n: int, nnz: int, ncols: int, rowptr, colidx, counts):
 
 
 def cosine_matrix(ctx, x: CountsCSR, x_rnorm, m: int, ncols: int, colptr, post, y_rnorm,
-                  row0: int = 0, row1: Optional[int] = None, mode: int = 0, out=None, ld: Optional[int] = None):
-    """a13/a14: float32 block [row1-row0, m] of cosine similarities (mode 0) or distances (mode 1)."""
+                  row0: int = 0, row1: Optional[int] = None, mode: int = 0, out=None, ld: Optional[int] = None,
+                  post_bits: int = 64, postcnt=None):
+    """a13/a14: float32 block [row1-row0, m] of cosine similarities (mode 0) or distances (mode 1).
+    `post_bits` / `postcnt`: the posting format of `post` (Basis.post_bits / Basis.postcnt)."""
     row1 = x.n if row1 is None else row1
     ld = m if ld is None else ld
     rows = row1 - row0
@@ -233,7 +245,7 @@ def cosine_matrix(ctx, x: CountsCSR, x_rnorm, m: int, ncols: int, colptr, post, 
         out = ctx.empty((max(rows, 1), max(ld, 1)), np.float32)
     ctx.call(
         "skm_cosine_csr", _i64(x.n), _ptr(x.rowptr), _ptr(x.colidx), _ptr(x.counts), _ptr(x_rnorm), _i64(m), _i64(ncols),
-        _ptr(colptr), _ptr(post), _ptr(y_rnorm), _i64(row0), _i64(row1), mode, _ptr(out), _i64(ld),
+        _ptr(colptr), _ptr(post), post_bits, _ptr(postcnt), _ptr(y_rnorm), _i64(row0), _i64(row1), mode, _ptr(out), _i64(ld),
     )
     return out
 
@@ -301,7 +313,7 @@ class NeighborLists:
 
 
 def gram_neighbors(ctx, x: CountsCSR, m: int, ncols: int, colptr, post, row0: int = 0, row1: Optional[int] = None,
-                   cap_entries: Optional[int] = None) -> NeighborLists:
+                   cap_entries: Optional[int] = None, post_bits: int = 64, postcnt=None) -> NeighborLists:
     """Neighbour lists (exact sparse Gram rows) for rows [row0,row1) of `x` against the postings of an
     m-row matrix: the reduced output when the dense matrix cannot be stored (skm_gram_neighbors)."""
     row1 = x.n if row1 is None else row1
@@ -312,8 +324,8 @@ def gram_neighbors(ctx, x: CountsCSR, m: int, ncols: int, colptr, post, row0: in
     ent = ctx.empty(max(cap, 1), np.uint64)
     total, ovf = _i64(0), _i64(0)
     ctx.call("skm_gram_neighbors", _i64(x.n), _ptr(x.rowptr), _ptr(x.colidx), _ptr(x.counts), _i64(m), _i64(ncols),
-             _ptr(colptr), _ptr(post), _i64(row0), _i64(row1), _i64(cap), _ptr(start), _ptr(length), _ptr(ent),
-             C.byref(total), C.byref(ovf))
+             _ptr(colptr), _ptr(post), post_bits, _ptr(postcnt), _i64(row0), _i64(row1), _i64(cap), _ptr(start), _ptr(length),
+             _ptr(ent), C.byref(total), C.byref(ovf))
     return NeighborLists(ctx, row0, row1, start, length, ent, int(total.value), int(ovf.value))
 
 
@@ -362,8 +374,12 @@ class Pipeline:
     N x N float32 cosine) resident in HBM.
     """
 
-    def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int):
+    def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int, post32: bool = False):
         self.ctx, self.lut, self.k = ctx, lut, k
+        # 4-byte posting words (batches under 2^24 sequences): half the posting bytes, but measured SLOWER
+        # end to end on MI355X (k_gram_sparse is bound by instruction issue and the decode costs
+        # instructions: 1.90 vs 1.75 ms at BASELINE configs[2]), so it is opt-in
+        self.post32 = post32
         self.csr: Optional[CountsCSR] = None
         self.basis: Optional[Basis] = None
         self.rnorm = None
@@ -371,7 +387,8 @@ class Pipeline:
 
     def vectorize(self, batch: SeqBatch) -> CountsCSR:
         self.csr = count_csr(self.ctx, batch, self.lut, self.k, out=self.csr)
-        self.basis = build_basis(self.ctx, self.csr, self.lut.nsym, self.k, out=self.basis, elide_singletons=True)
+        self.basis = build_basis(self.ctx, self.csr, self.lut.nsym, self.k, out=self.basis, elide_singletons=True,
+                                 post32=self.post32)
         self.rnorm = row_norms(self.ctx, self.csr.n, self.csr.rowptr, self.csr.counts, out=self.rnorm)
         return self.csr
 
@@ -385,7 +402,7 @@ class Pipeline:
             self.out = self.ctx.empty((max(rows, 1), max(ld, 1)), np.float32)
         b = self.basis
         cosine_matrix(self.ctx, self.csr, self.rnorm, n, b.ncols, b.colptr, b.post, self.rnorm,
-                      row0=row0, row1=row1, out=self.out, ld=ld)
+                      row0=row0, row1=row1, out=self.out, ld=ld, post_bits=b.post_bits, postcnt=b.postcnt)
         return self.out
 
     def step(self, batch: SeqBatch):

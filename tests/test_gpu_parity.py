@@ -286,7 +286,7 @@ def test_cosine_medium_vs_oracle_all_modes(ctx):
     assert (S_cur == S).all()
     # distance mode
     b = pipe.basis
-    D = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, b.ncols, b.colptr, b.post, pipe.rnorm, mode=1,
+    D = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, b.ncols, b.colptr, b.post, pipe.rnorm, mode=1, post_bits=b.post_bits, postcnt=b.postcnt,
                              ld=pipe.out.shape[1]).download().reshape(-1, pipe.out.shape[1])[:n, :n]
     refD = np.clip(1.0 - ref, 0, 2)
     np.fill_diagonal(refD, 0.0)
@@ -940,7 +940,7 @@ def test_gram_neighbors_and_topk_vs_oracle(ctx):
     n = batch.n
     b = pipe.basis
     lo, hi = 100, 1100
-    nb = engine.gram_neighbors(ctx, pipe.csr, n, b.ncols, b.colptr, b.post, row0=lo, row1=hi)
+    nb = engine.gram_neighbors(ctx, pipe.csr, n, b.ncols, b.colptr, b.post, row0=lo, row1=hi, post_bits=b.post_bits, postcnt=b.postcnt)
     start, length, jj, dot = nb.host()
     o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
     ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
@@ -1034,7 +1034,7 @@ def test_fuzz_small_batches_all_alphabets(ctx):
         assert (b.fs_order.download(b.ncols) == np.argsort(ofk, kind="stable")).all()
         assert (csr.colidx.download(csr.nnz) == ocol).all()
         rn = engine.row_norms(ctx, n, csr.rowptr, csr.counts)
-        out = engine.cosine_matrix(ctx, csr, rn, n, b.ncols, b.colptr, b.post, rn, ld=(n + 3) // 4 * 4)
+        out = engine.cosine_matrix(ctx, csr, rn, n, b.ncols, b.colptr, b.post, rn, ld=(n + 3) // 4 * 4, post_bits=b.post_bits, postcnt=b.postcnt)
         S = out.download().reshape(out.shape)[:n, :n]
         ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), np.arange(n))
         assert np.abs(S - ref).max() <= COS_TOL, (trial, name, k)
@@ -1069,11 +1069,50 @@ def test_c_abi_error_codes_and_messages(ctx):
     assert lib.skm_cosine_dense_i8(ctx.handle, C.c_int64(4), C.c_int64(4), C.c_int64(100), None, None, None, None, 0, None,
                                    C.c_int64(4)) == -1
     with pytest.raises(_hip.HipError) as e:
-        ctx.call("skm_cosine_csr", C.c_int64(4), None, None, None, None, C.c_int64(4), C.c_int64(1), None, None, None,
+        ctx.call("skm_cosine_csr", C.c_int64(4), None, None, None, None, C.c_int64(4), C.c_int64(1), None, None, 64, None, None,
                  C.c_int64(3), C.c_int64(2), 0, None, C.c_int64(4))
     assert e.value.code == -1 and "row range" in str(e.value)
     out = C.c_void_p()
     assert lib.skm_create(99, C.byref(out)) == -1 and b"out of range" in lib.skm_last_error()
+
+
+def test_posting_formats_agree_incl_saturated_counts(ctx):
+    """32-bit posting words (row | min(count,255) << 24 + side array for saturated counts) against the
+    64-bit form, on a batch with k-mers repeated hundreds of times inside one sequence."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.utils import pack_sequences
+
+    orc = _oracle()
+    lut = A.build_lut("hydro")
+    k = 6
+    seqs, _ = _mixed_batch(seed=21, n=300, long_lengths=(600, 2100))
+    seqs += ["A" * 700, "A" * 300 + "MKVL" + "A" * 400, "AG" * 500, "MKVLAAGIWSTC" * 60]
+    res, off = pack_sequences(seqs)
+    batch = engine.SeqBatch(ctx, res, off)
+    n = batch.n
+    outs = []
+    for p32 in (False, True):
+        pipe = engine.Pipeline(ctx, lut, k, post32=p32)
+        out = pipe.step(batch)
+        assert pipe.basis.post_bits == (32 if p32 else 64)
+        outs.append(out.download().reshape(out.shape)[:n, :n].copy())
+        nb = engine.gram_neighbors(ctx, pipe.csr, n, pipe.basis.ncols, pipe.basis.colptr, pipe.basis.post,
+                                   post_bits=pipe.basis.post_bits, postcnt=pipe.basis.postcnt)
+        outs.append(nb.host())
+    assert (outs[0] == outs[2]).all()
+
+    def rows_of(h):
+        start, length, jj, dot = h
+        return [sorted(zip(jj[int(s) : int(s) + int(l)].tolist(), dot[int(s) : int(s) + int(l)].tolist()))
+                for s, l in zip(start, length)]
+
+    assert rows_of(outs[1]) == rows_of(outs[3])
+    assert int(pipe.csr.counts.download(pipe.csr.nnz).max()) >= 255  # the escape path really ran
+    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
+    ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), np.arange(n))
+    assert np.abs(outs[2] - ref).max() <= COS_TOL
 
 
 # ------------------------------------------------------------------ f1: fused apply epilogue vs the reference rule body
@@ -1304,7 +1343,8 @@ def test_config4_one_rank_share_125k_rows_vs_1m(ctx):
     pipe = engine.Pipeline(ctx, lut, k)
     pipe.vectorize(batch)
     b = pipe.basis
-    nb = engine.gram_neighbors(ctx, pipe.csr, n, b.ncols, b.colptr, b.post, row0=0, row1=block, cap_entries=block * 6000)
+    nb = engine.gram_neighbors(ctx, pipe.csr, n, b.ncols, b.colptr, b.post, row0=0, row1=block, cap_entries=block * 6000,
+                               post_bits=b.post_bits, postcnt=b.postcnt)
     assert nb.overflow_rows == 0
     idx, val = engine.neighbors_topk(ctx, nb, pipe.rnorm, pipe.rnorm, topk, exclude_self=True)
     # ---- oracle, all host cores

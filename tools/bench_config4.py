@@ -79,7 +79,7 @@ for rnd in range(2):
     b = pipe.basis
     t0 = time.perf_counter()
     nb = engine.gram_neighbors(ctx, pipe.csr, n, b.ncols, b.colptr, b.post, row0=0, row1=block,
-                               cap_entries=block * 6000)
+                               cap_entries=block * 6000, post_bits=b.post_bits, postcnt=b.postcnt)
     ctx.sync()
     t_nb = time.perf_counter() - t0
     t0 = time.perf_counter()
