@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_cosine_dense_i8_v2(int64_t n, int64_t m
 constexpr int BM3 = 256, BN3 = 256;
 constexpr int STAGE3_BYTES = (BM3 + BN3) * BK2;  // 64 KiB
 
-template <int MODE>
+template <int MODE, int ABL = 0>  // ABL (SKM_DIAG only, results invalid): 3 no MFMA
 __global__ __launch_bounds__(512) void k_cosine_dense_i8_v3(int64_t n, int64_t m, int64_t kdim,
                                                             const int8_t *__restrict__ X,
                                                             const int8_t *__restrict__ Y,
@@ -360,8 +360,12 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v3(int64_t n, int64_t m
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 2; ++b) {
+                    if (ABL != 3)
+                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                    else
+                        asm volatile("" ::"v"(fa[a]), "v"(fb[b]));
+                }
         }
     }
 
@@ -389,6 +393,234 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v3(int64_t n, int64_t m
     }
 }
 
+
+
+// ------------------------------------------------------------------------------- i8 MFMA cosine, v4
+// The v3 tile (256 x 256, 8 waves of 128 x 64) with the K loop restructured so that the two waves that
+// share a SIMD never want the same pipe at the same time.  In v3 all eight waves issue their LDS-DMA
+// staging, then all read fragments, then all run MFMAs: while the staging instructions issue (60-185
+// cycles each on this chip) and the fragment reads return, the matrix pipe idles (PMC: busy 48 %).
+// Here a K stage is 64 bytes deep (32 KiB of LDS, a ring of four), every stage is cut into a LOAD
+// interval (12 fragment reads into registers) and a COMPUTE interval (16 MFMAs on registers, with the 4
+// LDS-DMA instructions for the stage three ahead issued between them), each closed by one raw
+// s_barrier, and waves 4-7 run one interval behind waves 0-3 (one extra barrier up front): on every
+// SIMD one wave computes while its partner loads.
+//   RAW  stage s+1 is read in L(s+1).  Every wave waits (counted vmcnt) for ITS part of stage s+1 at the
+//        end of its own L(s); the later of the two groups does so in the interval before group 0's
+//        L(s+1), so the barrier between them orders every part.
+//   WAR  stage s+3 goes to the slot of stage s-1, last read in L(s-1), whose reads are waited for
+//        (lgkmcnt(0)) before the barrier that closes it; the first writer issues two intervals later.
+// SYM (X is Y): only tiles on or above the diagonal are computed; a tile above it is also stored
+// transposed (four consecutive rows of an accumulator column are 16 contiguous bytes of the mirror).
+constexpr int BK4 = 64;
+constexpr int NSLOT4 = 4;
+constexpr int SLOT4_BYTES = (BM3 + BN3) * BK4;  // 32 KiB
+
+// ABL (SKM_DIAG builds only; results invalid): 1 no staging inside the K loop, 2 fragments read once, 3 no MFMA
+template <int MODE, bool SYM, int ABL = 0>
+__global__ __launch_bounds__(512) void k_cosine_dense_i8_v4(int64_t n, int64_t m, int64_t kdim,
+                                                            const int8_t *__restrict__ X,
+                                                            const int8_t *__restrict__ Y,
+                                                            const float *__restrict__ xr,
+                                                            const float *__restrict__ yr, float *__restrict__ out,
+                                                            int64_t ld)
+{
+    __shared__ __attribute__((aligned(16))) int8_t s_t[NSLOT4 * SLOT4_BYTES];  // the ONLY shared object (128 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 2, wc = wid & 3;
+    const int64_t nty = (n + BM3 - 1) / BM3, ntx = (m + BN3 - 1) / BN3;
+    const int64_t nsx = (ntx + 7) / 8;
+    const int64_t nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+    const int64_t seq = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+    int64_t st = seq / 32;
+    const int64_t within = seq % 32;
+    int64_t sy, sx;
+    if (SYM) {
+        // only the 4 x 8 supertiles that reach the diagonal or lie above it are enumerated (row sy keeps
+        // columns sx >= sy / 2), so that every XCD's contiguous share of the grid holds the same amount of work
+        sy = 0;
+        for (;; ++sy) {
+            const int64_t cnt = nsx - sy / 2;
+            if (st < cnt)
+                break;
+            st -= cnt;
+        }
+        sx = sy / 2 + st;
+    } else {
+        sy = st / nsx;
+        sx = st % nsx;
+    }
+    const int64_t ty = sy * 4 + within / 8, tx = sx * 8 + within % 8;
+    if (ty >= nty || tx >= ntx || (SYM && ty > tx))
+        return;
+    const int64_t row0 = ty * BM3, col0 = tx * BN3;
+
+    i32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[a][b][r] = 0;
+
+    // staging: one LDS-DMA instruction lands 16 rows x 64 B linearly (lane l -> row l / 4, 16-byte chunk l % 4);
+    // the XOR swizzle lives on the SOURCE chunk and on the fragment reads (same involution).  A wave stages
+    // rows [32 w, 32 w + 32) of both operands: four instructions per stage, piece p = 0..3 (A q0, B q0, A q1, B q1).
+    const int srow = lane >> 2, schunk = lane & 3;
+    auto stage_piece = [&](int slot, int64_t k0, int p) {
+        int8_t *sa = s_t + slot * SLOT4_BYTES, *sb = sa + BM3 * BK4;
+        const int q = p >> 1;
+        const int r = wid * 32 + q * 16 + srow;
+        const int src_chunk = schunk ^ ((r >> 2) & 3);
+        if ((p & 1) == 0) {
+            const int64_t gi = min(row0 + r, n - 1);  // clamp: masked in the epilogue
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(X + gi * kdim + k0 + src_chunk * 16),
+                                             (__attribute__((address_space(3))) void *)(sa + (wid * 32 + q * 16) * BK4), 16, 0, 0);
+        } else {
+            const int64_t gj = min(col0 + r, m - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Y + gj * kdim + k0 + src_chunk * 16),
+                                             (__attribute__((address_space(3))) void *)(sb + (wid * 32 + q * 16) * BK4), 16, 0, 0);
+        }
+    };
+    auto stage = [&](int slot, int64_t k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            stage_piece(slot, k0, p);
+    };
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int64_t nst = kdim / BK4;  // >= 4 (checked by the launcher)
+    stage(0, 0);
+    stage(1, BK4);
+    stage(2, 2 * BK4);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's part of stage 0
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1)
+        __builtin_amdgcn_s_barrier();  // waves 4-7 run one interval behind
+
+    i32x4 fa[4][2], fb[2][2];
+    for (int64_t s = 0; s < nst; ++s) {
+        // ---- LOAD interval: fragments of stage s into registers
+        const int8_t *sa = s_t + (int)(s & 3) * SLOT4_BYTES, *sb = sa + BM3 * BK4;
+        if (ABL != 2 || s == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int ra = wr * 128 + t * 32 + fr;
+                    fa[t][ks] = *reinterpret_cast<const i32x4 *>(sa + ra * BK4 + (((ks * 2 + fh) ^ ((ra >> 2) & 3)) * 16));
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int rb = wc * 64 + t * 32 + fr;
+                    fb[t][ks] = *reinterpret_cast<const i32x4 *>(sb + rb * BK4 + (((ks * 2 + fh) ^ ((rb >> 2) & 3)) * 16));
+                }
+            }
+        }
+        // this wave's part of stage s+1 has landed (stage s+2 may still fly); the partner group does the same
+        // one interval later, which is still one barrier before anyone reads stage s+1
+        if (s + 2 < nst)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers: the slot may be restaged
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- COMPUTE interval: 16 MFMAs on registers, the four staging instructions of stage s+3 (into the
+        // slot of stage s-1) issued between them: an LDS-DMA instruction costs ~60 cycles among MFMAs and
+        // 100-185 next to fragment reads, and the LOAD interval is the longer one
+        const bool more = ABL != 1 && s + 3 < nst;
+        const int nslot = (int)((s + 3) & 3);
+        const int64_t nk0 = (s + 3) * BK4;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (ABL != 3)
+                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a][ks], fb[b][ks], acc[a][b], 0, 0, 0);
+                    else
+                        asm volatile("" ::"v"(fa[a][ks]), "v"(fb[b][ks]));
+                }
+                if ((a & 1) == 1) {  // after every fourth MFMA
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more)
+                        stage_piece(nslot, nk0, ks * 2 + (a >> 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0)
+        __builtin_amdgcn_s_barrier();  // pairs with the extra barrier of waves 4-7
+
+    const int ccol = lane & 31, chalf = lane >> 5;
+    const bool mirror = SYM && ty < tx;
+    // the mirrored copy of a 32 x 32 sub-tile goes through LDS (free after the K loop; 4.5 KiB per wave) so
+    // that every store instruction writes whole 128-byte lines: storing the accumulator columns directly
+    // scatters 16-byte pieces over 32 rows per instruction and ran at 0.6 TB/s
+    constexpr int TROW = 36;  // floats per transposed row: 16-byte aligned, spreads the banks
+    float *tbuf = reinterpret_cast<float *>(s_t) + wid * (32 * TROW);
+    const bool vec_ok = (ld & 3) == 0 && ((uintptr_t)out & 15) == 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int64_t j = col0 + wc * 64 + b * 32 + ccol;
+            const float rj = j < m ? yr[j] : 0.0f;
+            const int64_t ibase = row0 + wr * 128 + a * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int li = 8 * q + 4 * chalf;  // registers 4q .. 4q+3 hold rows li .. li+3 of the sub-tile
+                float o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = ibase + li + u;
+                    float v = 0.0f;
+                    if (i < n && j < m) {
+                        v = (float)acc[a][b][4 * q + u] * xr[i] * rj;
+                        if (MODE == 1) {
+                            v = fminf(fmaxf(1.0f - v, 0.0f), 2.0f);
+                            if (i == j)
+                                v = 0.0f;
+                        }
+                        out[i * ld + j] = v;
+                    }
+                    o[u] = v;
+                }
+                if (mirror)
+                    *reinterpret_cast<float4 *>(tbuf + ccol * TROW + li) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            if (mirror) {
+                // tbuf[c][i] = value at (row ibase + i, column jbase + c); row jbase + c of the mirror gets columns ibase ..
+                const int64_t jbase = col0 + wc * 64 + b * 32;
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int c = pass * 8 + (lane >> 3), i4 = (lane & 7) * 4;
+                    const float4 v = *reinterpret_cast<const float4 *>(tbuf + c * TROW + i4);
+                    const int64_t jj = jbase + c, ii = ibase + i4;
+                    if (jj < m) {
+                        float *dst = out + jj * ld + ii;
+                        if (vec_ok && ii + 3 < n) {
+                            *reinterpret_cast<float4 *>(dst) = v;
+                        } else {
+                            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (ii + u < n)
+                                    dst[u] = e[u];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------- dense -> CSR
 // Sparse view of a dense count matrix (the inverse of k_count_dense / k_csr_to_dense).  A workgroup of
@@ -569,16 +801,64 @@ extern "C" int skm_cosine_dense_i8(skm_ctx *ctx, int64_t n, int64_t m, int64_t k
     SKM_REQUIRE((((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0, SKM_E_BADARG, "skm_cosine_dense_i8: operands must be 16-byte aligned");
     SKM_HIP(hipSetDevice(ctx->device));
     dim3 grid((unsigned)skm_ceil_div(m, BN), (unsigned)skm_ceil_div(n, BM));
-    const char *v_env = getenv("SKM_DENSE_VARIANT");  // 1: register-staged kernel, 2: 128x128 LDS-DMA kernel
-    const int forced = v_env ? atoi(v_env) : 0;
+    // SKM_DENSE_VARIANT (all variants exact; for A/B timing): 1 register-staged kernel, 2 128x128 LDS-DMA kernel,
+    // 3 the 256x256 lock-step kernel, 4 the staggered kernel (default where it applies), 5 staggered without symmetry
+    const char *v_env = getenv("SKM_DENSE_VARIANT");
+    const int forced0 = v_env ? atoi(v_env) : 0;
+    const int forced = forced0 == 5 ? 4 : forced0;
     const bool v2 = kdim % BK2 == 0 && forced != 1;
     const bool v3 = v2 && forced != 2 && n >= 1024 && m >= 1024;
+    // v4 (staggered wave groups, 64-byte K stages; symmetric form when X is Y): the default for large problems
+    const bool v4 = kdim % BK4 == 0 && kdim >= 4 * BK4 && n >= 1024 && m >= 1024 && (forced == 0 || forced == 4);
+    const bool sym = d_x == d_y && n == m && d_xrnorm == d_yrnorm && forced0 != 5;
     SKM_PROF(ctx, "k_cosine_dense_i8");
-    if (v3) {
+    if (v4) {
+        const int64_t nsy4 = skm_ceil_div(skm_ceil_div(n, BM3), 4), nsx4 = skm_ceil_div(skm_ceil_div(m, BN3), 8);
+        int64_t supertiles = nsy4 * nsx4;
+        if (sym) {  // rows of supertiles shrink towards the bottom: row sy keeps columns sx >= sy / 2 (see the kernel)
+            supertiles = 0;
+            for (int64_t sy = 0; sy < nsy4; ++sy)
+                supertiles += nsx4 - sy / 2 > 0 ? nsx4 - sy / 2 : 0;
+        }
+        SKM_REQUIRE(supertiles * 32 < ((int64_t)1 << 31), SKM_E_OVERFLOW, "skm_cosine_dense_i8: too many tiles");
+        dim3 grid4((unsigned)(supertiles * 32));
+#ifdef SKM_DIAG
+        const char *ab_env = getenv("SKM_DENSE_ABLATE");  // timing-only builds, results NOT valid
+        const int dabl = ab_env ? atoi(ab_env) : 0;
+        if (dabl == 1)
+            k_cosine_dense_i8_v4<0, false, 1><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+        else if (dabl == 2)
+            k_cosine_dense_i8_v4<0, false, 2><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+        else if (dabl == 3)
+            k_cosine_dense_i8_v4<0, false, 3><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+        if (dabl >= 1 && dabl <= 3)
+            return skm_check_launch("k_cosine_dense_i8");
+#endif
+#define SKM_V4(MODE, SYM) \
+    k_cosine_dense_i8_v4<MODE, SYM><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld)
+        if (mode == 0) {
+            if (sym)
+                SKM_V4(0, true);
+            else
+                SKM_V4(0, false);
+        } else {
+            if (sym)
+                SKM_V4(1, true);
+            else
+                SKM_V4(1, false);
+        }
+#undef SKM_V4
+    } else if (v3) {
         // padded to whole 4 x 8 supertiles; workgroups that fall outside the matrix exit at once
         const int64_t nsy3 = skm_ceil_div(skm_ceil_div(n, BM3), 4), nsx3 = skm_ceil_div(skm_ceil_div(m, BN3), 8);
         SKM_REQUIRE(nsy3 * nsx3 * 32 < ((int64_t)1 << 31), SKM_E_OVERFLOW, "skm_cosine_dense_i8: too many tiles");
         dim3 grid3((unsigned)(nsy3 * nsx3 * 32));
+#ifdef SKM_DIAG
+        if (getenv("SKM_DENSE_ABLATE") && atoi(getenv("SKM_DENSE_ABLATE")) == 3) {
+            k_cosine_dense_i8_v3<0, 3><<<grid3, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+            return skm_check_launch("k_cosine_dense_i8");
+        }
+#endif
         if (mode == 0)
             k_cosine_dense_i8_v3<0><<<grid3, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
         else

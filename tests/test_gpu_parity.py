@@ -382,7 +382,10 @@ def test_cosine_dense_i8_mfma_exact_gram_and_scaling(ctx):
         _check_dense_gram(ctx, rng, 200, 333, kdim)
     _check_dense_gram(ctx, rng, 129, 1, 128)
     _check_dense_gram(ctx, rng, 5, 300, 1024)
-    _check_dense_gram(ctx, rng, 1100, 1029, 256)  # 256 x 256 tile kernel incl. ragged edges
+    _check_dense_gram(ctx, rng, 1100, 1029, 256)  # 256 x 256 tile kernels incl. ragged edges
+    _check_dense_gram(ctx, rng, 1300, 2100, 448)   # K a multiple of 64 only: the staggered kernel's own K step
+    _check_dense_symmetric(ctx, rng, 1500, 320)    # X is Y: upper tiles + mirrored stores, ragged, odd ld
+    _check_dense_symmetric(ctx, rng, 2304, 256)    # whole tiles
 
 
 def _check_dense_gram(ctx, rng, n, m, kdim):
@@ -398,6 +401,35 @@ def _check_dense_gram(ctx, rng, n, m, kdim):
     G = out.download().reshape(out.shape)[:n, :m]
     ref = Xs.astype(np.int64) @ Ys.astype(np.int64).T
     assert (G.astype(np.int64) == ref).all()
+
+
+def _check_dense_symmetric(ctx, rng, n, kdim):
+    """X is Y (same device buffer and norms): only tiles on or above the diagonal are computed and the rest
+    is mirrored; the result must equal the full product (exactly, with unit norms), in both modes."""
+    from snekmer_amd import engine
+
+    X = (rng.integers(-128, 128, size=(n, kdim)) // 16).astype(np.int8)
+    X[n // 3] = 0
+    dX = ctx.to_device(X)
+    G = X.astype(np.int64) @ X.astype(np.int64).T
+    nsq = np.diag(G).astype(np.float64)
+    rn = np.where(nsq > 0, 1.0 / np.sqrt(np.where(nsq > 0, nsq, 1.0)), 1.0).astype(np.float32)
+    d_rn = ctx.to_device(np.concatenate([rn, np.zeros(4, np.float32)]))
+    for ld in ((n + 3) // 4 * 4, n + 1):  # vector and scalar mirror stores
+        for mode in (0, 1):
+            out = engine.cosine_dense_i8(ctx, n, n, kdim, dX, dX, d_rn, d_rn, mode=mode, ld=ld)
+            S = out.download().reshape(-1, ld)[:n, :n]
+            ref = G * rn.astype(np.float64)[:, None] * rn.astype(np.float64)[None, :]
+            if mode == 1:
+                ref = np.clip(1.0 - ref, 0, 2)
+                np.fill_diagonal(ref, 0.0)
+            # mirrored tiles are bit-symmetric; inside diagonal tiles (i,j) and (j,i) multiply the two norms
+            # in opposite orders: one float32 rounding apart
+            assert np.abs(S - S.T).max() <= 1.2e-7
+            assert np.abs(S - ref).max() <= 2e-6
+    ones = ctx.to_device(np.ones(n + 4, dtype=np.float32))
+    out = engine.cosine_dense_i8(ctx, n, n, kdim, dX, dX, ones, ones)
+    assert (out.download().reshape(out.shape)[:n, :n].astype(np.int64) == G).all()
 
 
 @pytest.mark.parametrize("name,k", [("hydro", 12), ("solvacc", 7), ("hydro", 14)])

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""A/B of the dense i8 MFMA cosine variants (SKM_DENSE_VARIANT) in one process, interleaved rounds.
+usage: ab_dense.py [alphabet k n]   also checks every variant against variant 3 bit for bit"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from snekmer_amd import _hip, alphabet, engine
+from snekmer_amd.synth import BASE_SEED, synth_families
+
+name = sys.argv[1] if len(sys.argv) > 1 else "hydro"
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 14
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 32768
+lut = alphabet.build_lut(name)
+res, off, _ = synth_families(n, 300, family=100, seed=BASE_SEED + 6)
+variants = {"3 lock-step": "3", "5 staggered, full": "5", "4 staggered, symmetric": "4"}
+ABL = {}
+if os.environ.get("SKM_AB_DIAG") == "1":  # needs libsnekmer_hip_diag.so (make diag); ablated runs give invalid results
+    _hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "libsnekmer_hip_diag.so")
+    variants.update({"5 ablate: no staging in loop": "5", "5 ablate: fragments read once": "5", "5 ablate: no MFMA": "5",
+                     "3 ablate: no MFMA": "3"})
+    ABL = {"5 ablate: no staging in loop": "1", "5 ablate: fragments read once": "2", "5 ablate: no MFMA": "3",
+           "3 ablate: no MFMA": "3"}
+ctx = _hip.Context(0)
+batch = engine.SeqBatch(ctx, res, off)
+pipe = engine.DensePipeline(ctx, lut, k)
+pipe.step(batch)
+kdim = pipe.kdim
+ref = None
+rows = {v: [] for v in variants}
+ctx.profile_enable(True)
+for rnd in range(5):
+    for vname, env in variants.items():
+        os.environ["SKM_DENSE_VARIANT"] = env
+        os.environ.pop("SKM_DENSE_ABLATE", None)
+        if vname in ABL:
+            os.environ["SKM_DENSE_ABLATE"] = ABL[vname]
+        ctx.profile_reset()
+        out = engine.cosine_dense_i8(ctx, n, n, kdim, pipe.dense, pipe.dense, pipe.rnorm, pipe.rnorm, out=pipe.out)
+        ms = ctx.profile_read("k_cosine_dense_i8")[1]
+        rows[vname].append(ms)
+        if rnd == 0 and vname not in ABL:
+            ld = out.shape[1]
+            sample = np.stack([out.download(n, offset=int(r) * ld) for r in (0, 1, 255, 256, 257, n // 2, n - 257, n - 1)])
+            if ref is None:
+                ref = sample
+            elif vname.startswith("4"):
+                # the mirrored half is (acc * r_i) * r_j instead of (acc * r_j) * r_i: one float32 rounding apart
+                d = float(np.abs(sample - ref).max())
+                assert d <= 2.5e-7, f"symmetric variant differs by {d}"
+                print(f"symmetric vs full: max |diff| {d:.2e} (rounding order of the two norms)")
+            else:
+                assert (sample == ref).all(), f"variant {vname} differs from variant 3"
+os.environ.pop("SKM_DENSE_VARIANT")
+for vname, v in rows.items():
+    ms = sorted(v)[len(v) // 2]
+    full = 2.0 * n * n * kdim
+    print(f"{vname:26s} {ms:8.3f} ms   {full / ms / 1e12:6.3f} POPS by 2NMK   (min {min(v):.3f} ms)")
