@@ -329,6 +329,29 @@ int skm_allgatherv(skm_ctx *ctx, const void *d_send, const int64_t *h_bytes, voi
 int skm_alltoallv(skm_ctx *ctx, const void *d_send, const int64_t *h_send_bytes, void *d_recv,
                   const int64_t *h_recv_bytes);
 
+/* Several parallel arrays in ONE exchange (one RCCL group = one launch; every pair of ranks uses its own
+ * xGMI link; every piece lands at its final offset).  The byte ranges are computed by two pure host
+ * functions that tests can execute without RCCL: out_ops[p * narrays + a] describes what this rank
+ * exchanges with peer p for array a (offsets into the rank's own send / receive buffer of that array). */
+#define SKM_MAX_ARRAYS 8
+typedef struct skm_p2p_op {
+    int32_t peer, array;
+    int64_t send_off, send_bytes; /* range of d_send[array] that goes to `peer` */
+    int64_t recv_off, recv_bytes; /* range of d_recv[array] that `peer`'s data lands in */
+} skm_p2p_op;
+/* All-to-all: h_send_counts[p] / h_recv_counts[p] elements (the same counts for every array, element size
+ * h_elem_bytes[a]) go to / come from rank p; segments are back to back in rank order in every buffer. */
+int skm_plan_alltoallv(int nranks, int narrays, const int64_t *h_elem_bytes, const int64_t *h_send_counts,
+                       const int64_t *h_recv_counts, skm_p2p_op *out_ops);
+int skm_alltoallv_multi(skm_ctx *ctx, int narrays, const void *const *d_send, void *const *d_recv,
+                        const int64_t *h_elem_bytes, const int64_t *h_send_counts, const int64_t *h_recv_counts);
+/* All-gather: rank r contributes h_counts[a * nranks + r] elements of array a (its whole d_send[a]); every
+ * rank receives all contributions back to back in rank order in d_recv[a]. */
+int skm_plan_allgatherv(int nranks, int rank, int narrays, const int64_t *h_elem_bytes, const int64_t *h_counts,
+                        skm_p2p_op *out_ops);
+int skm_allgatherv_multi(skm_ctx *ctx, int narrays, const void *const *d_send, void *const *d_recv,
+                         const int64_t *h_elem_bytes, const int64_t *h_counts);
+
 /* ---- multi-GPU basis: postings of a row-sharded count matrix, built in parallel ------------- *
  * Sharded form of skm_basis_build for the cosine pipeline (singletons elided); there is no
  * reference counterpart (one process per FASTA file, snekmer/rules/kmerize.smk:57-65).  A code's

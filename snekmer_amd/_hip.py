@@ -20,6 +20,13 @@ ERRORS = {-1: "BADARG", -2: "NOMEM", -3: "HIP", -4: "OVERFLOW", -5: "UNSUPPORTED
 COMM_ID_BYTES = 128
 
 
+class P2POp(C.Structure):
+    """skm_p2p_op of include/snekmer_hip.h."""
+
+    _fields_ = [("peer", C.c_int32), ("array", C.c_int32), ("send_off", C.c_int64), ("send_bytes", C.c_int64),
+                ("recv_off", C.c_int64), ("recv_bytes", C.c_int64)]
+
+
 class HipUnavailable(RuntimeError):
     """The HIP extension (or a GPU) is not available; there is no CPU fallback."""
 
@@ -95,6 +102,10 @@ _SIGNATURES = {
     "skm_comm_destroy": (C.c_int, [_p]),
     "skm_allgatherv": (C.c_int, [_p, _p, _p, _p]),
     "skm_alltoallv": (C.c_int, [_p, _p, _p, _p, _p]),
+    "skm_plan_alltoallv": (C.c_int, [C.c_int, C.c_int, _p, _p, _p, _p]),
+    "skm_alltoallv_multi": (C.c_int, [_p, C.c_int, _p, _p, _p, _p, _p]),
+    "skm_plan_allgatherv": (C.c_int, [C.c_int, C.c_int, C.c_int, _p, _p, _p]),
+    "skm_allgatherv_multi": (C.c_int, [_p, C.c_int, _p, _p, _p, _p]),
     "skm_bucket_partition": (C.c_int, [_p, C.c_int, C.c_int, _i64, _i64, _p, _p, _p, _i64, _p, _p, _p]),
     "skm_bucket_table_capacity": (_i64, [_i64]),
     "skm_bucket_postings": (C.c_int, [_p, C.c_int, C.c_int, _i64, _p, _p, _p, _p, _p, _p, _p]),

@@ -239,3 +239,123 @@ extern "C" int skm_alltoallv(skm_ctx *ctx, const void *d_send, const int64_t *h_
     SKM_NCCL(end_status);
     return SKM_OK;
 }
+
+// ------------------------------------------------------------------------------- several arrays, one group
+// The distributed basis moves struct-of-arrays data (codes + posting words; postings + column starts +
+// table keys + table values + row norms).  One RCCL group holds the point-to-point transfers of ALL the
+// arrays to ALL peers: RCCL fuses a group into one launch, every pair uses its own xGMI link, and each
+// piece lands at its final offset (no padded scratch, no unpack pass).  The byte ranges come from two
+// pure host functions, exported so that tests can execute the same plan without RCCL.
+
+extern "C" int skm_plan_alltoallv(int nranks, int narrays, const int64_t *h_elem_bytes, const int64_t *h_send_counts,
+                                  const int64_t *h_recv_counts, skm_p2p_op *out_ops)
+{
+    SKM_REQUIRE(nranks >= 1 && nranks <= SKM_MAX_RANKS && narrays >= 1 && narrays <= SKM_MAX_ARRAYS && h_elem_bytes &&
+                    h_send_counts && h_recv_counts && out_ops,
+                SKM_E_BADARG, "skm_plan_alltoallv: bad argument");
+    for (int a = 0; a < narrays; ++a) {
+        SKM_REQUIRE(h_elem_bytes[a] > 0, SKM_E_BADARG, "skm_plan_alltoallv: element size of array %d", a);
+        int64_t soff = 0, roff = 0;
+        for (int p = 0; p < nranks; ++p) {
+            SKM_REQUIRE(h_send_counts[p] >= 0 && h_recv_counts[p] >= 0, SKM_E_BADARG, "skm_plan_alltoallv: negative count for rank %d", p);
+            skm_p2p_op &op = out_ops[p * narrays + a];
+            op.peer = p;
+            op.array = a;
+            op.send_off = soff;
+            op.send_bytes = h_send_counts[p] * h_elem_bytes[a];
+            op.recv_off = roff;
+            op.recv_bytes = h_recv_counts[p] * h_elem_bytes[a];
+            soff += op.send_bytes;
+            roff += op.recv_bytes;
+        }
+    }
+    return SKM_OK;
+}
+
+extern "C" int skm_plan_allgatherv(int nranks, int rank, int narrays, const int64_t *h_elem_bytes, const int64_t *h_counts,
+                                   skm_p2p_op *out_ops)
+{
+    SKM_REQUIRE(nranks >= 1 && nranks <= SKM_MAX_RANKS && rank >= 0 && rank < nranks && narrays >= 1 &&
+                    narrays <= SKM_MAX_ARRAYS && h_elem_bytes && h_counts && out_ops,
+                SKM_E_BADARG, "skm_plan_allgatherv: bad argument");
+    for (int a = 0; a < narrays; ++a) {
+        SKM_REQUIRE(h_elem_bytes[a] > 0, SKM_E_BADARG, "skm_plan_allgatherv: element size of array %d", a);
+        int64_t roff = 0;
+        for (int p = 0; p < nranks; ++p) {
+            const int64_t cnt = h_counts[a * nranks + p];
+            SKM_REQUIRE(cnt >= 0, SKM_E_BADARG, "skm_plan_allgatherv: negative count (array %d, rank %d)", a, p);
+            skm_p2p_op &op = out_ops[p * narrays + a];
+            op.peer = p;
+            op.array = a;
+            op.send_off = 0;  // every peer gets this rank's whole contribution
+            op.send_bytes = h_counts[a * nranks + rank] * h_elem_bytes[a];
+            op.recv_off = roff;
+            op.recv_bytes = cnt * h_elem_bytes[a];
+            roff += op.recv_bytes;
+        }
+    }
+    return SKM_OK;
+}
+
+namespace {
+// Executes a plan: the self pieces are device copies, the rest one RCCL group.
+int run_p2p_plan(skm_ctx *ctx, const char *what, int narrays, const void *const *d_send, void *const *d_recv,
+                 const skm_p2p_op *ops)
+{
+    const int nr = ctx->comm ? ctx->nranks : 1, me = ctx->comm ? ctx->rank : 0;
+    SKM_REQUIRE(ctx->comm || ctx->nranks == 1, SKM_E_COMM, "%s: communicator not initialised", what);
+    for (int a = 0; a < narrays; ++a) {
+        const skm_p2p_op &op = ops[me * narrays + a];
+        SKM_REQUIRE(op.send_bytes == op.recv_bytes, SKM_E_BADARG, "%s: self segment sizes differ (array %d)", what, a);
+        if (op.send_bytes > 0) {
+            SKM_REQUIRE(d_send[a] && d_recv[a], SKM_E_BADARG, "%s: null buffer (array %d)", what, a);
+            if ((const uint8_t *)d_send[a] + op.send_off != (uint8_t *)d_recv[a] + op.recv_off)
+                SKM_HIP(hipMemcpyAsync((uint8_t *)d_recv[a] + op.recv_off, (const uint8_t *)d_send[a] + op.send_off,
+                                       (size_t)op.send_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    }
+    if (nr == 1)
+        return SKM_OK;
+    SKM_NCCL(g_rccl.group_start());
+    int status = 0;
+    for (int p = 0; p < nr && status == 0; ++p) {
+        if (p == me)
+            continue;
+        for (int a = 0; a < narrays && status == 0; ++a) {
+            const skm_p2p_op &op = ops[p * narrays + a];
+            if (op.send_bytes > 0)
+                status = g_rccl.send((const uint8_t *)d_send[a] + op.send_off, (size_t)op.send_bytes, NCCL_INT8, p, ctx->comm,
+                                     ctx->stream);
+            if (status == 0 && op.recv_bytes > 0)
+                status = g_rccl.recv((uint8_t *)d_recv[a] + op.recv_off, (size_t)op.recv_bytes, NCCL_INT8, p, ctx->comm,
+                                     ctx->stream);
+        }
+    }
+    const int end_status = g_rccl.group_end();  // always close the group, also after a failed call
+    SKM_NCCL(status);
+    SKM_NCCL(end_status);
+    return SKM_OK;
+}
+}  // namespace
+
+extern "C" int skm_alltoallv_multi(skm_ctx *ctx, int narrays, const void *const *d_send, void *const *d_recv,
+                                   const int64_t *h_elem_bytes, const int64_t *h_send_counts, const int64_t *h_recv_counts)
+{
+    SKM_REQUIRE(ctx && d_send && d_recv, SKM_E_BADARG, "skm_alltoallv_multi: bad argument");
+    SKM_HIP(hipSetDevice(ctx->device));
+    skm_p2p_op ops[SKM_MAX_RANKS * SKM_MAX_ARRAYS];
+    SKM_TRY(skm_plan_alltoallv(ctx->comm ? ctx->nranks : 1, narrays, h_elem_bytes, h_send_counts, h_recv_counts, ops));
+    SKM_PROF(ctx, "rccl_alltoallv");
+    return run_p2p_plan(ctx, "skm_alltoallv_multi", narrays, d_send, d_recv, ops);
+}
+
+extern "C" int skm_allgatherv_multi(skm_ctx *ctx, int narrays, const void *const *d_send, void *const *d_recv,
+                                    const int64_t *h_elem_bytes, const int64_t *h_counts)
+{
+    SKM_REQUIRE(ctx && d_send && d_recv, SKM_E_BADARG, "skm_allgatherv_multi: bad argument");
+    SKM_HIP(hipSetDevice(ctx->device));
+    skm_p2p_op ops[SKM_MAX_RANKS * SKM_MAX_ARRAYS];
+    SKM_TRY(skm_plan_allgatherv(ctx->comm ? ctx->nranks : 1, ctx->comm ? ctx->rank : 0, narrays, h_elem_bytes, h_counts, ops));
+    SKM_PROF(ctx, "rccl_allgatherv");
+    return run_p2p_plan(ctx, "skm_allgatherv_multi", narrays, d_send, d_recv, ops);
+}

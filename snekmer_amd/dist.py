@@ -11,9 +11,11 @@ Two forms of the exchange (`ShardedPipeline(basis=...)`):
 
 * ``"distributed"`` (default): the postings are built in parallel.  Every rank groups its entries
   by OWNER rank (a fixed hash of the k-mer code), one all-to-all moves them, each owner sorts its
-  share (1/G of the entries) and builds the postings of its k-mers, and all-gathers of the
-  postings and of the owners' column tables give every rank the full column-major copy; a rank
-  then finds the columns of its own rows by binary search.  No rank ever sorts the whole matrix.
+  share (1/G of the entries) and builds the postings of its k-mers, and one all-gather of the
+  postings, the owners' column tables and the row norms gives every rank the full column-major
+  copy; a rank then finds the columns of its own rows with one probe of the owner's hash table.
+  No rank ever sorts the whole matrix.  Four collectives per step: two small size exchanges, one
+  grouped all-to-all (codes + posting words), one grouped all-gather (five arrays).
 * ``"replicated"``: all-gather of the raw CSR shards, then every rank builds the basis of the full
   matrix itself (simple; the replicated sort is the Amdahl term of strong scaling).
 
@@ -68,6 +70,36 @@ def plan_alltoall(counts: np.ndarray, rank: int, itemsize: int):
     (send_bytes[dst], recv_bytes[src]) for `rank`."""
     counts = np.asarray(counts, dtype=np.int64)
     return counts[rank, :] * itemsize, counts[:, rank] * itemsize
+
+
+def plan_alltoallv_host(elem_bytes: Sequence[int], send_counts: Sequence[int], recv_counts: Sequence[int]):
+    """Host statement of skm_plan_alltoallv: ops[p][a] = (send_off, send_bytes, recv_off, recv_bytes) of what this
+    rank exchanges with peer p for array a; segments back to back in rank order in every buffer."""
+    world = len(send_counts)
+    ops = [[None] * len(elem_bytes) for _ in range(world)]
+    for a, eb in enumerate(elem_bytes):
+        so = ro = 0
+        for p in range(world):
+            sb, rb = int(send_counts[p]) * int(eb), int(recv_counts[p]) * int(eb)
+            ops[p][a] = (so, sb, ro, rb)
+            so += sb
+            ro += rb
+    return ops
+
+
+def plan_allgatherv_host(rank: int, elem_bytes: Sequence[int], counts):
+    """Host statement of skm_plan_allgatherv: counts[a][r] elements of array a come from rank r; every peer gets
+    this rank's whole contribution (send_off 0)."""
+    counts = np.asarray(counts, dtype=np.int64)
+    world = counts.shape[1]
+    ops = [[None] * len(elem_bytes) for _ in range(world)]
+    for a, eb in enumerate(elem_bytes):
+        ro = 0
+        for p in range(world):
+            rb = int(counts[a, p]) * int(eb)
+            ops[p][a] = (0, int(counts[a, rank]) * int(eb), ro, rb)
+            ro += rb
+    return ops
 
 
 def owner_host(codes: np.ndarray, world: int) -> np.ndarray:
@@ -148,6 +180,27 @@ class RcclExchange:
         sb = np.ascontiguousarray(send_bytes, dtype=np.int64)
         rb = np.ascontiguousarray(recv_bytes, dtype=np.int64)
         self.ctx.call("skm_alltoallv", _p(d_send.ptr), sb.ctypes.data_as(_p), _p(d_recv.ptr), rb.ctypes.data_as(_p))
+
+    @staticmethod
+    def _ptr_array(arrays):
+        return (C.c_void_p * len(arrays))(*[a.ptr for a in arrays])
+
+    def alltoallv_multi(self, sends, recvs, elem_bytes: Sequence[int], send_counts: Sequence[int], recv_counts: Sequence[int]):
+        """Several parallel arrays in one grouped all-to-all (skm_alltoallv_multi): send_counts[p] elements of
+        every array go to rank p, recv_counts[p] arrive from it."""
+        eb = np.ascontiguousarray(elem_bytes, dtype=np.int64)
+        sc = np.ascontiguousarray(send_counts, dtype=np.int64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        self.ctx.call("skm_alltoallv_multi", len(sends), self._ptr_array(sends), self._ptr_array(recvs), eb.ctypes.data_as(_p),
+                      sc.ctypes.data_as(_p), rc.ctypes.data_as(_p))
+
+    def allgatherv_multi(self, sends, recvs, elem_bytes: Sequence[int], counts):
+        """Several arrays in one grouped all-gather (skm_allgatherv_multi): counts[a][r] elements of array a come
+        from rank r; every contribution lands at its final offset of recvs[a]."""
+        eb = np.ascontiguousarray(elem_bytes, dtype=np.int64)
+        cn = np.ascontiguousarray(counts, dtype=np.int64)
+        self.ctx.call("skm_allgatherv_multi", len(sends), self._ptr_array(sends), self._ptr_array(recvs), eb.ctypes.data_as(_p),
+                      cn.ctypes.data_as(_p))
 
 
 class _ColumnMajor:
@@ -232,16 +285,17 @@ class ShardedPipeline:
         counts = np.zeros(G, dtype=np.int64)
         ctx.call("skm_bucket_partition", self.code_bits, G, _i64(loc.n), _i64(loc.nnz), _p(loc.rowptr.ptr),
                  _p(loc.codes.ptr), _p(loc.counts.ptr), _i64(lo), _p(p_codes.ptr), _p(p_rc.ptr), counts.ctypes.data_as(_p))
-        cmat = ex.allgather_i64(counts)  # [src, dst]
+        # norms of the local rows: independent of the exchange, queued before the first host round trip
+        rn = self._need("rn_local", nloc + 4, np.float32)
+        e.row_norms(ctx, nloc, loc.rowptr, loc.counts, out=rn)
+        cmat = ex.allgather_i64(counts)  # collective 1: [src, dst] entry counts
         self.nnz_total = int(cmat.sum())
         nrecv = int(cmat[:, me].sum())
-        # 2. all-to-all: every owner receives its k-mers' entries from all ranks, sources in rank order
+        # 2. one grouped all-to-all (codes + posting words): every owner receives its k-mers' entries from all
+        # ranks, sources in rank order
         r_codes = self._need("r_codes", nrecv, self.code_dtype)
         r_rc = self._need("r_rc", nrecv, np.uint64)
-        sb, rb = plan_alltoall(cmat, me, cb)
-        ex.alltoallv(p_codes, sb, r_codes, rb)
-        sb, rb = plan_alltoall(cmat, me, 8)
-        ex.alltoallv(p_rc, sb, r_rc, rb)
+        ex.alltoallv_multi([p_codes, p_rc], [r_codes, r_rc], [cb, 8], cmat[me, :], cmat[:, me])  # collective 2
         # 3. owner: sort its share by code, compact postings, column starts, hash table code -> column
         o_start = self._need("o_start", nrecv, np.uint32)
         o_post = self._need("o_post", nrecv, np.uint64)
@@ -251,10 +305,10 @@ class ShardedPipeline:
         out4 = np.zeros(4, dtype=np.int64)
         ctx.call("skm_bucket_postings", self.code_bits, e.key_bits(self.lut.nsym, self.k), _i64(nrecv), _p(r_codes.ptr),
                  _p(r_rc.ptr), out4.ctypes.data_as(_p), _p(o_start.ptr), _p(o_post.ptr), _p(o_tkeys.ptr), _p(o_tvals.ptr))
-        meta = ex.allgather_i64(out4)  # [rank, (distinct, shared columns, postings, table slots)]
+        meta = ex.allgather_i64(out4)  # collective 3: [rank, (distinct, shared columns, postings, table slots)]
         ncols, npost, tsize = meta[:, 1].copy(), meta[:, 2].copy(), meta[:, 3].copy()
         tot_cols, tot_post, tot_slots = int(ncols.sum()), int(npost.sum()), int(tsize.sum())
-        # 4. every rank gets all postings, column starts and tables
+        # 4. one grouped all-gather: every rank gets all postings, column starts, tables and row norms
         b = self.basis or _ColumnMajor()
         b.ncols, b.ncols_shared = int(meta[:, 0].sum()), tot_cols
         b.post = self._need("post", tot_post, np.uint64)
@@ -262,10 +316,8 @@ class ShardedPipeline:
         a_start = self._need("a_start", tot_cols, np.uint32)
         a_tkeys = self._need("a_tkeys", tot_slots, self.code_dtype)
         a_tvals = self._need("a_tvals", tot_slots, np.uint32)
-        ex.allgatherv(o_post, npost * 8, b.post)
-        ex.allgatherv(o_start, ncols * 4, a_start)
-        ex.allgatherv(o_tkeys, tsize * cb, a_tkeys)
-        ex.allgatherv(o_tvals, tsize * 4, a_tvals)
+        ex.allgatherv_multi([o_post, o_start, o_tkeys, o_tvals, rn], [b.post, a_start, a_tkeys, a_tvals, self.rnorm],
+                            [8, 4, cb, 4, 4], [npost, ncols, tsize, tsize, np.asarray(self.rows, dtype=np.int64)])  # collective 4
         ctx.call("skm_concat_colptr", G, ncols.ctypes.data_as(_p), npost.ctypes.data_as(_p), _p(a_start.ptr),
                  _p(b.colptr.ptr))
         self.basis = b
@@ -274,10 +326,6 @@ class ShardedPipeline:
         ctx.call("skm_colidx_lookup", self.code_bits, G, _i64(loc.nnz), _p(loc.codes.ptr), tsize.ctypes.data_as(_p),
                  ncols.ctypes.data_as(_p), _p(a_tkeys.ptr), _p(a_tvals.ptr), _p(colidx.ptr))
         ctx.call("skm_embed_rowptr", _i64(self.n_total), _i64(lo), _i64(nloc), _p(loc.rowptr.ptr), _p(self.rowptr_g.ptr))
-        # 6. norms of all rows
-        rn = self._need("rn_local", nloc + 4, np.float32)
-        e.row_norms(ctx, nloc, loc.rowptr, loc.counts, out=rn)
-        ex.allgatherv(rn, np.asarray(self.rows, dtype=np.int64) * 4, self.rnorm)
         x = e.CountsCSR(ctx, self.n_total, loc.nnz, self.code_bits, self.rowptr_g, loc.codes, loc.counts, None)
         x.colidx = colidx
         self.x = x
@@ -334,7 +382,11 @@ class ShardedPipeline:
             cap_entries = 16 * max(self.nnz_total // max(self.world, 1), 1) + (1 << 20)
         nb = e.gram_neighbors(ctx, self.x, self.n_total, getattr(b, "ncols_shared", b.ncols), b.colptr, b.post,
                               row0=lo, row1=hi, cap_entries=cap_entries)
-        if nb.overflow_rows:
-            raise OverflowError(f"{nb.overflow_rows} rows exceed the neighbour-list capacity; raise cap_entries")
+        # overflow is a COLLECTIVE decision: a rank that raised alone would leave its peers waiting in the next
+        # collective, so every rank learns every rank's count and all of them raise together
+        over = self.ex.allgather_i64([nb.overflow_rows])[:, 0]
+        if int(over.sum()):
+            raise OverflowError(
+                f"{int(over.sum())} rows (per rank: {over.tolist()}) exceed the neighbour-list capacity; raise cap_entries")
         idx, val = e.neighbors_topk(ctx, nb, self.rnorm, self.rnorm, k, exclude_self=exclude_self)
         return idx, val, nb

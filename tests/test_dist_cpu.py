@@ -248,3 +248,59 @@ def test_shard_bounds_cover_and_balance():
     assert plan_allgather([10, 0, 5], [3, 2, 4], 4, 1)["counts"] == [10, 0, 5]
     rp = concat_rowptr_host([np.array([0, 2, 5]), np.array([0]), np.array([0, 1, 1, 4])])
     assert rp.tolist() == [0, 2, 5, 6, 6, 9]
+
+
+def test_c_plans_of_the_grouped_collectives_match_the_host_statements():
+    """skm_plan_alltoallv / skm_plan_allgatherv (pure host functions of the C library: the byte ranges RCCL is
+    handed) against dist.plan_*_host for world sizes 1..8, random segment tables, several arrays; and the
+    pairing property RCCL relies on: what rank a sends to b is exactly what b expects from a."""
+    import ctypes as C
+
+    from snekmer_amd import _hip, dist as D
+
+    lib = _hip.load_library()
+    rng = np.random.default_rng(8)
+    for world in range(1, 9):
+        for trial in range(6):
+            na = int(rng.integers(1, 6))
+            eb = rng.choice([1, 2, 4, 8], size=na).astype(np.int64)
+            cmat = rng.integers(0, 50, size=(world, world)).astype(np.int64)  # [src, dst] element counts
+            if trial == 0:
+                cmat[:] = 0
+            plans = []
+            for me in range(world):
+                ops = (_hip.P2POp * (world * na))()
+                sc, rc = np.ascontiguousarray(cmat[me, :]), np.ascontiguousarray(cmat[:, me])
+                assert lib.skm_plan_alltoallv(world, na, eb.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
+                                              rc.ctypes.data_as(C.c_void_p), ops) == 0
+                ref = D.plan_alltoallv_host(eb, sc, rc)
+                for p in range(world):
+                    for a in range(na):
+                        o = ops[p * na + a]
+                        assert (o.peer, o.array) == (p, a)
+                        assert (o.send_off, o.send_bytes, o.recv_off, o.recv_bytes) == ref[p][a]
+                # single-array form agrees with the byte plan the first round used
+                sb, rb = D.plan_alltoall(cmat, me, int(eb[0]))
+                assert [ops[p * na].send_bytes for p in range(world)] == sb.tolist()
+                assert [ops[p * na].recv_bytes for p in range(world)] == rb.tolist()
+                plans.append(ops)
+            for a_ in range(world):
+                for b_ in range(world):
+                    for a in range(na):
+                        assert plans[a_][b_ * na + a].send_bytes == plans[b_][a_ * na + a].recv_bytes
+            # all-gather
+            counts = rng.integers(0, 40, size=(na, world)).astype(np.int64)
+            for me in range(world):
+                ops = (_hip.P2POp * (world * na))()
+                assert lib.skm_plan_allgatherv(world, me, na, eb.ctypes.data_as(C.c_void_p),
+                                               np.ascontiguousarray(counts).ctypes.data_as(C.c_void_p), ops) == 0
+                ref = D.plan_allgatherv_host(me, eb, counts)
+                for p in range(world):
+                    for a in range(na):
+                        o = ops[p * na + a]
+                        assert (o.send_off, o.send_bytes, o.recv_off, o.recv_bytes) == ref[p][a]
+                        assert o.recv_bytes == counts[a, p] * eb[a]
+    bad = (_hip.P2POp * 4)()
+    z = np.zeros(2, np.int64)
+    assert lib.skm_plan_alltoallv(2, 1, np.asarray([0], np.int64).ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p),
+                                  z.ctypes.data_as(C.c_void_p), bad) == -1

@@ -597,6 +597,63 @@ class _HostStagedExchange:
         if packed.size:
             self.ctx._h2d(d_recv.ptr, np.ascontiguousarray(packed))
 
+    # ---- the grouped multi-array forms: executed from the C library's own plan (skm_plan_*), so that the byte
+    # offsets RCCL would be handed are the ones exercised here; only the transport (gloo, through the host) differs
+    def _run_plan(self, ops, sends, recvs):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        na = len(sends)
+        reqs, landing = [], []
+        for p in range(self.world):
+            for a in range(na):
+                op = ops[p * na + a]
+                if p == self.rank:
+                    assert op.send_bytes == op.recv_bytes
+                    if op.send_bytes:
+                        self.ctx.call("skm_memcpy_d2d", C.c_void_p(recvs[a].ptr + op.recv_off), C.c_void_p(sends[a].ptr + op.send_off),
+                                      C.c_size_t(op.send_bytes))
+                    continue
+                if op.send_bytes:
+                    buf = np.zeros(op.send_bytes, dtype=np.uint8)
+                    self.ctx._d2h(buf, sends[a].ptr + op.send_off)
+                    reqs.append(dist.isend(torch.from_numpy(buf), dst=p, tag=a))
+                if op.recv_bytes:
+                    t = torch.zeros(op.recv_bytes, dtype=torch.uint8)
+                    reqs.append(dist.irecv(t, src=p, tag=a))
+                    landing.append((a, op.recv_off, t))
+        for r in reqs:
+            r.wait()
+        for a, off, t in landing:
+            self.ctx._h2d(recvs[a].ptr + off, np.ascontiguousarray(t.numpy()))
+        self.ctx.sync()
+
+    def alltoallv_multi(self, sends, recvs, elem_bytes, send_counts, recv_counts):
+        import ctypes as C
+
+        from snekmer_amd import _hip
+
+        na = len(sends)
+        ops = (_hip.P2POp * (self.world * na))()
+        eb, sc, rc = (np.ascontiguousarray(x, dtype=np.int64) for x in (elem_bytes, send_counts, recv_counts))
+        _hip._check(self.ctx.lib, self.ctx.lib.skm_plan_alltoallv(self.world, na, eb.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
+                                                                 rc.ctypes.data_as(C.c_void_p), ops))
+        self._run_plan(ops, sends, recvs)
+
+    def allgatherv_multi(self, sends, recvs, elem_bytes, counts):
+        import ctypes as C
+
+        from snekmer_amd import _hip
+
+        na = len(sends)
+        ops = (_hip.P2POp * (self.world * na))()
+        eb, cn = np.ascontiguousarray(elem_bytes, dtype=np.int64), np.ascontiguousarray(counts, dtype=np.int64)
+        _hip._check(self.ctx.lib, self.ctx.lib.skm_plan_allgatherv(self.world, self.rank, na, eb.ctypes.data_as(C.c_void_p),
+                                                                  cn.ctypes.data_as(C.c_void_p), ops))
+        self._run_plan(ops, sends, recvs)
+
     def _p2p_all_to_all(self, outs, ins):
         """gloo has no all_to_all: the segments travel point to point (their sizes are known on
         both sides, as in skm_alltoallv)."""
