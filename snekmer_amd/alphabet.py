@@ -214,14 +214,30 @@ class AlphabetLUT:
         codes = np.asarray(codes, dtype=np.uint64)
         if codes.size == 0:
             return np.array([], dtype=str)
-        letters = np.frombuffer(self.letters.encode("latin-1"), dtype=np.uint8)
-        out = np.empty((codes.size, k), dtype=np.uint8)
+        # G symbols per step through a table of all G-letter words (G chosen so the table stays small)
+        G = 1
+        while G < 4 and self.nsym ** (G + 1) <= 1 << 16:
+            G += 1
+        table = self.__dict__.get("_words")
+        if table is None or table.shape[1] != G:
+            letters = np.frombuffer(self.letters.encode("latin-1"), dtype=np.uint8).astype(np.uint32)
+            idx = np.arange(self.nsym**G)
+            table = np.empty((idx.size, G), dtype=np.uint32)  # UCS-4 code points: the result is VIEWED as unicode
+            for g in range(G - 1, -1, -1):
+                table[:, g] = letters[idx % self.nsym]
+                idx = idx // self.nsym
+            self.__dict__["_words"] = table
+        out = np.empty((codes.size, k), dtype=np.uint32)
         rem = codes.copy()
-        n = np.uint64(self.nsym)
-        for i in range(k - 1, -1, -1):
-            out[:, i] = letters[(rem % n).astype(np.intp)]
-            rem //= n
-        return out.view(f"S{k}").ravel().astype(f"<U{k}")
+        step = np.uint64(self.nsym**G)
+        i = k
+        while i >= G:
+            out[:, i - G : i] = table[(rem % step).astype(np.intp)]
+            rem //= step
+            i -= G
+        if i:  # the leading k mod G symbols
+            out[:, :i] = table[rem.astype(np.intp)][:, G - i :]
+        return out.view(f"<U{k}").ravel()
 
     def encode(self, kmers: Sequence[str], k: int) -> Tuple[np.ndarray, np.ndarray]:
         """k-mer strings -> (codes uint64, ok mask). ok is False for strings that are not

@@ -25,6 +25,9 @@ def group_sum(ctx, csr: engine.CountsCSR, groups: Sequence[int], ngroups: int) -
     `counts` are filled and whose `codes` are unused."""
     if csr.colidx is None:
         raise ValueError("group_sum needs column ids: call engine.build_basis first")
+    if getattr(csr, "elided", False):
+        raise ValueError("group_sum needs real column ids: build the basis without elide_singletons "
+                         "(0xFFFFFFFF marks k-mers of one row only and is not a column)")
     g = np.ascontiguousarray(groups, dtype=np.uint32)
     if g.size != csr.n:
         raise ValueError("one group id per row is required")
@@ -45,6 +48,8 @@ def group_sum(ctx, csr: engine.CountsCSR, groups: Sequence[int], ngroups: int) -
 def cosine_rows_vs_totals(ctx, csr: engine.CountsCSR, ncols: int, totals: engine.CountsCSR, mode: int = 0):
     """cosine_similarity(totals, counts).T of the reference: float32 [csr.n x totals.n] on the
     device, both operands over the same `ncols` columns."""
+    if getattr(csr, "elided", False) or getattr(totals, "elided", False):
+        raise ValueError("rectangular cosine needs real column ids on both sides (no elide_singletons)")
     xr = engine.row_norms(ctx, csr.n, csr.rowptr, csr.counts)
     yr = engine.row_norms(ctx, totals.n, totals.rowptr, totals.counts)
     colptr, post = engine.transpose(ctx, totals.n, totals.nnz, ncols, totals.rowptr, totals.colidx, totals.counts)
@@ -70,6 +75,8 @@ def apply_top2(ctx, csr: engine.CountsCSR, ncols: int, totals: engine.CountsCSR,
     ``round(score[:,0] - score[:,1], 2)`` is the reference's ``delta`` (apply.smk:320-325)."""
     row1 = csr.n if row1 is None else row1
     rows = row1 - row0
+    if getattr(csr, "elided", False) or getattr(totals, "elided", False):
+        raise ValueError("apply_top2 needs real column ids on both sides (no elide_singletons)")
     xsq = engine.row_normsq(ctx, csr.n, csr.rowptr, csr.counts)
     ysq = engine.row_normsq(ctx, totals.n, totals.rowptr, totals.counts)
     colptr, post = engine.transpose(ctx, totals.n, totals.nnz, ncols, totals.rowptr, totals.colidx, totals.counts)

@@ -28,7 +28,8 @@
 //                      chunk.  One dependent memory round trip per posting: slow, but general.
 //
 // Environment knobs of the shipped library select between EXACT kernels only: SKM_COSINE_PATH=cursor
-// forces the fallback everywhere, SKM_COSINE_OVERLAP=1 the blocked two-stream schedule.  The
+// forces the fallback everywhere, SKM_COSINE_PATH=lists the neighbour-list path also for outputs of at most
+// 1024 columns (which the cursor kernel takes by default), SKM_COSINE_OVERLAP=1 the blocked two-stream schedule.  The
 // timing-only ablations (SKM_COSINE_ABLATE / SKM_GRAM_ABLATE, results invalid by construction) and
 // the phase stamps exist only in the -DSKM_DIAG build (libsnekmer_hip_diag.so, `make diag`), which
 // tools/ablate_cosine.py loads; the product library does not read those variables.
@@ -854,10 +855,20 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
         return skm_check_launch("k_cosine_strip");
     }
 
+    // Few columns (the tall-skinny apply case: many query rows against a handful of family totals): the
+    // cursor kernel's dense per-strip accumulators hold every column, no neighbour lists are needed
+    // (a list path would pin SLOT entries of scratch per row for a few-MB output).
+    if (m <= CH && !(path_env && strcmp(path_env, "lists") == 0)) {  // SKM_COSINE_PATH=lists keeps the list path (tests)
+        SKM_PROF(ctx, "k_cosine_strip");
+        SKM_BY_MODE_VEC(SKM_CURSOR);
+        return skm_check_launch("k_cosine_strip");
+    }
+
     // ---- fast path: sparse Gram (+ large-table pass) -> streaming writer -> cursor kernel for what is left
     // neighbour lists: row r of the block owns SLOT entries at g_ent[r * SLOT] (all the first pass
-    // can produce); the lists of the large-table pass are allocated behind that region
-    constexpr unsigned long long SLOT = 1536;  // = the first pass's table capacity
+    // can produce, and never more than the m neighbours a row can have); the lists of the large-table
+    // pass are allocated behind that region
+    const unsigned long long SLOT = (unsigned long long)(m < 1536 ? m : 1536);  // 1536 = the first pass's table capacity
     const unsigned long long fixed_ent = (unsigned long long)nrows * SLOT;
     const unsigned long long cap_ent = fixed_ent + (unsigned long long)max((int64_t)(1 << 20), nrows * 256);
     void *p;

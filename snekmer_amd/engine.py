@@ -71,6 +71,9 @@ class CountsCSR:
         self.ctx, self.n, self.nnz, self.code_bits = ctx, n, nnz, code_bits
         self.rowptr, self.codes, self.counts, self.firstpos = rowptr, codes, counts, firstpos
         self.colidx: Optional[_hip.DeviceArray] = None
+        # True when colidx carries 0xFFFFFFFF for k-mers of one row only (build_basis(elide_singletons=True)):
+        # such a CSR is only meaningful as the X side of the SQUARE cosine against its own postings
+        self.elided = False
 
     @property
     def code_dtype(self):
@@ -119,6 +122,76 @@ def kmer_codes(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int) -> Tuple[np.ndarr
         _ptr(d_codes), _ptr(d_nwin),
     )
     return d_codes.download(batch.total), d_nwin.download(batch.n), bits
+
+
+ARENA_RESIDUES = 1 << 16  # batches up to this many residues / 4096 records use the per-context arena
+ARENA_RECORDS = 4096
+
+
+class _Arena:
+    """Persistent device + host staging of the small-batch path: [offsets | residues] travel up in ONE copy,
+    [window counts | codes] come down in one."""
+
+    def __init__(self, ctx):
+        self.up_bytes = 8 * (ARENA_RECORDS + 1) + ARENA_RESIDUES + 64
+        self.d_up = ctx.zeros(self.up_bytes, np.uint8)
+        self.h_up = np.zeros(self.up_bytes, dtype=np.uint8)
+        self.down_bytes = 4 * ARENA_RECORDS + 8 * (ARENA_RESIDUES + 1)
+        self.d_down = ctx.empty(self.down_bytes, np.uint8)
+        self.h_down = np.zeros(self.down_bytes, dtype=np.uint8)
+
+
+def recode_host(ctx, residues: np.ndarray, offsets: np.ndarray, lut: AlphabetLUT):
+    """a3 from host arrays to host arrays: (translated bytes in the input layout, stripped lengths); small inputs
+    through the context's arena."""
+    n, total = int(offsets.size - 1), int(residues.size)
+    if n > ARENA_RECORDS or total > ARENA_RESIDUES or n == 0:
+        return recode(ctx, SeqBatch(ctx, residues, offsets), lut)
+    arena = ctx.__dict__.get("_arena")
+    if arena is None:
+        arena = ctx.__dict__["_arena"] = _Arena(ctx)
+    off_bytes = 8 * (n + 1)
+    seq_at = (off_bytes + 15) // 16 * 16
+    arena.h_up[:off_bytes] = np.ascontiguousarray(offsets, dtype=np.int64).view(np.uint8)
+    arena.h_up[seq_at : seq_at + total] = residues
+    arena.h_up[seq_at + total : seq_at + total + 16] = 0
+    ctx._h2d(arena.d_up.ptr, arena.h_up[: seq_at + total + 16])
+    len_bytes = (4 * n + 15) // 16 * 16
+    ctx.call("skm_recode", _ptr(lut.translate), _p(arena.d_up.ptr + seq_at), _p(arena.d_up.ptr), _i64(n),
+             _p(arena.d_down.ptr + len_bytes), _p(arena.d_down.ptr))
+    got = arena.h_down[: len_bytes + total]
+    ctx._d2h(got, arena.d_down.ptr)
+    return got[len_bytes : len_bytes + total].copy(), got[: 4 * n].view(np.int32).copy()
+
+
+def kmer_codes_host(ctx, residues: np.ndarray, offsets: np.ndarray, lut: AlphabetLUT, k: int):
+    """a5/a6 from host arrays to host arrays: (codes per window slot, windows per sequence, code_bits).
+    Small inputs use the context's arena (no allocation, two copies in all); larger ones the general path."""
+    n, total = int(offsets.size - 1), int(residues.size)
+    if n > ARENA_RECORDS or total > ARENA_RESIDUES or n == 0:
+        batch = SeqBatch(ctx, residues, offsets)
+        return kmer_codes(ctx, batch, lut, k)
+    arena = ctx.__dict__.get("_arena")
+    if arena is None:
+        arena = ctx.__dict__["_arena"] = _Arena(ctx)
+    bits = lut.code_bits(k)
+    cb = bits // 8
+    off_bytes = 8 * (n + 1)
+    seq_at = (off_bytes + 15) // 16 * 16
+    arena.h_up[:off_bytes] = np.ascontiguousarray(offsets, dtype=np.int64).view(np.uint8)
+    arena.h_up[seq_at : seq_at + total] = residues
+    arena.h_up[seq_at + total : seq_at + total + 16] = 0
+    ctx._h2d(arena.d_up.ptr, arena.h_up[: seq_at + total + 16])
+    nwin_bytes = (4 * n + 15) // 16 * 16
+    d_nwin, d_codes = arena.d_down.ptr, arena.d_down.ptr + nwin_bytes
+    ctx.call("skm_kmer_codes", _ptr(lut.rank), lut.nsym, k, bits, _p(arena.d_up.ptr + seq_at), _p(arena.d_up.ptr), _i64(n),
+             _p(d_codes), _p(d_nwin))
+    got = arena.h_down[: nwin_bytes + cb * total]
+    if got.size:
+        ctx._d2h(got, arena.d_down.ptr)
+    nwin = got[: 4 * n].view(np.int32).copy()
+    codes = got[nwin_bytes : nwin_bytes + cb * total].view(np.uint32 if bits == 32 else np.uint64).copy()
+    return codes, nwin, bits
 
 
 def count_csr(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int, with_firstpos: bool = False,
@@ -189,6 +262,7 @@ def build_basis(ctx, csr: CountsCSR, nsym: int, k: int, stats: bool = False, fir
         _ptr(b.post if postings else None), _ptr(b.postcnt if post32 else None),
     )
     b.ncols = int(ncols.value)
+    csr.elided = bool(elide_singletons)
     return b
 
 
@@ -226,6 +300,8 @@ def dense_to_csr(ctx, dense, n: int, ncols: int, ld: int, cap_entries: int) -> C
 
 
 def transpose(ctx, n: int, nnz: int, ncols: int, rowptr, colidx, counts):
+    """Column-major copy (postings) of a CSR whose column ids are all real (< ncols): a CSR built with
+    elide_singletons carries 0xFFFFFFFF markers and must not come here."""
     colptr = ctx.empty(ncols + 1, np.uint32)
     post = ctx.empty(max(nnz, 1), np.uint64)
     ctx.call("skm_csr_transpose", _i64(n), _i64(nnz), _i64(ncols), _ptr(rowptr), _ptr(colidx), _ptr(counts),

@@ -118,17 +118,32 @@ def _restore_wide_chars(original: str, reduced: str) -> str:
     return "".join(o if ord(o) > 255 else r for o, r in zip(original, reduced))
 
 
+_LUTS: Dict[tuple, AlphabetLUT] = {}
+
+
+def _cached_lut(alphabet, mapping) -> AlphabetLUT:
+    """One LUT per (alphabet, mapping object); a mapping that was edited in place (alphabet.register_alphabet)
+    is recognised by its current table."""
+    table = get_alphabet(alphabet, mapping)
+    key = (str(alphabet), id(mapping), tuple(sorted((k, v) for k, v in dict(table).items() if k != "_keys")))
+    lut = _LUTS.get(key)
+    if lut is None:
+        if len(_LUTS) > 64:
+            _LUTS.clear()
+        lut = _LUTS[key] = build_lut(alphabet, mapping)
+    return lut
+
+
 def reduce_batch(sequences: Sequence[str], alphabet: Union[str, int], mapping: dict = FULL_ALPHABETS) -> List[str]:
     """`reduce` for many sequences in one device call."""
     from . import engine
 
     seqs = [str(s) for s in sequences]
-    lut = build_lut(alphabet, mapping)
+    lut = _cached_lut(alphabet, mapping)
     ctx = _ctx()
-    batch = engine.SeqBatch.from_strings(ctx, seqs)
-    out, lens = engine.recode(ctx, batch, lut)
+    data, off = pack_sequences(seqs)
+    out, lens = engine.recode_host(ctx, data, off, lut)
     raw = out.tobytes()
-    off = batch.h_offsets
     return [
         _restore_wide_chars(s, raw[int(off[i]) : int(off[i]) + int(lens[i])].decode("latin-1"))
         for i, s in enumerate(seqs)
@@ -211,9 +226,21 @@ class KmerVec:
         self.basis = KmerBasis()
         self.snekmer_version = __version__
 
-    # the LUT is derived state: rebuilt on demand so pickles keep the reference's attribute set
+    # The LUT is derived state: built once per object and kept OUT of the pickle, so that .kmers files keep
+    # the reference's attribute set (snekmer/vectorize.py:225-231).
     def _lut(self) -> AlphabetLUT:
-        return build_lut(self.alphabet)
+        lut = self.__dict__.get("_lut_cache")
+        if lut is None or self.__dict__.get("_lut_for") != self.alphabet:
+            lut = build_lut(self.alphabet)
+            self.__dict__["_lut_cache"] = lut
+            self.__dict__["_lut_for"] = self.alphabet
+        return lut
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_lut_cache", None)
+        state.pop("_lut_for", None)
+        return state
 
     def set_kmer_set(self, kmer_set=list()):
         self.kmer_set = KmerSet(self.alphabet, self.k, kmer_set)
@@ -240,15 +267,25 @@ class KmerVec:
         if not strip:
             # trailing '*' must survive as an (invalid) character: shield it from the strip
             seqs = [s + "\x00" if s.endswith("*") else s for s in seqs]
-        batch = engine.SeqBatch.from_strings(ctx, seqs)
-        codes, nwin, bits = engine.kmer_codes(ctx, batch, lut, self.k)
+        data, off = pack_sequences(seqs)
+        # small batches (the per-record calls of an unchanged rule body) go through a per-context arena:
+        # one upload, two launches, one download, no allocation
+        codes, nwin, bits = engine.kmer_codes_host(ctx, data, off, lut, self.k)
         sentinel = np.iinfo(codes.dtype).max
-        out = []
-        off = batch.h_offsets
-        for i in range(batch.n):
-            w = codes[int(off[i]) : int(off[i]) + int(nwin[i])]
-            out.append(lut.decode(w[w != sentinel], self.k))
-        return out
+        n = len(off) - 1
+        if n == 1:
+            w = codes[: int(nwin[0])]
+            return [lut.decode(w[w != sentinel], self.k)]
+        # every record's valid windows decoded in ONE pass, then cut per record
+        slot = np.arange(codes.size, dtype=np.int64)
+        rec = np.searchsorted(off, slot, side="right") - 1
+        live = (slot - off[rec] < nwin[rec]) & (codes != sentinel)
+        words = lut.decode(codes[live], self.k)
+        per = np.bincount(rec[live], minlength=n)
+        cuts = np.cumsum(per)[:-1]
+        parts = np.split(words, cuts) if words.size else [words[:0] for _ in range(n)]
+        empty = np.array([], dtype=str)  # '<U1', shape (0,): what np.array([], dtype=str) gives upstream
+        return [p if p.size else empty for p in parts]
 
     def reduce_vectorize_batch(self, sequences: Sequence[str]) -> List[np.ndarray]:
         """`reduce_vectorize` for many sequences in one device call."""

@@ -278,11 +278,15 @@ def test_cosine_medium_vs_oracle_all_modes(ctx):
     blk = pipe.cosine(row0=501, row1=1203).download().reshape(pipe.out.shape)[: 1203 - 501, :n]
     assert (blk == S[501:1203]).all()
     # the cursor (fallback) kernel alone gives the same bits as sparse-Gram + writer (+ fallback strips)
+    old_path = os.environ.get("SKM_COSINE_PATH")
     os.environ["SKM_COSINE_PATH"] = "cursor"
     try:
         S_cur = pipe.cosine().download().reshape(pipe.out.shape)[:n, :n]
     finally:
-        del os.environ["SKM_COSINE_PATH"]
+        if old_path is None:
+            del os.environ["SKM_COSINE_PATH"]
+        else:
+            os.environ["SKM_COSINE_PATH"] = old_path
     assert (S_cur == S).all()
     # distance mode
     b = pipe.basis
@@ -876,6 +880,16 @@ def test_group_sum_cosine_vs_totals_and_top2(ctx, tag):
     # ... and identical to reducing the materialised block (the unfused round-1 path)
     idx2, val2 = skm_apply.row_top2(ctx, out["scores"], n, 2, out["ld"])
     assert (idx2 == out["top2_index"]).all() and np.abs(val2 - out["top2_score"]).max() <= COS_TOL
+    # the route a handful of columns takes by default (cursor kernel, no neighbour lists) gives the same bits
+    # as the list path the test session pins (tests/conftest.py)
+    old_path = os.environ.pop("SKM_COSINE_PATH", None)
+    try:
+        S_def, ld_def = skm_apply.cosine_rows_vs_totals(ctx, csr, basis.ncols, out["totals"])
+        S_def = S_def.download().reshape(-1, ld_def)[:n, :2]
+    finally:
+        if old_path is not None:
+            os.environ["SKM_COSINE_PATH"] = old_path
+    assert (S_def == S).all()
 
 
 def test_row_top2_ties_and_edges(ctx):
