@@ -26,9 +26,17 @@ def avg(path, counter):
 
 
 shutil.copy(os.path.join(G, "bench.json"), os.path.join(P, f"bench_{tag}.json"))
-db = [f for f in os.listdir(os.path.join(G, "prof")) if f.endswith(".db")][0]
-subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "rocpd_stats.py"), os.path.join(G, "prof", db),
-                       os.path.join(P, f"{tag}_kernel_stats.csv")])
+def newest_db(d):
+    return sorted((f for f in os.listdir(d) if f.endswith(".db")), key=lambda f: os.path.getmtime(os.path.join(d, f)))[-1]
+
+
+# timed workload only (python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras) and the same with the extras
+for sub, name in (("prof", f"{tag}_kernel_stats.csv"), ("prof_x", f"{tag}_kernel_stats_with_extras.csv")):
+    d = os.path.join(G, sub)
+    if os.path.isdir(d):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "rocpd_stats.py"), os.path.join(d, newest_db(d)),
+                               os.path.join(P, name)])
+shutil.copy(os.path.join(G, "prof_bench.json"), os.path.join(P, f"bench_{tag}_under_rocprofv3.json"))
 os.makedirs(os.path.join(P, f"{tag}_pmc"), exist_ok=True)
 wcsv, fcsv = os.path.join(G, "pmc_w", "write_size_counter_collection.csv"), os.path.join(G, "pmc_f", "fetch_size_counter_collection.csv")
 shutil.copy(wcsv, os.path.join(P, f"{tag}_pmc"))

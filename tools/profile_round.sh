@@ -1,14 +1,17 @@
 #!/bin/bash
 # One GPU-box run that produces everything profiles/ holds for a round:
-#   gpu tests, the bench line, rocprofv3 --kernel-trace --stats of the same command, and the two PMC
-#   passes (WRITE_SIZE, FETCH_SIZE; separate passes as MI355X_MICROARCH.md prescribes).
+#   the bench line, rocprofv3 --kernel-trace --stats of the same workload (once without the after-region
+#   extras so that per-kernel averages are those of the timed steps, once with them for the config-5 scatter and
+#   the MFMA kernels), and the two PMC passes (WRITE_SIZE, FETCH_SIZE; separate passes as
+#   MI355X_MICROARCH.md prescribes).
 # rocprofv3 must launch python3 directly (no env/bash wrapper between it and the program).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
-mkdir -p $O && rm -rf $O/prof $O/pmc_w $O/pmc_f
+mkdir -p $O && rm -rf $O/prof $O/prof_x $O/pmc_w $O/pmc_f
 python bench.py > $O/bench.json 2> $O/bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/prof -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err || exit 1
+rocprofv3 --kernel-trace --stats -d $O/prof -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/prof_bench.json 2> $O/prof.err || exit 1
+rocprofv3 --kernel-trace --stats -d $O/prof_x -o x -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_x_bench.json 2> $O/prof_x.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o write_size -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_w.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o fetch_size -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_f.err || exit 1
 cut -c1-300 $O/bench.json
