@@ -23,7 +23,7 @@ namespace {
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 // ------------------------------------------------------------------------------- apply epilogue
-constexpr int ACH = 8192;  // families per LDS pass (64 KiB of int64 accumulators)
+constexpr int ACH = 8192;  // families per LDS pass at most (64 KiB of int64 accumulators)
 constexpr int ATB = 256;
 
 struct top2 {
@@ -62,32 +62,35 @@ __global__ __launch_bounds__(ATB) void k_apply_top2(const int64_t *__restrict__ 
                                                     const uint32_t *__restrict__ ycolptr,
                                                     const uint64_t *__restrict__ ypost,
                                                     const double *__restrict__ ynorm, int64_t row0, int64_t nrows,
-                                                    uint32_t *__restrict__ out_idx, double *__restrict__ out_score,
-                                                    long long *__restrict__ out_dot)
+                                                    int ach, uint32_t *__restrict__ out_idx,
+                                                    double *__restrict__ out_score, long long *__restrict__ out_dot)
 {
-    __shared__ unsigned long long s_acc[ACH];
+    // `ach` accumulators (families per pass) of dynamic LDS: sized to the problem so that a handful of
+    // families does not cost the occupancy of 8192
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_acc[];
     __shared__ top2 s_t[ATB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    constexpr int GL = 16;  // lanes sharing one posting list
-    const int grp = tid / GL, gl = tid % GL;
     for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
         const int64_t i = row0 + r;
         const int64_t b = xrowptr[i], e = xrowptr[i + 1];
         const uint64_t nx = xnormsq[i];
         const double sx = nx ? sqrt((double)nx) : 1.0;
         top2 t = {-INFINITY, -INFINITY, 0, 0, NONE, NONE};
-        for (int64_t a0 = 0; a0 < m; a0 += ACH) {
-            const int span = (int)min((int64_t)ACH, m - a0);
+        for (int64_t a0 = 0; a0 < m; a0 += ach) {
+            const int span = (int)min((int64_t)ach, m - a0);
             for (int z = tid; z < span; z += ATB)
                 s_acc[z] = 0ull;
             __syncthreads();
-            for (int64_t q = b + grp; q < e; q += ATB / GL) {
+            // one THREAD per entry of the query row: a family-total matrix has few families per k-mer (1.1 on
+            // average at 1000 families), so a posting list is a handful of words; the three dependent loads
+            // (column id, list bounds, postings) of all entries are in flight together
+            for (int64_t q = b + tid; q < e; q += ATB) {
                 const uint32_t c = xcolidx[q];
                 if (c == NONE)  // a column Y does not have
                     continue;
                 const unsigned long long v = xcounts[q];
                 const uint32_t pb = ycolptr[c], pe = ycolptr[c + 1];
-                for (uint32_t p = pb + gl; p < pe; p += GL) {
+                for (uint32_t p = pb; p < pe; ++p) {
                     const uint64_t pw = ypost[p];
                     const int64_t a = (int64_t)(uint32_t)pw - a0;
                     if (a >= 0 && a < span)
@@ -323,10 +326,15 @@ extern "C" int skm_apply_top2(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         k_norms_f64<<<(unsigned)skm_ceil_div(m, 256), 256, 0, ctx->stream>>>(m, d_ynormsq, ynorm);
         SKM_TRY(skm_check_launch("k_norms_f64"));
     }
+    int ach = 256;  // power of two >= m, at most ACH
+    while (ach < ACH && ach < m)
+        ach <<= 1;
+    const size_t lds = sizeof(unsigned long long) * (size_t)ach;
+    SKM_HIP(hipFuncSetAttribute((const void *)k_apply_top2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SKM_PROF(ctx, "k_apply_top2");
-    k_apply_top2<<<skm_grid_cap(ctx, nrows, 16), ATB, 0, ctx->stream>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xnormsq, m,
-                                                                        d_ycolptr, d_ypost, ynorm, row0, nrows, d_idx,
-                                                                        d_score, (long long *)d_dot);
+    k_apply_top2<<<skm_grid_cap(ctx, nrows, 32), ATB, lds, ctx->stream>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xnormsq, m,
+                                                                          d_ycolptr, d_ypost, ynorm, row0, nrows, ach, d_idx,
+                                                                          d_score, (long long *)d_dot);
     return skm_check_launch("k_apply_top2");
 }
 
