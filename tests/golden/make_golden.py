@@ -490,7 +490,17 @@ def extra(ref_root):
         demo_conn_cosine=S.connection_matrix_from_features(F, metric="cosine"),
         demo_cos=cosine_similarity(F, F),
     )
-    print("extra fixtures written: g12_apply_*.npz, g13_float_features.npz")
+    # ---- G14: a .kmers file as the reference writes it (rules/kmerize.smk:141-142: pickle.dump(kmer, f))
+    import pickle
+
+    kmer = V.KmerVec(alphabet="hydro", k=14)
+    kmer.set_kmer_set(out["kmerlist"][:200])
+    blob = pickle.dumps(kmer, protocol=4)
+    json.dump({"pickle_hex": blob.hex(), "alphabet": "hydro", "k": 14, "char_set": sorted(kmer.char_set),
+               "n_kmers": 200, "first": [str(x) for x in out["kmerlist"][:5]],
+               "snekmer_version": kmer.snekmer_version, "attrs": sorted(kmer.__dict__.keys())},
+              open(os.path.join(HERE, "g14_reference_kmers_pickle.json"), "w"))
+    print("extra fixtures written: g12_apply_*.npz, g13_float_features.npz, g14_reference_kmers_pickle.json")
 
 
 if __name__ == "__main__":

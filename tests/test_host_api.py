@@ -151,3 +151,32 @@ def test_sparse_npz_roundtrip(tmp_path):
     (kl,), df = skm.io.load_npz(path)
     assert list(kl) == ["AAC", "ACA", "CAA"] and list(df["sequence_length"]) == [4, 4, 2]
     assert [v.tolist() for v in df["sequence_vector"]] == [[1.0, 1.0, 0.0], [1.0, 0.0, 1.0], [0.0, 0.0, 0.0]]
+
+
+def test_reference_written_kmers_pickle_loads_through_the_module_alias():
+    """G14: a .kmers pickle written by the real reference (rules/kmerize.smk:141-142) is read with snekmer_amd
+    after aliasing the module path, as INTEGRATION.md describes; and a pickle written here carries exactly the
+    reference's attribute set (the cached LUT stays out of it)."""
+    import sys
+
+    g = gjson("g14_reference_kmers_pickle.json")
+    saved = {k: sys.modules.get(k) for k in ("snekmer", "snekmer.vectorize")}
+    try:
+        sys.modules["snekmer"] = skm
+        sys.modules["snekmer.vectorize"] = skm.vectorize
+        obj = pickle.loads(bytes.fromhex(g["pickle_hex"]))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    assert isinstance(obj, skm.vectorize.KmerVec) and isinstance(obj.basis, skm.vectorize.KmerBasis)
+    assert (obj.alphabet, obj.k, sorted(obj.char_set), obj.snekmer_version) == (g["alphabet"], g["k"], g["char_set"], g["snekmer_version"])
+    assert sorted(obj.__dict__.keys()) == g["attrs"]
+    assert [str(x) for x in list(obj.kmer_set.kmers)[:5]] == g["first"] and len(list(obj.kmer_set.kmers)) == g["n_kmers"]
+    mine = skm.vectorize.KmerVec("hydro", 14)
+    mine.set_kmer_set(list(obj.kmer_set.kmers))
+    mine._lut()  # populate the cache: it must not reach the pickle
+    state = pickle.loads(pickle.dumps(mine)).__dict__
+    assert sorted(state.keys()) == g["attrs"]
