@@ -138,6 +138,19 @@ int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int flags, int64_
                     uint64_t *d_total, uint64_t *d_firstkey, uint32_t *d_fs_order,
                     uint32_t *d_colptr, void *d_post, uint32_t *d_postcnt);
 
+/* The whole pre-cosine path of the square cosine in ONE call that never waits for the device: skm_count_csr +
+ * skm_basis_build(SKM_BASIS_ELIDE_SINGLETONS, postings) + skm_row_norms_csr, i.e. the body of
+ * rules/kmerize.smk:89-104 + rules/learn.smk:359-383 as the cosine stage needs it.  Sizes that depend on the data stay
+ * on the device: the entry count is d_rowptr[n], the number of basis columns *d_ncols (device int64); every launch is
+ * sized by total_residues.  Outputs as documented for the three calls it replaces, capacity cap_entries >
+ * total_residues each (d_colptr: cap_entries + 1); d_codes past the entry count is filled with the all-ones sentinel;
+ * d_rnorm / d_normsq are optional.  Nothing here is host-synchronous: read d_rowptr[n] / *d_ncols with
+ * skm_memcpy_d2h when the host needs them.  n >= 1 and total_residues >= 1. */
+int skm_vectorize_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits, const uint8_t *d_seq,
+                      const int64_t *d_off, int64_t n, int64_t total_residues, int64_t cap_entries, int64_t *d_rowptr,
+                      void *d_codes, uint32_t *d_counts, void *d_basis, uint32_t *d_colidx, uint32_t *d_colptr,
+                      uint64_t *d_post, float *d_rnorm, uint64_t *d_normsq, int64_t *d_ncols);
+
 /* Column-major copy (postings) of any CSR with column ids < ncols; rows ascending per column. */
 int skm_csr_transpose(skm_ctx *ctx, int64_t n, int64_t nnz, int64_t ncols, const int64_t *d_rowptr,
                       const uint32_t *d_colidx, const uint32_t *d_counts, uint32_t *d_colptr,

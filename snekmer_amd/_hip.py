@@ -70,6 +70,10 @@ _SIGNATURES = {
         C.c_int,
         [_p, C.c_int, C.c_int, C.c_int, _i64, _i64, _p, _p, _p, _p, C.POINTER(_i64), _p, _p, _p, _p, _p, _p, _p, _p, _p],
     ),
+    "skm_vectorize_csr": (
+        C.c_int,
+        [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    ),
     "skm_csr_transpose": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p]),
     "skm_csr_concat_rowptr": (C.c_int, [_p, C.c_int, _p, _p, _p, _p]),
     "skm_csr_to_dense": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, C.c_int, C.c_int, _p, _i64]),

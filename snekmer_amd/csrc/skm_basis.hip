@@ -383,6 +383,155 @@ __global__ __launch_bounds__(BLK) void k_row_norms(int64_t n, const int64_t *__r
     }
 }
 
+// ------------------------------------------------------------------------------- device-sized basis stage
+// The basis stage of skm_vectorize_csr: the entry count lives on the device (d_nnz), every launch is sized by the
+// host-known capacity `cap`, and the head scan is fused into the scatter (per-block head counts, one small scan
+// over the blocks, then every block rebuilds its local prefix): no rocPRIM scan pass over the entries, no
+// column-id array written and re-read, no host round trip.  Singletons are elided (cosine pipeline form).
+constexpr int HB = 2048;  // sorted positions per block: 256 threads x 8 consecutive positions
+
+template <typename K>
+__global__ __launch_bounds__(256) void k_head_count(const int64_t *__restrict__ d_nnz, const K *__restrict__ skeys,
+                                                    uint32_t *__restrict__ blockheads)
+{
+    __shared__ uint32_t s_w[4];
+    const int64_t nnz = *d_nnz;
+    const int64_t base = (int64_t)blockIdx.x * HB;
+    uint32_t heads = 0;
+#pragma unroll
+    for (int j = 0; j < HB / 256; ++j) {  // lane-consecutive positions: both loads coalesce
+        const int64_t t = base + j * 256 + threadIdx.x;
+        if (t < nnz)
+            heads += (t == 0 || skeys[t] != skeys[t - 1]) ? 1u : 0u;
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        heads += __shfl_down(heads, o);
+    if ((threadIdx.x & 63) == 0)
+        s_w[threadIdx.x >> 6] = heads;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        blockheads[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// exclusive prefix of the per-block head counts (one workgroup), the number of columns and the closing colptr entry
+__global__ __launch_bounds__(1024) void k_scan_blocks(int64_t nblocks, uint32_t *__restrict__ blockheads,
+                                                      const int64_t *__restrict__ d_nnz, int64_t *__restrict__ d_ncols,
+                                                      uint32_t *__restrict__ colptr)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0)
+        s_carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nblocks; base += 1024) {
+        const int64_t b = base + tid;
+        const uint32_t v = b < nblocks ? blockheads[b] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o)
+                incl += up;
+        }
+        if (lane == 63)
+            s_w[wid] = incl;
+        __syncthreads();
+        uint32_t before = s_carry, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            before += w < wid ? s_w[w] : 0u;
+            total += s_w[w];
+        }
+        if (b < nblocks)
+            blockheads[b] = before + incl - v;
+        __syncthreads();
+        if (tid == 0)
+            s_carry += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *d_ncols = (int64_t)s_carry;
+        if (colptr)
+            colptr[s_carry] = (uint32_t)*d_nnz;
+    }
+}
+
+template <typename K>
+__global__ __launch_bounds__(256) void k_basis_scatter_fused(const int64_t *__restrict__ d_nnz, const K *__restrict__ skeys,
+                                                             const uint32_t *__restrict__ sidx,
+                                                             const uint32_t *__restrict__ blockbase,
+                                                             const uint64_t *__restrict__ rowcount, K *__restrict__ basis,
+                                                             uint32_t *__restrict__ colidx, uint32_t *__restrict__ colptr,
+                                                             uint64_t *__restrict__ post)
+{
+    // Three phases so that every global access is lane-consecutive: (1) the block's keys come into LDS with
+    // coalesced loads; (2) every thread ranks 8 CONSECUTIVE positions out of LDS (blocked layout: what the scan
+    // wants) and leaves a column word per position in LDS; (3) positions are walked lane-consecutively again for
+    // the gathers and scatters.
+    __shared__ K s_key[HB + 2];      // [0] = key in front of the block, [HB + 1] = key behind it
+    __shared__ uint32_t s_col[HB];
+    __shared__ uint8_t s_flag[HB];  // bit 0 = first position of its column, bit 1 = also the last (singleton)
+    __shared__ uint32_t s_w[4];
+    const int64_t nnz = *d_nnz;
+    const int64_t base = (int64_t)blockIdx.x * HB;
+    if (base >= nnz)  // uniform for the workgroup
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int live = (int)min((int64_t)HB, nnz - base);
+    for (int z = tid; z < HB + 2; z += 256) {
+        const int64_t t = base + z - 1;
+        s_key[z] = (t >= 0 && t < nnz) ? skeys[t] : ~K(0);
+    }
+    __syncthreads();
+    const int p0 = tid * 8;
+    uint32_t hm = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (p0 + i < live && (base + p0 + i == 0 || s_key[p0 + i + 1] != s_key[p0 + i]))
+            hm |= 1u << i;
+    const uint32_t mine = (uint32_t)__popc(hm);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if (lane >= o)
+            incl += up;
+    }
+    if (lane == 63)
+        s_w[wid] = incl;
+    __syncthreads();
+    uint32_t heads = blockbase[blockIdx.x] + incl - mine;  // heads in front of this thread's first position
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        heads += w < wid ? s_w[w] : 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (p0 + i >= live)
+            break;
+        const bool head = (hm >> i) & 1u;
+        heads += head ? 1u : 0u;
+        const bool last_of_col = base + p0 + i == nnz - 1 || s_key[p0 + i + 2] != s_key[p0 + i + 1];
+        s_col[p0 + i] = heads - 1u;
+        s_flag[p0 + i] = (uint8_t)((head ? 1 : 0) | (head && last_of_col ? 2 : 0));
+    }
+    __syncthreads();
+    for (int z = tid; z < live; z += 256) {
+        const int64_t t = base + z;
+        const uint32_t c = s_col[z];
+        const uint32_t f = s_flag[z];
+        if (f & 1u) {
+            basis[c] = s_key[z + 1];
+            colptr[c] = (uint32_t)t;
+        }
+        if (f & 2u)  // the only position of its column: a k-mer of one sequence, no posting; colidx stays 0xFFFFFFFF
+            continue;
+        const uint32_t e = sidx[t];
+        colidx[e] = c;
+        post[t] = rowcount[e];
+    }
+}
+
 template <typename K, typename PW>
 int basis_impl(skm_ctx *ctx, int key_bits, int flags, int64_t n, int64_t nnz, const int64_t *d_rowptr, const K *d_codes,
                const uint32_t *d_counts, const uint32_t *d_firstpos, int64_t *h_ncols, K *d_basis, uint32_t *d_colidx,
@@ -795,4 +944,48 @@ extern "C" int skm_pair_work(skm_ctx *ctx, int64_t ncols, const uint32_t *d_colp
     SKM_HIP(hipStreamSynchronize(ctx->stream));
     *h_pairs = *(uint64_t *)ctx->h_pinned;
     return SKM_OK;
+}
+
+int skm_basis_stage_async(skm_ctx *ctx, int code_bits, int key_bits, int64_t cap, const int64_t *d_nnz, const void *d_codes,
+                          const uint64_t *d_rowcount, void *d_basis, uint32_t *d_colidx, uint32_t *d_colptr, uint64_t *d_post,
+                          int64_t *d_ncols)
+{
+    hipStream_t st = ctx->stream;
+    const size_t kb = (size_t)(code_bits / 8);
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_A, kb * (size_t)cap, &p));
+    void *skeys = p;
+    SKM_TRY(skm_ws(ctx, WS_C, sizeof(uint32_t) * (size_t)cap, &p));
+    uint32_t *sidx = (uint32_t *)p;
+    const int64_t nblocks = skm_ceil_div(cap, HB);
+    SKM_TRY(skm_ws(ctx, WS_L, sizeof(uint32_t) * (size_t)(nblocks + 1), &p));
+    uint32_t *blockheads = (uint32_t *)p;
+    if (key_bits <= 0 || key_bits > code_bits)
+        key_bits = code_bits;
+    SKM_HIP(hipMemsetAsync(d_colidx, 0xFF, sizeof(uint32_t) * (size_t)cap, st));
+    // Entries past the device-side count carry the all-ones sentinel (skm_count_stage_async): they are the last
+    // ones of the input, and the sort is stable, so positions [0, nnz) of the sorted order are exactly the entries.
+    if (code_bits == 32)
+        SKM_TRY(sort_pairs<uint32_t>(ctx, (const uint32_t *)d_codes, (uint32_t *)skeys, sidx, cap, key_bits, "rocprim_radix_sort_codes"));
+    else
+        SKM_TRY(sort_pairs<uint64_t>(ctx, (const uint64_t *)d_codes, (uint64_t *)skeys, sidx, cap, key_bits, "rocprim_radix_sort_codes"));
+    {
+        SKM_PROF(ctx, "k_head_count");
+        if (code_bits == 32)
+            k_head_count<uint32_t><<<(unsigned)nblocks, 256, 0, st>>>(d_nnz, (const uint32_t *)skeys, blockheads);
+        else
+            k_head_count<uint64_t><<<(unsigned)nblocks, 256, 0, st>>>(d_nnz, (const uint64_t *)skeys, blockheads);
+        k_scan_blocks<<<1, 1024, 0, st>>>(nblocks, blockheads, d_nnz, d_ncols, d_colptr);
+    }
+    SKM_TRY(skm_check_launch("k_head_count"));
+    {
+        SKM_PROF(ctx, "k_basis_scatter");
+        if (code_bits == 32)
+            k_basis_scatter_fused<uint32_t><<<(unsigned)nblocks, 256, 0, st>>>(d_nnz, (const uint32_t *)skeys, sidx, blockheads, d_rowcount,
+                                                                             (uint32_t *)d_basis, d_colidx, d_colptr, d_post);
+        else
+            k_basis_scatter_fused<uint64_t><<<(unsigned)nblocks, 256, 0, st>>>(d_nnz, (const uint64_t *)skeys, sidx, blockheads, d_rowcount,
+                                                                             (uint64_t *)d_basis, d_colidx, d_colptr, d_post);
+    }
+    return skm_check_launch("k_basis_scatter");
 }

@@ -39,7 +39,7 @@ void skm_set_error(const char *fmt, ...);
 // Grow-only scratch slots.  Every entry point draws its temporaries from fixed slots so that,
 // after a warm-up call, the timed path performs no hipMalloc/hipFree.
 enum skm_ws_slot {
-    WS_A = 0, WS_B, WS_C, WS_D, WS_E, WS_F, WS_G, WS_H, WS_I, WS_J, WS_ROCPRIM, WS_SMALL, WS_LUT,
+    WS_A = 0, WS_B, WS_C, WS_D, WS_E, WS_F, WS_G, WS_H, WS_I, WS_J, WS_K, WS_L, WS_ROCPRIM, WS_SMALL, WS_LUT,
     WS_COUNT
 };
 
@@ -55,6 +55,7 @@ struct skm_ctx {
     void *ws[WS_COUNT] = {};
     size_t ws_bytes[WS_COUNT] = {};
     void *h_pinned = nullptr;  // small pinned buffer for count read-backs
+    hipEvent_t ev_host = nullptr;  // marks an asynchronous read-back the host waits for while later kernels run
     bool profiling = false;
     std::vector<skm_prof_entry> prof;
     std::vector<hipEvent_t> event_pool;
@@ -108,3 +109,12 @@ static inline int skm_grid_cap(const skm_ctx *ctx, int64_t want, int per_cu = 8)
         want = 1;
     return (int)(want < cap ? want : cap);
 }
+
+// Stage functions shared by the fused entry point skm_vectorize_csr (skm_api.hip would be the natural home; they
+// live with their kernels in skm_kmer.hip / skm_basis.hip).  Neither waits for the device.
+int skm_count_stage_async(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits, const uint8_t *d_seq,
+                          const int64_t *d_off, int64_t n, int64_t total_residues, int64_t *d_rowptr, void *d_codes,
+                          uint32_t *d_counts, uint64_t *d_rowcount, float *d_rnorm, uint64_t *d_normsq);
+int skm_basis_stage_async(skm_ctx *ctx, int code_bits, int key_bits, int64_t cap, const int64_t *d_nnz, const void *d_codes,
+                          const uint64_t *d_rowcount, void *d_basis, uint32_t *d_colidx, uint32_t *d_colptr, uint64_t *d_post,
+                          int64_t *d_ncols);

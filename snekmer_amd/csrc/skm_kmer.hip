@@ -166,10 +166,13 @@ __global__ __launch_bounds__(64) void k_count_short(skm_lut256 lut, int nsym, in
                                                     const uint8_t *__restrict__ seq,
                                                     const int64_t *__restrict__ off,
                                                     const int32_t *__restrict__ slen,
-                                                    const uint32_t *__restrict__ list, uint32_t nlist,
+                                                    const uint32_t *__restrict__ list,
+                                                    const uint32_t *__restrict__ nlist_ptr,
                                                     K *__restrict__ tmp_codes, uint32_t *__restrict__ tmp_counts,
                                                     uint32_t *__restrict__ tmp_first, int32_t *__restrict__ row_nnz)
 {
+    // the list length is read on the device: the launch does not wait for the host to learn it
+    const uint32_t nlist = *nlist_ptr;
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_rank[SHORT_MAX + 64 + 8];
     __shared__ K s_uniq[SHORT_MAX];
@@ -457,6 +460,9 @@ __global__ __launch_bounds__(BLK) void k_count_block(skm_lut256 lut, int nsym, i
 }
 
 // Copy each row's entries from its padded slot (at off[i]) to the tight CSR position.
+// Optional by-products of the same pass (the fused vectorize entry point asks for them, so that the basis and
+// norm stages need no pass of their own over the entries): rowcount[e] = row | count << 32, the posting word of
+// entry e; rnorm[i] = 1/||row i|| (1 for an all-zero row) and normsq[i] = its exact squared norm.
 template <typename K>
 __global__ __launch_bounds__(BLK) void k_compact_rows(const int64_t *__restrict__ off,
                                                       const int64_t *__restrict__ rowptr, int64_t n,
@@ -464,7 +470,8 @@ __global__ __launch_bounds__(BLK) void k_compact_rows(const int64_t *__restrict_
                                                       const uint32_t *__restrict__ tmp_counts,
                                                       const uint32_t *__restrict__ tmp_first,
                                                       K *__restrict__ codes, uint32_t *__restrict__ counts,
-                                                      uint32_t *__restrict__ first)
+                                                      uint32_t *__restrict__ first, uint64_t *__restrict__ rowcount,
+                                                      float *__restrict__ rnorm, uint64_t *__restrict__ normsq)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -472,11 +479,26 @@ __global__ __launch_bounds__(BLK) void k_compact_rows(const int64_t *__restrict_
     for (int64_t i = wave; i < n; i += nwaves) {
         const int64_t src = off[i], dst = rowptr[i];
         const int64_t cnt = rowptr[i + 1] - dst;
+        unsigned long long sq = 0;
         for (int64_t t = lane; t < cnt; t += 64) {
+            const uint32_t c = tmp_counts[src + t];
             codes[dst + t] = tmp_codes[src + t];
-            counts[dst + t] = tmp_counts[src + t];
+            counts[dst + t] = c;
             if (first)
                 first[dst + t] = tmp_first[src + t];
+            if (rowcount)
+                rowcount[dst + t] = (uint64_t)(uint32_t)i | ((uint64_t)c << 32);
+            sq += (unsigned long long)c * c;
+        }
+        if (rnorm || normsq) {
+            for (int o = 32; o > 0; o >>= 1)
+                sq += __shfl_down(sq, o);
+            if (lane == 0) {
+                if (normsq)
+                    normsq[i] = sq;
+                if (rnorm)
+                    rnorm[i] = sq ? (float)(1.0 / sqrt((double)sq)) : 1.0f;
+            }
         }
     }
 }
@@ -513,10 +535,13 @@ int check_code_space(int nsym, int k, int code_bits)
     return SKM_OK;
 }
 
+// `h_nnz` == nullptr: nothing waits for the device (the caller sizes later stages by `total_residues` and reads the
+// entry count from d_rowptr[n] on the device); d_rowcount / d_rnorm / d_normsq: by-products of the compaction pass.
 template <typename K, bool WITH_POS>
 int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const uint8_t *d_seq,
                    const int64_t *d_off, int64_t n, int64_t total_residues, int64_t *d_rowptr, K *d_codes,
-                   uint32_t *d_counts, uint32_t *d_firstpos, int64_t *h_nnz)
+                   uint32_t *d_counts, uint32_t *d_firstpos, int64_t *h_nnz, uint64_t *d_rowcount = nullptr,
+                   float *d_rnorm = nullptr, uint64_t *d_normsq = nullptr)
 {
     hipStream_t st = ctx->stream;
     void *p;
@@ -546,17 +571,22 @@ int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const u
                                                                      row_nnz);
     }
     SKM_TRY(skm_check_launch("k_classify"));
+    // The size-class counts travel to the host asynchronously; the short-sequence kernel (nearly all of the work) is
+    // launched at once with a worst-case grid and reads its list length on the device, so the host's wait for the
+    // counts overlaps with it instead of idling the GPU.
     uint32_t *h_fill = (uint32_t *)ctx->h_pinned;
     SKM_HIP(hipMemcpyAsync(h_fill, fill, sizeof(uint32_t) * NBUCKET, hipMemcpyDeviceToHost, st));
-    SKM_HIP(hipStreamSynchronize(st));
-
-    if (h_fill[1]) {
+    if (!ctx->ev_host)
+        SKM_HIP(hipEventCreateWithFlags(&ctx->ev_host, hipEventDisableTiming));
+    SKM_HIP(hipEventRecord(ctx->ev_host, st));
+    {
         SKM_PROF(ctx, "k_count_short");
-        int grid = skm_grid_cap(ctx, h_fill[1], 64);
-        k_count_short<K, WITH_POS><<<grid, 64, 0, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + 1 * n, h_fill[1],
+        int grid = skm_grid_cap(ctx, n, 64);
+        k_count_short<K, WITH_POS><<<grid, 64, 0, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + 1 * n, fill + 1,
                                                          tmp_codes, tmp_counts, tmp_first, row_nnz);
         SKM_TRY(skm_check_launch("k_count_short"));
     }
+    SKM_HIP(hipEventSynchronize(ctx->ev_host));
     for (int bk = 2; bk <= 5; ++bk) {
         if (!h_fill[bk])
             continue;
@@ -619,13 +649,15 @@ int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const u
         SKM_PROF(ctx, "k_compact_rows");
         int grid = skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16);
         k_compact_rows<K><<<grid, BLK, 0, st>>>(d_off, d_rowptr, n, tmp_codes, tmp_counts, tmp_first, d_codes, d_counts,
-                                                 WITH_POS ? d_firstpos : nullptr);
+                                                 WITH_POS ? d_firstpos : nullptr, d_rowcount, d_rnorm, d_normsq);
     }
     SKM_TRY(skm_check_launch("k_compact_rows"));
-    int64_t *h_n = (int64_t *)ctx->h_pinned;
-    SKM_HIP(hipMemcpyAsync(h_n, d_rowptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    SKM_HIP(hipStreamSynchronize(st));
-    *h_nnz = *h_n;
+    if (h_nnz) {
+        int64_t *h_n = (int64_t *)ctx->h_pinned;
+        SKM_HIP(hipMemcpyAsync(h_n, d_rowptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        SKM_HIP(hipStreamSynchronize(st));
+        *h_nnz = *h_n;
+    }
     return SKM_OK;
 }
 
@@ -724,4 +756,22 @@ extern "C" int skm_count_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int 
                                               (uint64_t *)d_codes, d_counts, d_firstpos, h_nnz);
     return count_csr_impl<uint64_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, d_rowptr,
                                            (uint64_t *)d_codes, d_counts, nullptr, h_nnz);
+}
+
+// Count stage of skm_vectorize_csr: the same kernels as skm_count_csr, nothing waits for the device, d_codes is
+// pre-filled with the sentinel so that everything past the (device-side) entry count sorts last, and the
+// compaction pass also emits the posting words and the row norms.
+int skm_count_stage_async(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits, const uint8_t *d_seq,
+                          const int64_t *d_off, int64_t n, int64_t total_residues, int64_t *d_rowptr, void *d_codes,
+                          uint32_t *d_counts, uint64_t *d_rowcount, float *d_rnorm, uint64_t *d_normsq)
+{
+    skm_lut256 lut;
+    SKM_TRY(make_lut(h_rank, &lut));
+    SKM_TRY(check_code_space(nsym, k, code_bits));
+    SKM_HIP(hipMemsetAsync(d_codes, 0xFF, (size_t)(code_bits / 8) * (size_t)(total_residues + 1), ctx->stream));
+    if (code_bits == 32)
+        return count_csr_impl<uint32_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, d_rowptr, (uint32_t *)d_codes,
+                                               d_counts, nullptr, nullptr, d_rowcount, d_rnorm, d_normsq);
+    return count_csr_impl<uint64_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, d_rowptr, (uint64_t *)d_codes,
+                                           d_counts, nullptr, nullptr, d_rowcount, d_rnorm, d_normsq);
 }

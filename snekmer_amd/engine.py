@@ -68,8 +68,9 @@ class CountsCSR:
     """Per-sequence (code, count) lists on the device; codes ascending within a row."""
 
     def __init__(self, ctx, n, nnz, code_bits, rowptr, codes, counts, firstpos):
-        self.ctx, self.n, self.nnz, self.code_bits = ctx, n, nnz, code_bits
+        self.ctx, self.n, self.code_bits = ctx, n, code_bits
         self.rowptr, self.codes, self.counts, self.firstpos = rowptr, codes, counts, firstpos
+        self.nnz = nnz
         self.colidx: Optional[_hip.DeviceArray] = None
         # True when colidx carries 0xFFFFFFFF for k-mers of one row only (build_basis(elide_singletons=True)):
         # such a CSR is only meaningful as the X side of the SQUARE cosine against its own postings
@@ -78,6 +79,18 @@ class CountsCSR:
     @property
     def code_dtype(self):
         return np.uint32 if self.code_bits == 32 else np.uint64
+
+    # The entry count may live on the device only (vectorize_fused leaves it in rowptr[n] and never waits for
+    # the GPU): it is fetched, once, when the host first asks for it.
+    @property
+    def nnz(self) -> int:
+        if self._nnz is None:
+            self._nnz = int(self.rowptr.download(1, offset=self.n)[0])
+        return self._nnz
+
+    @nnz.setter
+    def nnz(self, value):
+        self._nnz = None if value is None else int(value)
 
     def host(self):
         """(rowptr, codes, counts, firstpos|None) as numpy arrays."""
@@ -94,13 +107,29 @@ class Basis:
     """Observed k-mer basis of one CountsCSR plus its column-major copy (postings)."""
 
     def __init__(self):
-        self.ncols = 0
+        self._ncols = 0
+        self.d_ncols = None  # device int64 written by skm_vectorize_csr
         self.codes = self.df = self.total = self.firstkey = self.fs_order = None
         self.colptr = self.post = None
         # posting words: 64 = row | count << 32; 32 = row | min(count, 255) << 24 with the real counts of
         # saturated postings in `postcnt` (include/snekmer_hip.h, SKM_BASIS_POST32)
         self.post_bits = 64
         self.postcnt = None
+
+    @property
+    def ncols(self) -> int:
+        """Number of basis columns; fetched from the device on first use after a fused vectorize."""
+        if self._ncols is None:
+            self._ncols = int(self.d_ncols.download(1)[0])
+        return self._ncols
+
+    @ncols.setter
+    def ncols(self, value):
+        self._ncols = None if value is None else int(value)
+
+    def ncols_hint(self) -> int:
+        """The column count if the host already knows it, else an upper bound (the kernels only validate it)."""
+        return self._ncols if self._ncols is not None else int(self.colptr.size - 1)
 
 
 def recode(ctx: _hip.Context, batch: SeqBatch, lut: AlphabetLUT) -> Tuple[np.ndarray, np.ndarray]:
@@ -264,6 +293,43 @@ def build_basis(ctx, csr: CountsCSR, nsym: int, k: int, stats: bool = False, fir
     b.ncols = int(ncols.value)
     csr.elided = bool(elide_singletons)
     return b
+
+
+def vectorize_fused(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int, csr: Optional[CountsCSR] = None,
+                    basis: Optional[Basis] = None, rnorm=None):
+    """count_csr + build_basis(elide_singletons, postings) + row_norms in one call that never waits for the GPU
+    (skm_vectorize_csr): sizes that depend on the data (entry count, number of columns) stay on the device and are
+    fetched lazily by `CountsCSR.nnz` / `Basis.ncols`.  Returns (csr, basis, rnorm); pass the previous ones to reuse
+    their buffers."""
+    if batch.n < 1 or batch.total < 1:
+        raise ValueError("vectorize_fused needs a non-empty batch")
+    bits = lut.code_bits(k)
+    dt = np.uint32 if bits == 32 else np.uint64
+    cap = batch.total + 1
+    if csr is None or csr.codes.size < cap or csr.code_bits != bits or csr.rowptr.size < batch.n + 1:
+        csr = CountsCSR(ctx, batch.n, None, bits, ctx.empty(batch.n + 1, np.int64), ctx.empty(cap, dt),
+                        ctx.empty(cap, np.uint32), None)
+    if csr.colidx is None or csr.colidx.size < cap:
+        csr.colidx = ctx.empty(cap, np.uint32)
+    b = basis or Basis()
+    if b.codes is None or b.codes.size < cap or b.codes.dtype != np.dtype(dt):
+        b.codes = ctx.empty(cap, dt)
+    if b.colptr is None or b.colptr.size < cap + 1:
+        b.colptr = ctx.empty(cap + 1, np.uint32)
+    if b.post is None or b.post.size < cap or b.post.dtype != np.dtype(np.uint64):
+        b.post = ctx.empty(cap, np.uint64)
+    if b.d_ncols is None:
+        b.d_ncols = ctx.zeros(1, np.int64)
+    b.post_bits, b.postcnt = 64, None
+    rn = rnorm if rnorm is not None and rnorm.size >= batch.n else ctx.empty(batch.n + 4, np.float32)
+    ctx.call(
+        "skm_vectorize_csr", _ptr(lut.rank), lut.nsym, k, bits, _ptr(batch.d_seq), _ptr(batch.d_off), _i64(batch.n),
+        _i64(batch.total), _i64(cap), _ptr(csr.rowptr), _ptr(csr.codes), _ptr(csr.counts), _ptr(b.codes), _ptr(csr.colidx),
+        _ptr(b.colptr), _ptr(b.post), _ptr(rn), _ptr(None), _ptr(b.d_ncols),
+    )
+    csr.n, csr.nnz, csr.elided = batch.n, None, True
+    b.ncols = None
+    return csr, b, rn
 
 
 def row_norms(ctx, n: int, rowptr, counts, out=None) -> _hip.DeviceArray:
@@ -450,8 +516,9 @@ class Pipeline:
     N x N float32 cosine) resident in HBM.
     """
 
-    def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int, post32: bool = False):
+    def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int, post32: bool = False, fused: bool = True):
         self.ctx, self.lut, self.k = ctx, lut, k
+        self.fused = fused  # skm_vectorize_csr (one call, no host synchronisation) instead of the three-call form
         # 4-byte posting words (batches under 2^24 sequences): half the posting bytes, but measured SLOWER
         # end to end on MI355X (k_gram_sparse is bound by instruction issue and the decode costs
         # instructions: 1.90 vs 1.75 ms at BASELINE configs[2]), so it is opt-in
@@ -462,6 +529,11 @@ class Pipeline:
         self.out = None
 
     def vectorize(self, batch: SeqBatch) -> CountsCSR:
+        if self.fused and not self.post32 and batch.n >= 1 and batch.total >= 1:
+            # one call, no host round trip: the host runs ahead of the GPU through the whole step
+            self.csr, self.basis, self.rnorm = vectorize_fused(self.ctx, batch, self.lut, self.k, csr=self.csr,
+                                                               basis=self.basis, rnorm=self.rnorm)
+            return self.csr
         self.csr = count_csr(self.ctx, batch, self.lut, self.k, out=self.csr)
         self.basis = build_basis(self.ctx, self.csr, self.lut.nsym, self.k, out=self.basis, elide_singletons=True,
                                  post32=self.post32)
@@ -477,7 +549,7 @@ class Pipeline:
             self.out = None
             self.out = self.ctx.empty((max(rows, 1), max(ld, 1)), np.float32)
         b = self.basis
-        cosine_matrix(self.ctx, self.csr, self.rnorm, n, b.ncols, b.colptr, b.post, self.rnorm,
+        cosine_matrix(self.ctx, self.csr, self.rnorm, n, b.ncols_hint(), b.colptr, b.post, self.rnorm,
                       row0=row0, row1=row1, out=self.out, ld=ld, post_bits=b.post_bits, postcnt=b.postcnt)
         return self.out
 

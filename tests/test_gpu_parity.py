@@ -1478,3 +1478,49 @@ def test_config4_one_rank_share_125k_rows_vs_1m(ctx):
         assert np.abs(np.sort(cosr[got])[::-1] - cosr[best][: len(got)]).max() <= COS_TOL
         assert (fam[got[:3]] == fam[r]).all()
     assert int((length == 0xFFFFFFFF).sum()) == 0  # no row of the block was left out
+
+
+# ------------------------------------------------------------------ fused vectorize (no host synchronisation)
+@pytest.mark.parametrize("name,k", [("red6", 12), ("standard", 12), ("hydro", 20), ("hydro", 3)])
+def test_fused_vectorize_equals_the_three_call_form(ctx, name, k):
+    """skm_vectorize_csr (count + basis/postings + norms in one call, sizes left on the device) against
+    skm_count_csr + skm_basis_build + skm_row_norms_csr: every output array identical, and the cosine matrix with it;
+    all size classes (long sequences take the LDS-block and global-scratch count kernels), both code widths."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+
+    lut = A.build_lut(name)
+    seqs, (res, off) = _mixed_batch(seed=31, n=700)
+    batch = engine.SeqBatch(ctx, res, off)
+    n = batch.n
+    a = engine.Pipeline(ctx, lut, k, fused=False)
+    b = engine.Pipeline(ctx, lut, k, fused=True)
+    Sa = a.step(batch)
+    Sa = Sa.download().reshape(Sa.shape)[:n, :n].copy()
+    for _ in range(2):  # second step reuses every buffer
+        Sb = b.step(batch)
+    assert b.csr._nnz is None and b.basis._ncols is None  # nothing was read back during the step
+    Sb = Sb.download().reshape(Sb.shape)[:n, :n]
+    assert (Sa == Sb).all()
+    assert b.csr.nnz == a.csr.nnz and b.basis.ncols == a.basis.ncols
+    nnz, B = a.csr.nnz, a.basis.ncols
+    for x, y in ((a.csr.rowptr.download(n + 1), b.csr.rowptr.download(n + 1)),
+                 (a.csr.codes.download(nnz), b.csr.codes.download(nnz)),
+                 (a.csr.counts.download(nnz), b.csr.counts.download(nnz)),
+                 (a.csr.colidx.download(nnz), b.csr.colidx.download(nnz)),
+                 (a.basis.codes.download(B), b.basis.codes.download(B)),
+                 (a.basis.colptr.download(B + 1), b.basis.colptr.download(B + 1)),
+                 (a.rnorm.download(n), b.rnorm.download(n))):
+        assert (x == y).all()
+    # postings: only the positions of shared columns are written in either form
+    cp = a.basis.colptr.download(B + 1).astype(np.int64)
+    shared = np.zeros(nnz, dtype=bool)
+    col = a.csr.colidx.download(nnz)
+    df = np.diff(cp)
+    for c in np.nonzero(df > 1)[0][:2000]:
+        shared[cp[c]:cp[c + 1]] = True
+    pa, pb = a.basis.post.download(nnz), b.basis.post.download(nnz)
+    assert (pa[shared] == pb[shared]).all()
+    # the sentinel fill past the entry count (what lets the sort run without knowing it)
+    tail = b.csr.codes.download(batch.total + 1 - nnz, offset=nnz)
+    assert (tail == np.iinfo(tail.dtype).max).all()

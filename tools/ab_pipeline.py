@@ -15,9 +15,10 @@ ctx = _hip.Context(0)
 lut = alphabet.build_lut("red6")
 res, off, _ = synth_families(n, 300, family=100, seed=BASE_SEED + 2)
 batch = engine.SeqBatch(ctx, res, off)
-variants = {"post64": (engine.Pipeline(ctx, lut, 12, post32=False), {}),
-            "post32": (engine.Pipeline(ctx, lut, 12, post32=True), {}),
-            "post64/overlap": (engine.Pipeline(ctx, lut, 12, post32=False), {"SKM_COSINE_OVERLAP": "1"})}
+variants = {"three calls": (engine.Pipeline(ctx, lut, 12, fused=False), {}),
+            "fused vectorize": (engine.Pipeline(ctx, lut, 12, fused=True), {}),
+            "fused + overlap": (engine.Pipeline(ctx, lut, 12, fused=True), {"SKM_COSINE_OVERLAP": "1"}),
+            "three calls, post32": (engine.Pipeline(ctx, lut, 12, post32=True, fused=False), {})}
 KNOBS = ("SKM_COSINE_OVERLAP",)
 
 
