@@ -175,6 +175,69 @@ def load_pmc_traffic():
     return rec.get("k_cosine_write_bytes_per_launch"), rec.get("note", "rocprofv3 --pmc, separate passes")
 
 
+def pmc_child(args, seed):
+    """Body of one rocprofv3 --pmc pass (see live_pmc_traffic): the bench workload, one warm-up and two steps."""
+    from snekmer_amd import _hip, alphabet, engine
+    from snekmer_amd.synth import synth_families
+
+    if "red6" not in alphabet.ALPHABETS:
+        alphabet.register_alphabet("red6", alphabet.RED6_GROUPS)
+    ctx = _hip.Context(0)
+    res, off, _ = synth_families(args.n, args.length, family=100, seed=seed)
+    batch = engine.SeqBatch(ctx, res, off)
+    pipe = engine.Pipeline(ctx, alphabet.build_lut(args.alphabet), args.k)
+    for _ in range(3):
+        pipe.step(batch)
+    ctx.sync()
+
+
+def live_pmc_traffic(args, budget_s=150.0):
+    """HBM bytes per launch of the dominant kernel, measured in THIS run: two child processes of this script under
+    `rocprofv3 --pmc WRITE_SIZE` and `rocprofv3 --pmc FETCH_SIZE` (separate passes, as MI355X_MICROARCH.md
+    prescribes; values are KiB per dispatch, FETCH_SIZE doubled for gfx950's wide streaming reads).  Called before
+    this process touches the GPU; rocprofv3 launches python3 directly.  Returns (bytes or None, note)."""
+    import csv
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    t0 = time.perf_counter()
+    got = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for counter in ("WRITE_SIZE", "FETCH_SIZE"):
+            left = budget_s - (time.perf_counter() - t0)
+            if left < 20:
+                return None, "live PMC passes ran out of their time budget"
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "-o", "p", "--",
+                   "python3", os.path.abspath(__file__), "--pmc-child", "--n", str(args.n), "--length", str(args.length),
+                   "--k", str(args.k), "--alphabet", args.alphabet]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=left)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} pass timed out"
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed: {r.stderr.decode(errors='replace')[-200:]}"
+            vals = []
+            for root, _, files in os.walk(os.path.join(tmp, counter)):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        with open(os.path.join(root, f)) as fh:
+                            for row in csv.DictReader(fh):
+                                if row["Counter_Name"] == counter and re.search(r"\bk_cosine_write\b", row["Kernel_Name"]):
+                                    vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"rocprofv3 --pmc {counter}: no k_cosine_write dispatch in the output"
+            got[counter] = (sum(vals) / len(vals) * 1024.0, len(vals))
+    w, f = got["WRITE_SIZE"], got["FETCH_SIZE"]
+    return w[0] + 2.0 * f[0], (f"measured in this run: rocprofv3 --pmc WRITE_SIZE ({w[0] / 1e9:.2f} GB/launch, {w[1]} launches) and "
+                               f"--pmc FETCH_SIZE (2 x {f[0] / 1e9:.3f} GB), separate child passes, {time.perf_counter() - t0:.0f} s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,7 +253,10 @@ def main():
     ap.add_argument("--cpu-sparse-n", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip config 2 / config 5 / MFMA / host-to-result extras")
+    ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from profiles/pmc_traffic.json instead of two "
+                    "rocprofv3 --pmc child passes in this run")
     ap.add_argument("--cpu-point", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     from snekmer_amd.synth import BASE_SEED
@@ -198,6 +264,9 @@ def main():
     seed = BASE_SEED + 2
     if args.cpu_point:
         cpu_point_child(args.cpu_point, args.k, args.alphabet, seed)
+        return
+    if args.pmc_child:
+        pmc_child(args, seed)
         return
 
     real_stdout = reserve_stdout()
@@ -214,6 +283,13 @@ def main():
 
     if "red6" not in alphabet.ALPHABETS:
         alphabet.register_alphabet("red6", alphabet.RED6_GROUPS)
+
+    # roofline.traffic: PMC passes as child processes, before this process opens the device
+    live_traffic = None
+    under_profiler = any("rocprof" in os.environ.get(v, "") for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+    if (world == 1 and rank == 0 and not args.no_live_pmc and not under_profiler
+            and os.environ.get("SKM_BENCH_FORCE_SHARDED") != "1"):
+        live_traffic = live_pmc_traffic(args)
 
     # SKM_BENCH_FORCE_SHARDED=1 runs the multi-GPU code path (gloo control plane, RCCL exchange,
     # ShardedPipeline) even with one rank, so that a 1-GPU box can exercise it.
@@ -295,7 +371,9 @@ def main():
         # (One launch per step; written so that it stays right if a step ever splits the launch.)
         algo_bytes = rows_local * ld * 4 * args.steps / max(launches, 1)
         achieved = algo_bytes / (strip_avg_ms * 1e-3) / 1e9 if strip_avg_ms > 0 else 0.0
-        traffic, traffic_note = load_pmc_traffic()
+        traffic, traffic_note = live_traffic if live_traffic and live_traffic[0] else load_pmc_traffic()
+        if live_traffic and not live_traffic[0]:
+            traffic_note = f"{traffic_note} (live pass: {live_traffic[1]})"
         line = {
             "metric": "sequences/sec vectorize+pairwise-cosine, 100k x 300aa k=12",
             "value": n_total / (elapsed / args.steps),
@@ -364,12 +442,16 @@ def stage_rooflines(ctx, engine, args, pipe, prof, residues_total):
     kb = engine.key_bits(pipe.lut.nsym, pipe.k)
     passes = min((kb + 8) // 9, (kb + 7) // 8)  # 9-bit digits whenever they save a pass (skm_sort.h)
     ld = (n + 3) // 4 * 4
+    fused = getattr(pipe, "fused", False)
     table = [
         ("k_count_short", residues_total + nnz * (code_b + 4), "1 B/residue read + (code,count) per distinct k-mer written"),
-        ("k_compact_rows", nnz * 2 * (code_b + 4), "padded rows -> tight CSR: read + write every entry"),
+        ("k_compact_rows", nnz * 2 * (code_b + 4) + (nnz * 8 if fused else 0),
+         "padded rows -> tight CSR: read + write every entry" + (" + the 8-byte posting word of every entry" if fused else "")),
         ("rocprim_radix_sort_codes", nnz * passes * 2 * (code_b + 4), f"{passes} Onesweep passes x (key + index payload) read + written"),
-        ("k_basis_scatter", nnz * (code_b + 8) + shared * 20 + b.ncols * (code_b + 4),
-         "sorted keys/indices/column ids read; per shared entry: posting word gathered, colidx + posting written; per column: code + start"),
+        ("k_head_count", nnz * code_b, "sorted keys read once"),
+        ("k_basis_scatter", nnz * (code_b + (4 if fused else 8)) + shared * 20 + b.ncols * (code_b + 4),
+         "sorted keys/indices" + ("" if fused else "/column ids") + " read; per shared entry: posting word gathered, colidx + posting "
+         "written; per column: code + start"),
         ("k_gram_sparse", pairs * 8, "every (row, posting) pair reads one 8-byte posting: sum over shared columns of df^2"),
         ("k_cosine_write", n * ld * 4, "the float32 result"),
     ]
@@ -407,6 +489,22 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
         del b2
     line["host_to_result_ms"] = {"value": min(times), "what": "H2D of residues + offsets (pageable host memory) + one step, result left in HBM",
                                  "h2d_bytes": int(res.nbytes + off.nbytes)}
+
+    # the opt-in two-stream schedule of skm_cosine_csr (neighbour lists of block b+1 built while block b is written):
+    # faster as a whole, but both kernels slow each other down, so the per-kernel rooflines above are taken without it
+    os.environ["SKM_COSINE_OVERLAP"] = "1"
+    try:
+        pipe.step(batch)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            pipe.step(batch)
+        ctx.sync()
+        ov_ms = (time.perf_counter() - t1) / 5 * 1e3
+    finally:
+        os.environ.pop("SKM_COSINE_OVERLAP", None)
+    line["overlap_schedule"] = {"ms_per_step": ov_ms, "sequences_per_s": n_total / (ov_ms * 1e-3),
+                                "what": "SKM_COSINE_OVERLAP=1: same step, Gram and writer kernels on two CU-partitioned streams"}
 
     if args.alphabet == "red6":
         # red6 is a benchmark alphabet; the nearest reference alphabet (`standard`,

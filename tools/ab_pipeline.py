@@ -18,7 +18,9 @@ batch = engine.SeqBatch(ctx, res, off)
 variants = {"three calls": (engine.Pipeline(ctx, lut, 12, fused=False), {}),
             "fused vectorize": (engine.Pipeline(ctx, lut, 12, fused=True), {}),
             "fused + overlap": (engine.Pipeline(ctx, lut, 12, fused=True), {"SKM_COSINE_OVERLAP": "1"}),
-            "three calls, post32": (engine.Pipeline(ctx, lut, 12, post32=True, fused=False), {})}
+            "three calls, post32": (engine.Pipeline(ctx, lut, 12, post32=True, fused=False), {}),
+            "three calls + overlap": (engine.Pipeline(ctx, lut, 12, fused=False), {"SKM_COSINE_OVERLAP": "1"}),
+            "three calls, post32 + overlap": (engine.Pipeline(ctx, lut, 12, post32=True, fused=False), {"SKM_COSINE_OVERLAP": "1"})}
 KNOBS = ("SKM_COSINE_OVERLAP",)
 
 
