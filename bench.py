@@ -140,6 +140,15 @@ def cpu_baseline(alphabet_name, k, seed, points, budget_s, n_sparse):
     }
 
 
+_T0 = time.perf_counter()
+
+
+def note(msg: str) -> None:
+    """Progress on stderr (stdout carries the one JSON line)."""
+    sys.stderr.write(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}\n")
+    sys.stderr.flush()
+
+
 def reserve_stdout() -> int:
     """gloo and RCCL print banners on stdout (RCCL through C stdio, flushed as late as process
     exit); stdout is reserved for the one JSON line.  Point fd 1 at stderr for the whole run and
@@ -289,7 +298,9 @@ def main():
     under_profiler = any("rocprof" in os.environ.get(v, "") for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
     if (world == 1 and rank == 0 and not args.no_live_pmc and not under_profiler
             and os.environ.get("SKM_BENCH_FORCE_SHARDED") != "1"):
+        note("rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE child passes")
         live_traffic = live_pmc_traffic(args)
+        note(f"PMC traffic: {live_traffic[1]}")
 
     # SKM_BENCH_FORCE_SHARDED=1 runs the multi-GPU code path (gloo control plane, RCCL exchange,
     # ShardedPipeline) even with one rank, so that a 1-GPU box can exercise it.
@@ -339,6 +350,7 @@ def main():
             dist.barrier()
         ctx.sync()
 
+    note(f"input resident ({n_total} sequences, {residues_total} residues); warm-up")
     for _ in range(args.warmup):
         step()
     barrier()
@@ -352,6 +364,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_dump()
     ctx.profile_enable(False)
+    note(f"timed region: {elapsed / args.steps * 1e3:.3f} ms/step on rank {rank}")
 
     if dist is not None:
         import torch
@@ -419,7 +432,9 @@ def main():
             extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
         if world == 1 and not args.no_cpu_baseline:
             pts = [int(x) for x in args.cpu_points.split(",") if x]
+            note(f"CPU baseline leg (bounded to {args.cpu_budget_s:.0f} s)")
             line["cpu_baseline"] = cpu_baseline(args.alphabet, args.k, seed, pts, args.cpu_budget_s, args.cpu_sparse_n)
+        note("done")
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
     if dist is not None:
@@ -487,6 +502,7 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
         ctx.sync()
         times.append((time.perf_counter() - t1) * 1e3)
         del b2
+    note("extras: host_to_result_ms")
     line["host_to_result_ms"] = {"value": min(times), "what": "H2D of residues + offsets (pageable host memory) + one step, result left in HBM",
                                  "h2d_bytes": int(res.nbytes + off.nbytes)}
 
@@ -503,6 +519,7 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
         ov_ms = (time.perf_counter() - t1) / 5 * 1e3
     finally:
         os.environ.pop("SKM_COSINE_OVERLAP", None)
+    note("extras: overlap_schedule")
     line["overlap_schedule"] = {"ms_per_step": ov_ms, "sequences_per_s": n_total / (ov_ms * 1e-3),
                                 "what": "SKM_COSINE_OVERLAP=1: same step, Gram and writer kernels on two CU-partitioned streams"}
 
@@ -519,6 +536,7 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
             pipe7.step(batch)
         ctx.sync()
         dt7 = (time.perf_counter() - t1) / 3
+        note("extras: reference_alphabet_check")
         line["reference_alphabet_check"] = {
             "alphabet": "standard", "k": args.k, "code_bits": 64, "ms_per_step": dt7 * 1e3,
             "sequences_per_s": n_total / dt7, "nnz": pipe7.csr.nnz, "basis_columns": pipe7.basis.ncols,
@@ -538,6 +556,7 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
         p2.step(b2)
     ctx.sync()
     dt2 = (time.perf_counter() - t1) / 50
+    note("extras: config2")
     line["config2"] = {"workload": f"BASELINE configs[1]: 10000 x {args.length}aa, {args.alphabet} k={args.k}",
                        "ms_per_step": dt2 * 1e3, "sequences_per_s": 10000 / dt2}
     del p2, b2
@@ -565,6 +584,7 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
     ms_fill = p5["memset_count_dense"][1] / reps
     ms_sc = p5["k_count_dense"][1] / reps
     bytes5 = int(res5.size + cells * 2 + windows * 4)  # N*L + N*B*2 (zero fill) + N*W*2*2 (RMW)
+    note("extras: config5_count_dense")
     line["config5_count_dense"] = {
         "workload": f"BASELINE configs[4]: {n5} x {args.length}aa, hydro k=20, dense uint16 [{n5} x {dense.shape[1]}]",
         "matrix_bytes": int(cells * 2), "windows": windows, "memset_ms": ms_fill, "k_count_dense_ms": ms_sc,
@@ -602,6 +622,7 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
     ops_full = 2.0 * nm * nm * dp.kdim
     nt = -(-nm // 256)
     ops_sym = (nt * (nt + 1) // 2) * 2.0 * 256 * 256 * dp.kdim  # MFMA work the symmetric launch executes
+    note("extras: dense_mfma")
     line["dense_mfma"] = {
         "shape": f"N = M = {nm}, K = {dp.kdim} (hydro k=14 full basis), int8 x int8 -> int32 -> float32",
         "kernel": "k_cosine_dense_i8_v4 (v_mfma_i32_32x32x32_i8, 256x256 tile, staggered wave groups)",

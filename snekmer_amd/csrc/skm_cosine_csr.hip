@@ -940,6 +940,8 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
                 SKM_GRAM(2);
             else if (gabl == 4)
                 SKM_GRAM(4);
+            else if (gabl == 5)
+                SKM_GRAM(5);
             else if (gabl == 3) {  // phase stamps (exact results, slower): read with skm_debug_gram_phases
                 unsigned long long zeros[8] = {};
                 SKM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gram_phase_ticks), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice, st));

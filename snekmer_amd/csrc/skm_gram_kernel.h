@@ -185,6 +185,8 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
         if (col[q] != G_SINGLETON) {
             pb[q] = ycolptr[col[q]];
             pe[q] = ycolptr[col[q] + 1];
+            if (GABL == 5)  // diagnostic: half of every list (the visit count of a symmetric half-Gram)
+                pb[q] += (pe[q] - pb[q] + 1) / 2;
         }
     }
     // Lists are binned by length so that every bin gets lane groups of a fitting width (a list

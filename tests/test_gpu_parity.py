@@ -1524,3 +1524,31 @@ def test_fused_vectorize_equals_the_three_call_form(ctx, name, k):
     # the sentinel fill past the entry count (what lets the sort run without knowing it)
     tail = b.csr.codes.download(batch.total + 1 - nnz, offset=nnz)
     assert (tail == np.iinfo(tail.dtype).max).all()
+
+
+@pytest.mark.parametrize("seqs", [["MKV", "", "XXXXXXXXXXXXXXXXXXXX", "*"], ["MKVLAAGIWSTCMKVLAAGIWSTC"],
+                                  ["MKVLAAGIWSTCDE", "MKVLAAGIWSTCDE", "XX"]])
+def test_fused_vectorize_degenerate_batches(ctx, seqs):
+    """No k-mer at all (every size counter stays 0 on the device), a single row, duplicate rows: the fused call
+    against the oracle's CSR, and the cosine step on top of it against the three-call form."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.utils import pack_sequences
+
+    O = _oracle()
+    lut = A.build_lut("standard")
+    k = 12
+    res, off = pack_sequences(seqs)
+    batch = engine.SeqBatch(ctx, res, off)
+    b = engine.Pipeline(ctx, lut, k, fused=True)
+    Sb = b.step(batch)
+    Sb = Sb.download().reshape(Sb.shape)[: batch.n, : batch.n].copy()
+    a = engine.Pipeline(ctx, lut, k, fused=False)
+    Sa = a.step(batch)
+    Sa = Sa.download().reshape(Sa.shape)[: batch.n, : batch.n]
+    assert (Sa == Sb).all()
+    rp, codes, counts, _ = O.count_csr(lut.rank, lut.nsym, k, res, off)
+    assert b.csr.nnz == len(codes) and (b.csr.rowptr.download(batch.n + 1) == rp).all()
+    if len(codes):
+        assert (b.csr.codes.download(len(codes)) == codes).all() and (b.csr.counts.download(len(codes)) == counts).all()
+    assert b.basis.ncols == len(np.unique(codes))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic timings of the cosine stage on one MI355X (interleaved rounds in one process).
 
-  SKM_GRAM_ABLATE   1 no pair loop   2 no emit   4 loads but no hash insert
+  SKM_GRAM_ABLATE   1 no pair loop   2 no emit   4 loads but no hash insert   5 second half of every list only
                     3 exact kernel with shader-clock stamps per phase
   SKM_COSINE_ABLATE (cursor kernel) 1 no accumulate   2 no global stores   3 plain (not nt) stores
   SKM_COSINE_PATH=cursor  the general fallback kernel for every strip
@@ -37,6 +37,7 @@ cases = [
     ("gram: no pair loop", {"SKM_GRAM_ABLATE": "1"}),
     ("gram: no emit", {"SKM_GRAM_ABLATE": "2"}),
     ("gram: no hash insert", {"SKM_GRAM_ABLATE": "4"}),
+    ("gram: half of every list", {"SKM_GRAM_ABLATE": "5"}),
     ("cursor kernel everywhere", {"SKM_COSINE_PATH": "cursor"}),
     ("cursor: no accumulate", {"SKM_COSINE_ABLATE": "1"}),
     ("cursor: no stores", {"SKM_COSINE_ABLATE": "2"}),
