@@ -912,6 +912,10 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     if (gabl == 0 && ov_env && atoi(ov_env) == 1 && nrows >= 4096 && (double)nrows * (double)ld * 4.0 >= 2e9 &&
         overlap_streams(ctx) == SKM_OK)
         nblk = 8;
+#ifdef SKM_DIAG
+    if (nblk > 1 && getenv("SKM_OVERLAP_BLOCKS"))  // diagnostic: block count of the overlapped schedule (2..16)
+        nblk = max(2, min(16, atoi(getenv("SKM_OVERLAP_BLOCKS"))));
+#endif
     const int64_t brows = skm_ceil_div(skm_ceil_div(nrows, nblk), 8) * 8;  // whole cursor strips per block
     hipStream_t s_g = nblk > 1 ? ctx->s_gram : st, s_w = nblk > 1 ? ctx->s_writer : st;
     if (nblk > 1) {

@@ -49,7 +49,9 @@ out = {
              "half of wide streaming reads; for the random 8-byte reads of k_gram_sparse and k_basis_scatter the factor is "
              "uncalibrated: raw and doubled values both given)",
 }
-for k in ("k_cosine_write", "k_gram_sparse", "k_basis_scatter"):
+for k in ("k_cosine_write", "k_gram_sparse", "k_basis_scatter", "k_basis_scatter_fused", "k_compact_rows", "k_head_count", "k_count_short"):
+    if k not in w or k not in f:
+        continue
     out[k] = {"WRITE_SIZE_KiB": w[k][0], "FETCH_SIZE_KiB_raw": f[k][0], "launches_sampled": w[k][1], "write_bytes": w[k][0] * 1024,
               "fetch_bytes_raw": f[k][0] * 1024, "fetch_bytes_doubled": 2 * f[k][0] * 1024}
 out["k_cosine_write_bytes_per_launch"] = out["k_cosine_write"]["write_bytes"] + out["k_cosine_write"]["fetch_bytes_doubled"]
