@@ -938,6 +938,23 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
         d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0 + b0, row0 + b1, SLOT, b0, g_ent, cap_ent, \
         g_counter, g_start + b0, g_len + b0, b_over_list, b_over_count)
 #ifdef SKM_DIAG
+            // diagnostic: other lane-group shapes for the lists of 17+ postings (exact results)
+#define SKM_GRAM_SHAPE(GG, UU)                                                                                       \
+    k_gram_sparse<0, 1, 2048, 256, 2, GG, UU, PW><<<(unsigned)bn, 256, 0, gs>>>(                                     \
+        d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0 + b0, row0 + b1, SLOT, b0, g_ent, cap_ent, \
+        g_counter, g_start + b0, g_len + b0, b_over_list, b_over_count)
+            const char *shape_env = getenv("SKM_GRAM_SHAPE");
+            const int shape = shape_env ? atoi(shape_env) : 0;
+            if (gabl == 0 && shape == 1)
+                SKM_GRAM_SHAPE(16, 2);
+            else if (gabl == 0 && shape == 2)
+                SKM_GRAM_SHAPE(16, 1);
+            else if (gabl == 0 && shape == 3)
+                SKM_GRAM_SHAPE(32, 1);
+            else if (gabl == 0 && shape == 4)
+                SKM_GRAM_SHAPE(64, 1);
+            else
+#undef SKM_GRAM_SHAPE
             if (gabl == 1)
                 SKM_GRAM(1);
             else if (gabl == 2)
@@ -946,6 +963,12 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
                 SKM_GRAM(4);
             else if (gabl == 5)
                 SKM_GRAM(5);
+            else if (gabl == 6)
+                SKM_GRAM(6);
+            else if (gabl == 7)
+                SKM_GRAM(7);
+            else if (gabl == 8)
+                SKM_GRAM(8);
             else if (gabl == 3) {  // phase stamps (exact results, slower): read with skm_debug_gram_phases
                 unsigned long long zeros[8] = {};
                 SKM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gram_phase_ticks), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice, st));

@@ -379,11 +379,12 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
             const uint32_t lv = t_liv[tl];
             walk_all(t_start[tl], t_df[tl], (int)(lv & 0x0FFFFFFFu), (int)(lv >> 28));
         }
-        if (boff[3] > boff[2])
+        // GABL 6 / 7 / 8 (diagnostic): without the long / middle / short bin
+        if (boff[3] > boff[2] && GABL != 6)
             run_bin(std::integral_constant<int, G>{}, std::integral_constant<int, U>{}, (int)boff[2], (int)boff[3]);
-        if (boff[2] > boff[1])
+        if (boff[2] > boff[1] && GABL != 7)
             run_bin(std::integral_constant<int, B1>{}, std::integral_constant<int, 1>{}, (int)boff[1], (int)boff[2]);
-        if (boff[1] > boff[0])
+        if (boff[1] > boff[0] && GABL != 8)
             run_bin(std::integral_constant<int, B0>{}, std::integral_constant<int, 1>{}, (int)boff[0], (int)boff[1]);
     }
     if (GABL != 1 && GABL != 4)

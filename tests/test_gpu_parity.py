@@ -1481,11 +1481,13 @@ def test_config4_one_rank_share_125k_rows_vs_1m(ctx):
 
 
 # ------------------------------------------------------------------ fused vectorize (no host synchronisation)
-@pytest.mark.parametrize("name,k", [("red6", 12), ("standard", 12), ("hydro", 20), ("hydro", 3)])
+@pytest.mark.parametrize("name,k", [("red6", 12), ("standard", 12), ("hydro", 20), ("hydro", 3), ("hydro", 32)])
 def test_fused_vectorize_equals_the_three_call_form(ctx, name, k):
     """skm_vectorize_csr (count + basis/postings + norms in one call, sizes left on the device) against
     skm_count_csr + skm_basis_build + skm_row_norms_csr: every output array identical, and the cosine matrix with it;
-    all size classes (long sequences take the LDS-block and global-scratch count kernels), both code widths."""
+    all size classes (long sequences take the LDS-block and global-scratch count kernels), both code widths.
+    hydro k=32: the k-mer of 32 V's has the all-ones 32-bit code, the same word as the tail fill the sort runs over;
+    hydro k=3 / k=20: the same in the key bits the sort looks at (the stable sort keeps entries in front of the tail)."""
     from snekmer_amd import alphabet as A
     from snekmer_amd import engine
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic timings of the cosine stage on one MI355X (interleaved rounds in one process).
 
-  SKM_GRAM_ABLATE   1 no pair loop   2 no emit   4 loads but no hash insert   5 second half of every list only
+  SKM_GRAM_ABLATE   1 no pair loop   2 no emit   4 loads but no hash insert   5 second half of every list only   6/7/8 without the bin of lists of 17+ / 5-16 / 1-4 postings
                     3 exact kernel with shader-clock stamps per phase
   SKM_COSINE_ABLATE (cursor kernel) 1 no accumulate   2 no global stores   3 plain (not nt) stores
   SKM_COSINE_PATH=cursor  the general fallback kernel for every strip
@@ -21,7 +21,7 @@ if not os.path.exists(_hip.LIB_PATH):
     sys.exit("build the diagnostic library first: make -C snekmer_amd/csrc diag")
 from snekmer_amd.synth import BASE_SEED, synth_families
 
-KNOBS = ("SKM_GRAM_ABLATE", "SKM_COSINE_ABLATE", "SKM_COSINE_PATH")
+KNOBS = ("SKM_GRAM_ABLATE", "SKM_COSINE_ABLATE", "SKM_COSINE_PATH", "SKM_GRAM_SHAPE")
 alphabet.register_alphabet("red6", alphabet.RED6_GROUPS)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 ctx = _hip.Context(0)
@@ -38,6 +38,13 @@ cases = [
     ("gram: no emit", {"SKM_GRAM_ABLATE": "2"}),
     ("gram: no hash insert", {"SKM_GRAM_ABLATE": "4"}),
     ("gram: half of every list", {"SKM_GRAM_ABLATE": "5"}),
+    ("gram: no lists of 17+", {"SKM_GRAM_ABLATE": "6"}),
+    ("gram: no lists of 5-16", {"SKM_GRAM_ABLATE": "7"}),
+    ("gram: no lists of 1-4", {"SKM_GRAM_ABLATE": "8"}),
+    ("gram shape 16x2 (exact)", {"SKM_GRAM_SHAPE": "1"}),
+    ("gram shape 16x1 (exact)", {"SKM_GRAM_SHAPE": "2"}),
+    ("gram shape 32x1 (exact)", {"SKM_GRAM_SHAPE": "3"}),
+    ("gram shape 64x1 (exact)", {"SKM_GRAM_SHAPE": "4"}),
     ("cursor kernel everywhere", {"SKM_COSINE_PATH": "cursor"}),
     ("cursor: no accumulate", {"SKM_COSINE_ABLATE": "1"}),
     ("cursor: no stores", {"SKM_COSINE_ABLATE": "2"}),
