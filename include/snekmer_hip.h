@@ -60,6 +60,11 @@ int skm_device_info(skm_ctx *ctx, char *h_name, int name_cap, int *h_cus, int64_
 /* ---- device memory ----------------------------------------------------------------------- */
 int skm_malloc(skm_ctx *ctx, size_t bytes, void **out_dptr);
 int skm_free(skm_ctx *ctx, void *dptr);
+/* Pinned host memory that kernels of this context's device can read and write at the same address (zero-copy,
+ * coherent): the staging of the per-record API, where a launch + skm_sync beats two explicit copies.  The pointer
+ * may be passed wherever a d_* argument is expected. */
+int skm_host_alloc(skm_ctx *ctx, size_t bytes, void **out_hptr);
+int skm_host_free(skm_ctx *ctx, void *hptr);
 int skm_memcpy_h2d(skm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* host-sync */
 int skm_memcpy_d2h(skm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* host-sync */
 int skm_memcpy_d2d(skm_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);

@@ -52,6 +52,8 @@ _SIGNATURES = {
     "skm_device_info": (C.c_int, [_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_i64)]),
     "skm_malloc": (C.c_int, [_p, C.c_size_t, C.POINTER(_p)]),
     "skm_free": (C.c_int, [_p, _p]),
+    "skm_host_alloc": (C.c_int, [_p, C.c_size_t, C.POINTER(_p)]),
+    "skm_host_free": (C.c_int, [_p, _p]),
     "skm_memcpy_h2d": (C.c_int, [_p, _p, _p, C.c_size_t]),
     "skm_memcpy_d2h": (C.c_int, [_p, _p, _p, C.c_size_t]),
     "skm_memcpy_d2d": (C.c_int, [_p, _p, _p, C.c_size_t]),
@@ -218,6 +220,8 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None) is not None:
+            for ptr in self.__dict__.pop("_pinned", []):
+                self.lib.skm_host_free(self.handle, _p(ptr))
             self.lib.skm_destroy(self.handle)
             self.handle = None
 
@@ -235,6 +239,14 @@ class Context:
 
     def _free(self, ptr: int):
         self.lib.skm_free(self.handle, _p(ptr))
+
+    def host_alloc(self, nbytes: int) -> np.ndarray:
+        """Pinned, device-addressable host bytes (skm_host_alloc) as a uint8 array; `arr.ctypes.data` is valid as a
+        device pointer.  Lives as long as the context (freed in close())."""
+        out = _p()
+        _check(self.lib, self.lib.skm_host_alloc(self.handle, C.c_size_t(nbytes), C.byref(out)))
+        self.__dict__.setdefault("_pinned", []).append(out.value)
+        return np.ctypeslib.as_array(C.cast(out.value, C.POINTER(C.c_uint8)), shape=(max(nbytes, 1),))[:nbytes]
 
     def _h2d(self, dptr: int, host: np.ndarray):
         _check(self.lib, self.lib.skm_memcpy_h2d(self.handle, _p(dptr), host.ctypes.data_as(_p), host.nbytes))

@@ -131,6 +131,39 @@ extern "C" int skm_free(skm_ctx *ctx, void *dptr)
     return SKM_OK;
 }
 
+extern "C" int skm_host_alloc(skm_ctx *ctx, size_t bytes, void **out_hptr)
+{
+    SKM_REQUIRE(ctx && out_hptr, SKM_E_BADARG, "skm_host_alloc: null argument");
+    *out_hptr = nullptr;
+    SKM_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(out_hptr, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        skm_set_error("hipHostMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+        return SKM_E_NOMEM;
+    }
+    void *dev = nullptr;
+    e = hipHostGetDevicePointer(&dev, *out_hptr, 0);
+    if (e != hipSuccess || dev != *out_hptr) {  // the callers rely on one address for both sides
+        (void)hipGetLastError();
+        (void)hipHostFree(*out_hptr);
+        *out_hptr = nullptr;
+        skm_set_error("skm_host_alloc: pinned memory is not device-addressable at its host address");
+        return SKM_E_UNSUPPORTED;
+    }
+    return SKM_OK;
+}
+
+extern "C" int skm_host_free(skm_ctx *ctx, void *hptr)
+{
+    SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    if (hptr) {
+        SKM_HIP(hipSetDevice(ctx->device));
+        SKM_HIP(hipHostFree(hptr));
+    }
+    return SKM_OK;
+}
+
 extern "C" int skm_memcpy_h2d(skm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
 {
     SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");

@@ -158,16 +158,17 @@ ARENA_RECORDS = 4096
 
 
 class _Arena:
-    """Persistent device + host staging of the small-batch path: [offsets | residues] travel up in ONE copy,
-    [window counts | codes] come down in one."""
+    """Persistent staging of the small-batch path in pinned host memory that the device addresses directly
+    (skm_host_alloc): [offsets | residues] are written by the host and read by the kernels over PCIe, [window counts |
+    codes] are written by the kernels and read by the host.  A call is the launches plus one stream synchronise: no
+    allocation and no explicit copy."""
 
     def __init__(self, ctx):
         self.up_bytes = 8 * (ARENA_RECORDS + 1) + ARENA_RESIDUES + 64
-        self.d_up = ctx.zeros(self.up_bytes, np.uint8)
-        self.h_up = np.zeros(self.up_bytes, dtype=np.uint8)
-        self.down_bytes = 4 * ARENA_RECORDS + 8 * (ARENA_RESIDUES + 1)
-        self.d_down = ctx.empty(self.down_bytes, np.uint8)
-        self.h_down = np.zeros(self.down_bytes, dtype=np.uint8)
+        self.h_up = ctx.host_alloc(self.up_bytes)
+        self.down_bytes = 4 * ARENA_RECORDS + 8 * (ARENA_RESIDUES + 1) + 64
+        self.h_down = ctx.host_alloc(self.down_bytes)
+        self.up_ptr, self.down_ptr = self.h_up.ctypes.data, self.h_down.ctypes.data
 
 
 def recode_host(ctx, residues: np.ndarray, offsets: np.ndarray, lut: AlphabetLUT):
@@ -184,18 +185,17 @@ def recode_host(ctx, residues: np.ndarray, offsets: np.ndarray, lut: AlphabetLUT
     arena.h_up[:off_bytes] = np.ascontiguousarray(offsets, dtype=np.int64).view(np.uint8)
     arena.h_up[seq_at : seq_at + total] = residues
     arena.h_up[seq_at + total : seq_at + total + 16] = 0
-    ctx._h2d(arena.d_up.ptr, arena.h_up[: seq_at + total + 16])
     len_bytes = (4 * n + 15) // 16 * 16
-    ctx.call("skm_recode", _ptr(lut.translate), _p(arena.d_up.ptr + seq_at), _p(arena.d_up.ptr), _i64(n),
-             _p(arena.d_down.ptr + len_bytes), _p(arena.d_down.ptr))
+    ctx.call("skm_recode", _ptr(lut.translate), _p(arena.up_ptr + seq_at), _p(arena.up_ptr), _i64(n),
+             _p(arena.down_ptr + len_bytes), _p(arena.down_ptr))
+    ctx.sync()
     got = arena.h_down[: len_bytes + total]
-    ctx._d2h(got, arena.d_down.ptr)
     return got[len_bytes : len_bytes + total].copy(), got[: 4 * n].view(np.int32).copy()
 
 
 def kmer_codes_host(ctx, residues: np.ndarray, offsets: np.ndarray, lut: AlphabetLUT, k: int):
     """a5/a6 from host arrays to host arrays: (codes per window slot, windows per sequence, code_bits).
-    Small inputs use the context's arena (no allocation, two copies in all); larger ones the general path."""
+    Small inputs use the context's arena (pinned zero-copy staging: no allocation, no copy call); larger ones the general path."""
     n, total = int(offsets.size - 1), int(residues.size)
     if n > ARENA_RECORDS or total > ARENA_RESIDUES or n == 0:
         batch = SeqBatch(ctx, residues, offsets)
@@ -210,14 +210,12 @@ def kmer_codes_host(ctx, residues: np.ndarray, offsets: np.ndarray, lut: Alphabe
     arena.h_up[:off_bytes] = np.ascontiguousarray(offsets, dtype=np.int64).view(np.uint8)
     arena.h_up[seq_at : seq_at + total] = residues
     arena.h_up[seq_at + total : seq_at + total + 16] = 0
-    ctx._h2d(arena.d_up.ptr, arena.h_up[: seq_at + total + 16])
     nwin_bytes = (4 * n + 15) // 16 * 16
-    d_nwin, d_codes = arena.d_down.ptr, arena.d_down.ptr + nwin_bytes
-    ctx.call("skm_kmer_codes", _ptr(lut.rank), lut.nsym, k, bits, _p(arena.d_up.ptr + seq_at), _p(arena.d_up.ptr), _i64(n),
+    d_nwin, d_codes = arena.down_ptr, arena.down_ptr + nwin_bytes
+    ctx.call("skm_kmer_codes", _ptr(lut.rank), lut.nsym, k, bits, _p(arena.up_ptr + seq_at), _p(arena.up_ptr), _i64(n),
              _p(d_codes), _p(d_nwin))
+    ctx.sync()
     got = arena.h_down[: nwin_bytes + cb * total]
-    if got.size:
-        ctx._d2h(got, arena.d_down.ptr)
     nwin = got[: 4 * n].view(np.int32).copy()
     codes = got[nwin_bytes : nwin_bytes + cb * total].view(np.uint32 if bits == 32 else np.uint64).copy()
     return codes, nwin, bits
