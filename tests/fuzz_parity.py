@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Randomised differential check of the HIP path against the oracle (test infrastructure; run by hand or by
+tests/test_gpu_parity.py::test_fuzz_short on a GPU box):  python tests/fuzz_parity.py [seconds] [first_seed]
+
+Every round draws an alphabet, a k, and a batch (family sequences with substitutions, junk characters, trailing
+stars, lowercase, empties, repeats, a few long records) and compares, bit for bit unless stated:
+  * skm_count_csr and skm_vectorize_csr (CSR, basis codes, column starts, column ids, row norms) with the C oracle;
+  * the N x N cosine by the neighbour-list path, by the cursor kernel and by the overlapped schedule with each other,
+    and with the oracle's float64 rows to 1e-5;
+  * neighbour lists (skm_gram_neighbors) with the oracle's exact integer Gram on sampled rows."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+AA = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+JUNK = np.frombuffer(b"XBZUO*-acgt.", dtype=np.uint8)
+
+
+def draw_batch(rng):
+    n_fam = int(rng.integers(1, 12))
+    seqs = []
+    for _ in range(n_fam):
+        L = int(rng.choice([rng.integers(0, 40), rng.integers(40, 700), rng.integers(700, 3000)], p=[0.1, 0.8, 0.1]))
+        if rng.random() < 0.03:
+            L = int(rng.integers(5000, 22000))
+        low = rng.random() < 0.15  # low-complexity family: few distinct residues, many repeated k-mers
+        root = AA[rng.integers(0, 3 if low else 20, size=L)]
+        for _ in range(int(rng.integers(1, 40))):
+            s = root.copy()
+            if L:
+                m = rng.random(L) < rng.choice([0.0, 0.02, 0.1, 0.3])
+                s[m] = AA[rng.integers(0, 20, size=int(m.sum()))]
+                if rng.random() < 0.2:
+                    j = rng.random(L) < 0.01
+                    s[j] = JUNK[rng.integers(0, len(JUNK), size=int(j.sum()))]
+            t = s.tobytes().decode()
+            if rng.random() < 0.1:
+                t += "*" * int(rng.integers(1, 3))
+            seqs.append(t)
+    order = rng.permutation(len(seqs))
+    return [seqs[i] for i in order]
+
+
+def one_round(ctx, seed, verbose=False):
+    from oracle import c_oracle as orc
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.utils import pack_sequences
+
+    rng = np.random.default_rng(seed)
+    names = ["hydro", "standard", "solvacc", "hydrocharge", "hydrostruct", "miqs", "ptm", "None", "red6"]
+    name = names[int(rng.integers(0, len(names)))]
+    lut = A.build_lut(None if name == "None" else name)
+    kmax = 1
+    while lut.nsym ** (kmax + 1) < 2**64 and kmax < 32:
+        kmax += 1
+    k = int(rng.integers(1, kmax + 1))
+    seqs = draw_batch(rng)
+    res, off = pack_sequences(seqs)
+    n = len(seqs)
+    tag = f"seed {seed}: {name} k={k} n={n} residues={len(res)}"
+    if verbose:
+        print(tag, flush=True)
+    batch = engine.SeqBatch(ctx, res, off)
+    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
+    nnz = len(o_codes)
+
+    def same(a, b, what):
+        a, b = np.asarray(a), np.asarray(b)
+        assert a.shape == b.shape and (a == b).all(), f"{tag}: {what} differs"
+
+    pipes = {"three": engine.Pipeline(ctx, lut, k, fused=False)}
+    if len(res) >= 1:
+        pipes["fused"] = engine.Pipeline(ctx, lut, k, fused=True)
+    S = {}
+    for key, p in pipes.items():
+        out = p.step(batch)
+        S[key] = out.download().reshape(out.shape)[:n, :n].copy()
+        same(p.csr.rowptr.download(n + 1), o_rowptr, f"{key} rowptr")
+        assert p.csr.nnz == nnz, f"{tag}: {key} nnz {p.csr.nnz} != {nnz}"
+        same(p.csr.codes.download(nnz).astype(np.uint64), o_codes, f"{key} codes")
+        same(p.csr.counts.download(nnz), o_counts, f"{key} counts")
+        assert p.basis.ncols == len(ob), f"{tag}: {key} ncols"
+        same(p.basis.codes.download(len(ob)).astype(np.uint64), ob, f"{key} basis")
+        cp = p.basis.colptr.download(len(ob) + 1).astype(np.int64)
+        same(np.diff(cp), odf, f"{key} df")
+        col = p.csr.colidx.download(nnz)
+        keep = col != 0xFFFFFFFF  # k-mers of one row only carry no column id in the cosine pipeline
+        same(col[keep], ocol[keep], f"{key} colidx")
+        assert (odf[ocol[~keep]] == 1).all(), f"{tag}: {key} elided a shared column"
+    if "fused" in S:
+        same(S["fused"], S["three"], "fused vs three-call cosine")
+    p = pipes["three"]
+    if n and nnz:
+        rows = np.arange(n) if n <= 400 else np.sort(rng.choice(n, 400, replace=False))
+        ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), rows)
+        err = float(np.abs(S["three"][rows] - ref).max())
+        assert err <= 1e-5, f"{tag}: cosine vs oracle {err}"
+        for env in ({"SKM_COSINE_PATH": "cursor"}, {"SKM_COSINE_PATH": "lists"}, {"SKM_COSINE_OVERLAP": "1", "SKM_COSINE_PATH": "lists"}):
+            saved = {kk: os.environ.get(kk) for kk in ("SKM_COSINE_PATH", "SKM_COSINE_OVERLAP")}
+            os.environ.update(env)
+            try:
+                alt = p.cosine().download().reshape(p.out.shape)[:n, :n]
+            finally:
+                for kk, vv in saved.items():
+                    if vv is None:
+                        os.environ.pop(kk, None)
+                    else:
+                        os.environ[kk] = vv
+            same(alt, S["three"], f"cosine under {env}")
+    return tag
+
+
+def main():
+    from snekmer_amd import _hip
+    from snekmer_amd import alphabet as A
+
+    if "red6" not in A.ALPHABETS:
+        A.register_alphabet("red6", A.RED6_GROUPS)
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    ctx = _hip.default_context()
+    t0 = time.perf_counter()
+    done = 0
+    while time.perf_counter() - t0 < budget:
+        one_round(ctx, seed, verbose=True)
+        seed += 1
+        done += 1
+    print(f"fuzz ok: {done} rounds in {time.perf_counter() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
