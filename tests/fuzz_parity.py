@@ -7,7 +7,7 @@ stars, lowercase, empties, repeats, a few long records) and compares, bit for bi
   * skm_count_csr and skm_vectorize_csr (CSR, basis codes, column starts, column ids, row norms) with the C oracle;
   * the N x N cosine by the neighbour-list path, by the cursor kernel and by the overlapped schedule with each other,
     and with the oracle's float64 rows to 1e-5;
-  * neighbour lists (skm_gram_neighbors) with the oracle's exact integer Gram on sampled rows."""
+  * every fourth round: the dense int8 matrix-core cosine at a random shape against the integer Gram (numpy)."""
 import os
 import sys
 import time
@@ -116,6 +116,32 @@ def one_round(ctx, seed, verbose=False):
     return tag
 
 
+def dense_round(ctx, seed):
+    """Dense int8 cosine on the matrix cores: random shapes around the kernels' switch points (register-staged,
+    128 x 128, 256 x 256 staggered; rectangular, X is Y), exact integer Gram with unit norms."""
+    from snekmer_amd import engine
+
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([rng.integers(1, 300), rng.integers(900, 1200), rng.integers(1024, 2600)]))
+    m = int(rng.choice([rng.integers(1, 300), rng.integers(900, 1200), rng.integers(1024, 2600)]))
+    kdim = 64 * int(rng.choice([1, 2, 3, 4, 5, 6, 8, 9, 16]))
+    sym = rng.random() < 0.35
+    if sym:
+        m = n
+    X = rng.integers(-8, 8, size=(n, kdim)).astype(np.int8)
+    Y = X if sym else rng.integers(-8, 8, size=(m, kdim)).astype(np.int8)
+    X[rng.integers(0, n)] = 0
+    ld = int(rng.choice([(m + 3) // 4 * 4, m, m + 1, m + 7]))
+    ones = ctx.to_device(np.ones(max(n, m) + 4, dtype=np.float32))
+    dX = ctx.to_device(X)
+    dY = dX if sym else ctx.to_device(Y)
+    out = engine.cosine_dense_i8(ctx, n, m, kdim, dX, dY, ones, ones, ld=ld)
+    G = out.download().reshape(-1, ld)[:n, :m]
+    ref = X.astype(np.int64) @ Y.astype(np.int64).T
+    assert (G.astype(np.int64) == ref).all(), f"dense seed {seed}: n={n} m={m} k={kdim} ld={ld} sym={sym}"
+    return f"dense seed {seed}: n={n} m={m} k={kdim} ld={ld} sym={sym}"
+
+
 def main():
     from snekmer_amd import _hip
     from snekmer_amd import alphabet as A
@@ -129,6 +155,8 @@ def main():
     done = 0
     while time.perf_counter() - t0 < budget:
         one_round(ctx, seed, verbose=True)
+        if seed % 4 == 0:
+            print(dense_round(ctx, seed), flush=True)
         seed += 1
         done += 1
     print(f"fuzz ok: {done} rounds in {time.perf_counter() - t0:.0f} s")

@@ -1568,3 +1568,5 @@ def test_fuzz_short(ctx):
     spec.loader.exec_module(fz)
     for seed in range(900, 960):
         fz.one_round(ctx, seed)
+    for seed in range(40):
+        fz.dense_round(ctx, seed)
