@@ -7,6 +7,7 @@ stars, lowercase, empties, repeats, a few long records) and compares, bit for bi
   * skm_count_csr and skm_vectorize_csr (CSR, basis codes, column starts, column ids, row norms) with the C oracle;
   * the N x N cosine by the neighbour-list path, by the cursor kernel and by the overlapped schedule with each other,
     and with the oracle's float64 rows to 1e-5;
+  * neighbour lists (skm_gram_neighbors) of a random row block: neighbour sets and exact integer dot products;
   * every fourth round: the dense int8 matrix-core cosine at a random shape against the integer Gram (numpy)."""
 import os
 import sys
@@ -20,8 +21,8 @@ AA = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
 JUNK = np.frombuffer(b"XBZUO*-acgt.", dtype=np.uint8)
 
 
-def draw_batch(rng):
-    n_fam = int(rng.integers(1, 12))
+def draw_batch(rng, big=False):
+    n_fam = int(rng.integers(20, 60)) if big else int(rng.integers(1, 12))
     seqs = []
     for _ in range(n_fam):
         L = int(rng.choice([rng.integers(0, 40), rng.integers(40, 700), rng.integers(700, 3000)], p=[0.1, 0.8, 0.1]))
@@ -29,7 +30,7 @@ def draw_batch(rng):
             L = int(rng.integers(5000, 22000))
         low = rng.random() < 0.15  # low-complexity family: few distinct residues, many repeated k-mers
         root = AA[rng.integers(0, 3 if low else 20, size=L)]
-        for _ in range(int(rng.integers(1, 40))):
+        for _ in range(int(rng.integers(20, 90)) if big else int(rng.integers(1, 40))):
             s = root.copy()
             if L:
                 m = rng.random(L) < rng.choice([0.0, 0.02, 0.1, 0.3])
@@ -59,7 +60,7 @@ def one_round(ctx, seed, verbose=False):
     while lut.nsym ** (kmax + 1) < 2**64 and kmax < 32:
         kmax += 1
     k = int(rng.integers(1, kmax + 1))
-    seqs = draw_batch(rng)
+    seqs = draw_batch(rng, big=seed % 16 == 7)  # every 16th round: thousands of rows (lists by default, overflow passes)
     res, off = pack_sequences(seqs)
     n = len(seqs)
     tag = f"seed {seed}: {name} k={k} n={n} residues={len(res)}"
@@ -113,6 +114,25 @@ def one_round(ctx, seed, verbose=False):
                     else:
                         os.environ[kk] = vv
             same(alt, S["three"], f"cosine under {env}")
+        # neighbour lists of a random row block: the same neighbour set and the exact integer dot products
+        lo = int(rng.integers(0, n))
+        hi = int(rng.integers(lo + 1, n + 1))
+        b = p.basis
+        nb = engine.gram_neighbors(ctx, p.csr, n, b.ncols, b.colptr, b.post, row0=lo, row1=hi, post_bits=b.post_bits, postcnt=b.postcnt)
+        start, length, jj, dot = nb.host()
+        nsq = np.add.reduceat(np.concatenate([o_counts.astype(np.float64) ** 2, [0.0]]), np.minimum(o_rowptr[:-1], nnz))
+        nsq[np.diff(o_rowptr) == 0] = 0.0
+        norms = np.sqrt(np.where(nsq > 0, nsq, 1.0))
+        full = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), np.arange(lo, hi))
+        for r in range(hi - lo):
+            if length[r] == 0xFFFFFFFF:
+                continue  # a row the list kernels cannot hold (the cosine path computes it with the cursor kernel)
+            js = jj[int(start[r]) : int(start[r]) + int(length[r])]
+            ds = dot[int(start[r]) : int(start[r]) + int(length[r])]
+            assert sorted(js.tolist()) == np.nonzero(full[r] > 0)[0].tolist(), f"{tag}: neighbour set of row {lo + r}"
+            if len(js):
+                gram = full[r, js] * norms[lo + r] * norms[js]
+                assert np.abs(ds - np.rint(gram)).max() == 0, f"{tag}: dot products of row {lo + r}"
     return tag
 
 
