@@ -395,6 +395,25 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v3(int64_t n, int64_t m
 
 
 
+// Row-major int8 [rows x kdim] -> the tiled image k_cosine_dense_i8_v4<.., TILED> stages from (see there).
+// One thread per 16 bytes; rows are padded with zeros to a multiple of 256.
+__global__ __launch_bounds__(256) void k_retile_i8(int64_t rows, int64_t kdim, const int8_t *__restrict__ in, int64_t nrb,
+                                                   int8_t *__restrict__ out)
+{
+    const int64_t nst = kdim / 64;
+    const int64_t total = nst * nrb * 64;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)(t & 63);
+        const int64_t piece = t >> 6, rb = piece % nrb, sidx = piece / nrb;
+        const int64_t r = rb * 16 + (l >> 2);
+        const int src_chunk = (l & 3) ^ (int)((r >> 2) & 3);
+        int4 v = make_int4(0, 0, 0, 0);
+        if (r < rows)
+            v = *reinterpret_cast<const int4 *>(in + r * kdim + sidx * 64 + src_chunk * 16);
+        *reinterpret_cast<int4 *>(out + t * 16) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------- i8 MFMA cosine, v4
 // The v3 tile (256 x 256, 8 waves of 128 x 64) with the K loop restructured so that the two waves that
 // share a SIMD never want the same pipe at the same time.  In v3 all eight waves issue their LDS-DMA
@@ -416,8 +435,13 @@ constexpr int BK4 = 64;
 constexpr int NSLOT4 = 4;
 constexpr int SLOT4_BYTES = (BM3 + BN3) * BK4;  // 32 KiB
 
+// TILED: the operands were re-laid out by k_retile_i8 so that the 16 rows x 64 B one LDS-DMA instruction lands are
+// 1 KiB of CONTIGUOUS global memory in exactly the LDS image (swizzle included), K stage major: piece (stage s, row
+// block rb) at ((s * nrb + rb) * 1024).  From row-major operands the same instruction touches 16 half lines (one
+// 64-byte L2 request each, 2.1e9 per launch at N = 32 768, K = 16 384: the kernel's bound, section 5.2 of
+// DESIGN.md); from the tiled image it reads 8 whole lines.  Rows past n / m are zero in the image (no clamping).
 // ABL (SKM_DIAG builds only; results invalid): 1 no staging inside the K loop, 2 fragments read once, 3 no MFMA
-template <int MODE, bool SYM, int ABL = 0>
+template <int MODE, bool SYM, int ABL = 0, bool TILED = false>
 __global__ __launch_bounds__(512) void k_cosine_dense_i8_v4(int64_t n, int64_t m, int64_t kdim,
                                                             const int8_t *__restrict__ X,
                                                             const int8_t *__restrict__ Y,
@@ -471,6 +495,20 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v4(int64_t n, int64_t m
     auto stage_piece = [&](int slot, int64_t k0, int p) {
         int8_t *sa = s_t + slot * SLOT4_BYTES, *sb = sa + BM3 * BK4;
         const int q = p >> 1;
+        if (TILED) {
+            const int64_t nrbx = (n + BM3 - 1) / BM3 * (BM3 / 16), nrby = (m + BN3 - 1) / BN3 * (BN3 / 16);
+            const int64_t sidx = k0 / BK4;
+            if ((p & 1) == 0) {
+                const int64_t rb = row0 / 16 + wid * 2 + q;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(X + ((sidx * nrbx + rb) * 64 + lane) * 16),
+                                                 (__attribute__((address_space(3))) void *)(sa + (wid * 32 + q * 16) * BK4), 16, 0, 0);
+            } else {
+                const int64_t rb = col0 / 16 + wid * 2 + q;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Y + ((sidx * nrby + rb) * 64 + lane) * 16),
+                                                 (__attribute__((address_space(3))) void *)(sb + (wid * 32 + q * 16) * BK4), 16, 0, 0);
+            }
+            return;
+        }
         const int r = wid * 32 + q * 16 + srow;
         const int src_chunk = schunk ^ ((r >> 2) & 3);
         if ((p & 1) == 0) {
@@ -809,8 +847,9 @@ extern "C" int skm_cosine_dense_i8(skm_ctx *ctx, int64_t n, int64_t m, int64_t k
     const bool v2 = kdim % BK2 == 0 && forced != 1;
     const bool v3 = v2 && forced != 2 && n >= 1024 && m >= 1024;
     // v4 (staggered wave groups, 64-byte K stages; symmetric form when X is Y): the default for large problems
-    const bool v4 = kdim % BK4 == 0 && kdim >= 4 * BK4 && n >= 1024 && m >= 1024 && (forced == 0 || forced == 4);
-    const bool sym = d_x == d_y && n == m && d_xrnorm == d_yrnorm && forced0 != 5;
+    // 6: v4 staging from tiled operand copies (the default), 7: the same without symmetry
+    const bool v4 = kdim % BK4 == 0 && kdim >= 4 * BK4 && n >= 1024 && m >= 1024 && (forced == 0 || forced == 4 || forced0 == 6 || forced0 == 7);
+    const bool sym = d_x == d_y && n == m && d_xrnorm == d_yrnorm && forced0 != 5 && forced0 != 7;
     SKM_PROF(ctx, "k_cosine_dense_i8");
     if (v4) {
         const int64_t nsy4 = skm_ceil_div(skm_ceil_div(n, BM3), 4), nsx4 = skm_ceil_div(skm_ceil_div(m, BN3), 8);
@@ -834,6 +873,36 @@ extern "C" int skm_cosine_dense_i8(skm_ctx *ctx, int64_t n, int64_t m, int64_t k
         if (dabl >= 1 && dabl <= 3)
             return skm_check_launch("k_cosine_dense_i8");
 #endif
+        // default: stage from a tiled copy of the operands (SKM_DENSE_VARIANT=4 / 5 keep the row-major form, for A/B)
+        if (forced0 == 0 || forced0 == 6 || forced0 == 7) {
+            const bool sym6 = sym;
+            const int64_t nrbx = skm_ceil_div(n, BM3) * (BM3 / 16), nrby = skm_ceil_div(m, BN3) * (BN3 / 16);
+            void *p;
+            SKM_TRY(skm_ws(ctx, WS_K, (size_t)nrbx * 16 * (size_t)kdim, &p));
+            int8_t *xt = (int8_t *)p, *yt = xt;
+            k_retile_i8<<<skm_grid_cap(ctx, skm_ceil_div(nrbx * 16 * kdim / 16, 256), 8), 256, 0, ctx->stream>>>(n, kdim, d_x, nrbx, xt);
+            if (!(d_x == d_y && n == m)) {
+                SKM_TRY(skm_ws(ctx, WS_L, (size_t)nrby * 16 * (size_t)kdim, &p));
+                yt = (int8_t *)p;
+                k_retile_i8<<<skm_grid_cap(ctx, skm_ceil_div(nrby * 16 * kdim / 16, 256), 8), 256, 0, ctx->stream>>>(m, kdim, d_y, nrby, yt);
+            }
+            SKM_TRY(skm_check_launch("k_retile_i8"));
+#define SKM_V4T(MODE, SYM) \
+    k_cosine_dense_i8_v4<MODE, SYM, 0, true><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, xt, yt, d_xrnorm, d_yrnorm, d_out, ld)
+            if (mode == 0) {
+                if (sym6)
+                    SKM_V4T(0, true);
+                else
+                    SKM_V4T(0, false);
+            } else {
+                if (sym6)
+                    SKM_V4T(1, true);
+                else
+                    SKM_V4T(1, false);
+            }
+#undef SKM_V4T
+            return skm_check_launch("k_cosine_dense_i8");
+        }
 #define SKM_V4(MODE, SYM) \
     k_cosine_dense_i8_v4<MODE, SYM><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld)
         if (mode == 0) {

@@ -15,7 +15,8 @@ k = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 32768
 lut = alphabet.build_lut(name)
 res, off, _ = synth_families(n, 300, family=100, seed=BASE_SEED + 6)
-variants = {"3 lock-step": "3", "5 staggered, full": "5", "4 staggered, symmetric": "4"}
+variants = {"3 lock-step": "3", "5 staggered, full": "5", "4 staggered, symmetric": "4",
+            "7 staggered, tiled operands, full": "7", "6 staggered, tiled operands, symmetric": "6"}
 ABL = {}
 if os.environ.get("SKM_AB_DIAG") == "1":  # needs libsnekmer_hip_diag.so (make diag); ablated runs give invalid results
     _hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "libsnekmer_hip_diag.so")
@@ -46,7 +47,7 @@ for rnd in range(5):
             sample = np.stack([out.download(n, offset=int(r) * ld) for r in (0, 1, 255, 256, 257, n // 2, n - 257, n - 1)])
             if ref is None:
                 ref = sample
-            elif vname.startswith("4"):
+            elif vname.startswith(("4", "6")):
                 # the mirrored half is (acc * r_i) * r_j instead of (acc * r_j) * r_i: one float32 rounding apart
                 d = float(np.abs(sample - ref).max())
                 assert d <= 2.5e-7, f"symmetric variant differs by {d}"
