@@ -8,6 +8,7 @@ stars, lowercase, empties, repeats, a few long records) and compares, bit for bi
   * the N x N cosine by the neighbour-list path, by the cursor kernel and by the overlapped schedule with each other,
     and with the oracle's float64 rows to 1e-5;
   * neighbour lists (skm_gram_neighbors) of a random row block: neighbour sets and exact integer dot products;
+  * every fourth round: the learn/apply chain (group sums, fused top-2 epilogue) against float64 numpy;
   * every fourth round: the dense int8 matrix-core cosine at a random shape against the integer Gram (numpy)."""
 import os
 import sys
@@ -136,6 +137,65 @@ def one_round(ctx, seed, verbose=False):
     return tag
 
 
+def apply_round(ctx, seed):
+    """Learn / apply chain on a random batch: per-annotation sums of count rows (skm_csr_group_sum) against a dense
+    numpy sum, and the fused top-2 epilogue (skm_apply_top2) against float64 numpy on the dense matrices: indices
+    (score desc, column asc), exact integer dots, scores to 1e-12."""
+    from oracle import c_oracle as orc
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import apply as skm_apply
+    from snekmer_amd import engine
+    from snekmer_amd.utils import pack_sequences
+
+    rng = np.random.default_rng(seed)
+    name = ["hydro", "standard", "solvacc", "miqs", "red6"][int(rng.integers(0, 5))]
+    lut = A.build_lut(name)
+    k = int(rng.integers(2, 9))
+    seqs = [s for s in draw_batch(rng) if len(s) < 3000]
+    if len(seqs) < 2:
+        return f"apply seed {seed}: skipped"
+    res, off = pack_sequences(seqs)
+    n = len(seqs)
+    batch = engine.SeqBatch(ctx, res, off)
+    csr = engine.count_csr(ctx, batch, lut, k)
+    basis = engine.build_basis(ctx, csr, lut.nsym, k, postings=False)
+    B = basis.ncols
+    tag = f"apply seed {seed}: {name} k={k} n={n} B={B}"
+    if B == 0 or B * n > 3e7:
+        return tag + " skipped"
+    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
+    X = np.zeros((n, B), dtype=np.int64)
+    rows = np.repeat(np.arange(n), np.diff(o_rowptr))
+    X[rows, ocol] = o_counts
+    ng = int(rng.integers(1, min(n, 40) + 1))
+    groups = rng.integers(0, ng, size=n)
+    T = np.zeros((ng, B), dtype=np.int64)
+    np.add.at(T, groups, X)
+    totals = skm_apply.group_sum(ctx, csr, groups, ng)
+    rp = totals.rowptr.download(ng + 1)
+    tc, tv = totals.colidx.download(totals.nnz), totals.counts.download(totals.nnz)
+    Td = np.zeros((ng, B), dtype=np.int64)
+    Td[np.repeat(np.arange(ng), np.diff(rp)), tc] = tv
+    assert (Td == T).all(), f"{tag}: group sums"
+    idx, score, dot = skm_apply.apply_top2(ctx, csr, B, totals)
+    G = X @ T.T
+    nx, ny = np.sqrt((X * X).sum(axis=1).astype(np.float64)), np.sqrt((T * T).sum(axis=1).astype(np.float64))
+    nx[nx == 0] = 1.0
+    ny[ny == 0] = 1.0
+    S = G / (nx[:, None] * ny[None, :])
+    for r in range(n):
+        order = np.lexsort((np.arange(ng), -S[r]))[:2]
+        for slot in range(min(2, ng)):
+            j = int(idx[r, slot])
+            assert j < ng, f"{tag}: row {r} slot {slot} has no column"
+            # equal scores may be told apart differently in the last bit: compare values, then ids where clear
+            assert abs(score[r, slot] - S[r, order[slot]]) <= 1e-12, f"{tag}: row {r} slot {slot} score"
+            assert dot[r, slot] == G[r, j], f"{tag}: row {r} slot {slot} dot"
+            assert abs(S[r, j] - score[r, slot]) <= 1e-12, f"{tag}: row {r} slot {slot} column {j}"
+    return tag
+
+
 def dense_round(ctx, seed):
     """Dense int8 cosine on the matrix cores: random shapes around the kernels' switch points (register-staged,
     128 x 128, 256 x 256 staggered; rectangular, X is Y), exact integer Gram with unit norms."""
@@ -177,6 +237,8 @@ def main():
         one_round(ctx, seed, verbose=True)
         if seed % 4 == 0:
             print(dense_round(ctx, seed), flush=True)
+        if seed % 4 == 2:
+            print(apply_round(ctx, seed), flush=True)
         seed += 1
         done += 1
     print(f"fuzz ok: {done} rounds in {time.perf_counter() - t0:.0f} s")

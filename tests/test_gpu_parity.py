@@ -1570,3 +1570,5 @@ def test_fuzz_short(ctx):
         fz.one_round(ctx, seed)
     for seed in range(40):
         fz.dense_round(ctx, seed)
+    for seed in range(40):
+        fz.apply_round(ctx, seed)
