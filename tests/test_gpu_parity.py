@@ -1486,8 +1486,9 @@ def test_fused_vectorize_equals_the_three_call_form(ctx, name, k):
     """skm_vectorize_csr (count + basis/postings + norms in one call, sizes left on the device) against
     skm_count_csr + skm_basis_build + skm_row_norms_csr: every output array identical, and the cosine matrix with it;
     all size classes (long sequences take the LDS-block and global-scratch count kernels), both code widths.
-    hydro k=32: the k-mer of 32 V's has the all-ones 32-bit code, the same word as the tail fill the sort runs over;
-    hydro k=3 / k=20: the same in the key bits the sort looks at (the stable sort keeps entries in front of the tail)."""
+    hydro k=3 / k=20 / k=32: the k-mer of k V's is all ones in the key bits the sort looks at, like the tail fill the
+    sort runs over (the full-width word differs: |S|^k < 2^bits is required); the stable sort keeps entries in front
+    of the tail."""
     from snekmer_amd import alphabet as A
     from snekmer_amd import engine
 
