@@ -14,7 +14,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 ctx = _hip.Context(0)
 lut = alphabet.build_lut("red6")
 out = None
-for shuffle in (True, False):
+for shuffle, overlap in ((True, False), (False, False), (True, True), (False, True)):
+    os.environ.pop("SKM_COSINE_OVERLAP", None)
+    if overlap:
+        os.environ["SKM_COSINE_OVERLAP"] = "1"
     res, off, _ = synth_families(n, 300, family=100, seed=BASE_SEED + 2, shuffle=shuffle)
     batch = engine.SeqBatch(ctx, res, off)
     p = engine.Pipeline(ctx, lut, 12)
@@ -31,4 +34,4 @@ for shuffle in (True, False):
     dt = (time.perf_counter() - t0) / 5 * 1e3
     prof = ctx.profile_dump()
     ctx.profile_enable(False)
-    print(f"shuffle={shuffle}: {dt:.3f} ms/step  " + " ".join(f"{k}={v[1] / 5:.3f}" for k, v in prof.items() if v[1] / 5 > 0.04))
+    print(f"shuffle={shuffle} overlap={overlap}: {dt:.3f} ms/step  " + " ".join(f"{k}={v[1] / 5:.3f}" for k, v in prof.items() if v[1] / 5 > 0.04))
