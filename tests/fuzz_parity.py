@@ -8,6 +8,8 @@ stars, lowercase, empties, repeats, a few long records) and compares, bit for bi
   * the N x N cosine by the neighbour-list path, by the cursor kernel and by the overlapped schedule with each other,
     and with the oracle's float64 rows to 1e-5;
   * neighbour lists (skm_gram_neighbors) of a random row block: neighbour sets and exact integer dot products;
+  * every fourth round: the rule body (`vectorize_records`: first-seen basis, min_filter, presence rows, reduced
+    strings, explicit basis) against the oracle's restatement of rules/kmerize.smk:67-139;
   * every fourth round: the learn/apply chain (group sums, fused top-2 epilogue) against float64 numpy;
   * every fourth round: the dense int8 matrix-core cosine at a random shape against the integer Gram (numpy)."""
 import os
@@ -196,6 +198,39 @@ def apply_round(ctx, seed):
     return tag
 
 
+def records_round(ctx, seed):
+    """The rule body (rules/kmerize.smk:67-139) on random records: snekmer_amd.kmerize.vectorize_records against the
+    oracle's restatement of the rule (oracle/ref_path.kmerize_rule: first-seen basis, `> min_filter`, np.isin
+    presence rows, reduced strings, ids, raw lengths), with and without an explicit basis."""
+    from oracle import ref_path as R
+    from snekmer_amd import alphabet as A
+    from snekmer_amd.kmerize import vectorize_records
+
+    rng = np.random.default_rng(seed)
+    name = ["hydro", "standard", "solvacc", "hydrocharge", "hydrostruct", "miqs", "ptm", "None"][int(rng.integers(0, 8))]
+    key = None if name == "None" else name
+    table = A.FULL_ALPHABETS[name]
+    k = int(rng.integers(1, 7))
+    seqs = [s[:400] for s in draw_batch(rng)][:60]
+    records = [(f"rec{i}|x", s) for i, s in enumerate(seqs)]
+    min_filter = int(rng.integers(0, 3))
+    tag = f"records seed {seed}: {name} k={k} n={len(records)} min_filter={min_filter}"
+    ref = R.kmerize_rule(records, k, table, min_filter=min_filter)
+    got = vectorize_records(records, key, k, min_filter=min_filter, ctx=ctx)
+    for f in ("kmerlist", "ids", "seqs", "lengths"):
+        assert [str(x) for x in got[f]] == [str(x) for x in ref[f]], f"{tag}: {f}"
+    assert got["vecs"].shape == ref["vecs"].shape and (got["vecs"] == ref["vecs"]).all(), f"{tag}: vecs"
+    if len(ref["kmerlist"]) >= 2:
+        # the basis.txt branch: an explicit basis (shuffled subset plus a k-mer nobody has), min_filter ignored
+        kl = [str(x) for x in ref["kmerlist"]]
+        basis = [kl[i] for i in rng.permutation(len(kl))[: max(1, len(kl) // 2)]]
+        ref2 = R.kmerize_rule(records, k, table, min_filter=min_filter, basis=basis)
+        got2 = vectorize_records(records, key, k, min_filter=min_filter, basis=basis, ctx=ctx)
+        assert [str(x) for x in got2["kmerlist"]] == basis, f"{tag}: explicit basis order"
+        assert (got2["vecs"] == ref2["vecs"]).all(), f"{tag}: vecs with an explicit basis"
+    return tag
+
+
 def dense_round(ctx, seed):
     """Dense int8 cosine on the matrix cores: random shapes around the kernels' switch points (register-staged,
     128 x 128, 256 x 256 staggered; rectangular, X is Y), exact integer Gram with unit norms."""
@@ -239,6 +274,8 @@ def main():
             print(dense_round(ctx, seed), flush=True)
         if seed % 4 == 2:
             print(apply_round(ctx, seed), flush=True)
+        if seed % 4 == 1:
+            print(records_round(ctx, seed), flush=True)
         seed += 1
         done += 1
     print(f"fuzz ok: {done} rounds in {time.perf_counter() - t0:.0f} s")

@@ -1573,3 +1573,5 @@ def test_fuzz_short(ctx):
         fz.dense_round(ctx, seed)
     for seed in range(40):
         fz.apply_round(ctx, seed)
+    for seed in range(40):
+        fz.records_round(ctx, seed)
