@@ -10,6 +10,8 @@ stars, lowercase, empties, repeats, a few long records) and compares, bit for bi
   * neighbour lists (skm_gram_neighbors) of a random row block: neighbour sets and exact integer dot products;
   * every fourth round: the rule body (`vectorize_records`: first-seen basis, min_filter, presence rows, reduced
     strings, explicit basis) against the oracle's restatement of rules/kmerize.smk:67-139;
+  * every fourth round: the sklearn call sites (cosine_similarity on ndarrays / DataFrames / scipy CSR, real-valued
+    matrices, connection_matrix_from_features, Jaccard) against scikit-learn and scipy themselves;
   * every fourth round: the learn/apply chain (group sums, fused top-2 epilogue) against float64 numpy;
   * every fourth round: the dense int8 matrix-core cosine at a random shape against the integer Gram (numpy)."""
 import os
@@ -231,6 +233,53 @@ def records_round(ctx, seed):
     return tag
 
 
+def score_round(ctx, seed):
+    """The sklearn call sites (rules/apply.smk:282, score.py:166-171) against scikit-learn itself on random matrices:
+    cosine_similarity for count matrices (ndarray, DataFrame, scipy CSR; every kernel path) to 1e-5 and for
+    real-valued matrices to 1e-12, connection_matrix_from_features for "cosine" and the "jaccard" (= 1 - hamming)
+    branch, jaccard_distance against scipy."""
+    import pandas as pd
+    import scipy.sparse as sp
+    from scipy.spatial.distance import pdist, squareform
+    from sklearn.metrics import pairwise_distances
+    from sklearn.metrics.pairwise import cosine_similarity as sk_cos
+
+    import snekmer_amd as skm
+
+    rng = np.random.default_rng(seed)
+    n, m = int(rng.integers(1, 300)), int(rng.integers(1, 200))
+    K = int(rng.choice([1, 7, 64, 200, 1024, 4096]))
+    dens = float(rng.choice([0.01, 0.1, 0.6]))
+    X = (rng.random((n, K)) < dens) * rng.integers(1, int(rng.choice([2, 5, 127, 300])), size=(n, K))
+    Y = (rng.random((m, K)) < dens) * rng.integers(1, 5, size=(m, K))
+    X[rng.integers(0, n)] = 0  # a zero row: similarity 0 with everything, itself included
+    tag = f"score seed {seed}: n={n} m={m} K={K} density={dens}"
+    ref = sk_cos(X, Y)
+    for path in ("auto", "sparse"):
+        got = skm.score.cosine_similarity(X, Y, ctx=ctx, path=path)
+        assert got.dtype == np.float64 and np.abs(got - ref).max() <= 1e-5, f"{tag}: counts, path {path}"
+    got = skm.score.cosine_similarity(pd.DataFrame(X), pd.DataFrame(Y), ctx=ctx)
+    assert np.abs(got - ref).max() <= 1e-5, f"{tag}: DataFrames"
+    got = skm.score.cosine_similarity(sp.csr_matrix(X), sp.csr_matrix(Y), ctx=ctx)
+    assert np.abs(got - ref).max() <= 1e-5, f"{tag}: scipy CSR"
+    got = skm.score.cosine_similarity(X, ctx=ctx)
+    assert np.abs(got - sk_cos(X)).max() <= 1e-5, f"{tag}: X with itself"
+    Xf = X / np.maximum(X.sum(axis=1, keepdims=True), 1) + rng.random((n, K)) * (rng.random() < 0.5)
+    got = skm.score.cosine_similarity(Xf, Y.astype(np.float64) * 0.5, ctx=ctx)
+    assert np.abs(got - sk_cos(Xf, Y * 0.5)).max() <= 1e-12, f"{tag}: real-valued"
+    D = skm.score.connection_matrix_from_features(X, metric="cosine")
+    assert np.abs(D - pairwise_distances(X, metric="cosine")).max() <= 1e-5 and (np.diag(D) == 0).all(), f"{tag}: cosine distance"
+    Df = skm.score.connection_matrix_from_features(Xf, metric="cosine")
+    assert np.abs(Df - pairwise_distances(Xf, metric="cosine")).max() <= 1e-12, f"{tag}: cosine distance, real-valued"
+    Bm = X > 0
+    H = skm.score.connection_matrix_from_features(Bm)  # metric="jaccard": 1 - hamming upstream
+    assert np.abs(H - (1 - pairwise_distances(Bm, metric="hamming"))).max() <= 1e-6, f"{tag}: 1 - hamming"
+    if n >= 2:
+        J = skm.score.jaccard_distance(Bm)
+        assert np.abs(J - squareform(pdist(Bm, "jaccard"))).max() <= 1e-6, f"{tag}: jaccard distance"
+    return tag
+
+
 def dense_round(ctx, seed):
     """Dense int8 cosine on the matrix cores: random shapes around the kernels' switch points (register-staged,
     128 x 128, 256 x 256 staggered; rectangular, X is Y), exact integer Gram with unit norms."""
@@ -276,6 +325,8 @@ def main():
             print(apply_round(ctx, seed), flush=True)
         if seed % 4 == 1:
             print(records_round(ctx, seed), flush=True)
+        if seed % 4 == 3:
+            print(score_round(ctx, seed), flush=True)
         seed += 1
         done += 1
     print(f"fuzz ok: {done} rounds in {time.perf_counter() - t0:.0f} s")

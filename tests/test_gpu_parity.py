@@ -1560,8 +1560,9 @@ def test_fused_vectorize_degenerate_batches(ctx, seqs):
 # ------------------------------------------------------------------ randomised differential check
 def test_fuzz_short(ctx):
     """Sixty rounds of tests/fuzz_parity.py (random alphabet, k, batch composition): counts, basis, column ids, the
-    fused call and the cosine by every schedule against the oracle and against each other.  The script runs for
-    minutes by hand (21 000 rounds passed in round 2)."""
+    fused call and the cosine by every schedule against the oracle and against each other; forty each of the dense
+    matrix-core shapes, the learn/apply chain, the rule body and the sklearn call sites (against scikit-learn).  The script runs for
+    minutes by hand (41 000 rounds passed in round 2)."""
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "fuzz_parity.py"))
@@ -1575,3 +1576,5 @@ def test_fuzz_short(ctx):
         fz.apply_round(ctx, seed)
     for seed in range(40):
         fz.records_round(ctx, seed)
+    for seed in range(40):
+        fz.score_round(ctx, seed)
