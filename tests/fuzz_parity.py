@@ -12,6 +12,8 @@ stars, lowercase, empties, repeats, a few long records) and compares, bit for bi
     strings, explicit basis) against the oracle's restatement of rules/kmerize.smk:67-139;
   * every fourth round: the sklearn call sites (cosine_similarity on ndarrays / DataFrames / scipy CSR, real-valued
     matrices, connection_matrix_from_features, Jaccard) against scikit-learn and scipy themselves;
+  * every eighth round: the per-record Python surface (reduce, reduce_vectorize, make_feature_matrix,
+    KmerBasis.transform) against the oracle's restatements of snekmer/vectorize.py, string for string;
   * every fourth round: the learn/apply chain (group sums, fused top-2 epilogue) against float64 numpy;
   * every fourth round: the dense int8 matrix-core cosine at a random shape against the integer Gram (numpy)."""
 import os
@@ -280,6 +282,48 @@ def score_round(ctx, seed):
     return tag
 
 
+def surface_round(ctx, seed):
+    """The per-record Python surface an unchanged rule body calls (vectorize.reduce, KmerVec.reduce_vectorize and its
+    batch form, make_feature_matrix, KmerBasis.transform / harmonize) against the oracle's restatements of
+    snekmer/vectorize.py, string for string."""
+    from oracle import ref_path as R
+
+    import snekmer_amd as skm
+    from snekmer_amd import alphabet as A
+
+    rng = np.random.default_rng(seed)
+    name = ["hydro", "standard", "solvacc", "hydrocharge", "hydrostruct", "miqs", "ptm", "None"][int(rng.integers(0, 8))]
+    key = None if name == "None" else name
+    table = A.FULL_ALPHABETS[name]
+    k = int(rng.integers(1, 9))
+    seqs = [s[:300] for s in draw_batch(rng)][:25] + ["", "M", "*", "MKV*", "mkvl"]
+    tag = f"surface seed {seed}: {name} k={k} n={len(seqs)}"
+    kv = skm.vectorize.KmerVec(alphabet=key, k=k)
+    vecs_ref = []
+    for sq in seqs:
+        assert skm.vectorize.reduce(sq, alphabet=key, mapping=A.FULL_ALPHABETS) == R.reduce(sq, table), f"{tag}: reduce"
+        got, ref = kv.reduce_vectorize(sq), R.reduce_vectorize(sq, k, table)
+        assert got.shape == ref.shape and [str(x) for x in got] == [str(x) for x in ref], f"{tag}: reduce_vectorize"
+        vecs_ref.append(ref)
+    for got, ref in zip(kv.reduce_vectorize_batch(seqs), vecs_ref):
+        assert [str(x) for x in got] == [str(x) for x in ref], f"{tag}: reduce_vectorize_batch"
+    if sum(len(v) for v in vecs_ref):
+        mf = int(rng.integers(0, 3))
+        rows, kl = skm.vectorize.make_feature_matrix(vecs_ref, mf)
+        rrows, rkl = R.make_feature_matrix(vecs_ref, mf)
+        assert [str(x) for x in kl] == [str(x) for x in rkl], f"{tag}: make_feature_matrix kmerlist"
+        assert len(rows) == len(rrows) and all((np.asarray(a) == np.asarray(b)).all() for a, b in zip(rows, rrows)), f"{tag}: rows"
+        if len(rkl) >= 2:
+            # KmerBasis.transform: columns from one k-mer order into another, unknown k-mers -> zero columns
+            vb = [str(x) for x in rkl]
+            mat = rng.integers(0, 5, size=(4, len(vb))).astype(np.float64)
+            target = [vb[i] for i in rng.permutation(len(vb))[: max(1, len(vb) - 1)]] + ["?" * k]
+            kb = skm.vectorize.KmerBasis()
+            kb.set_basis(target)
+            assert (kb.transform(mat, vb) == R.basis_transform(target, mat, vb)).all(), f"{tag}: KmerBasis.transform"
+    return tag
+
+
 def dense_round(ctx, seed):
     """Dense int8 cosine on the matrix cores: random shapes around the kernels' switch points (register-staged,
     128 x 128, 256 x 256 staggered; rectangular, X is Y), exact integer Gram with unit norms."""
@@ -327,6 +371,8 @@ def main():
             print(records_round(ctx, seed), flush=True)
         if seed % 4 == 3:
             print(score_round(ctx, seed), flush=True)
+        if seed % 8 == 5:
+            print(surface_round(ctx, seed), flush=True)
         seed += 1
         done += 1
     print(f"fuzz ok: {done} rounds in {time.perf_counter() - t0:.0f} s")

@@ -1578,3 +1578,5 @@ def test_fuzz_short(ctx):
         fz.records_round(ctx, seed)
     for seed in range(40):
         fz.score_round(ctx, seed)
+    for seed in range(20):
+        fz.surface_round(ctx, seed)
