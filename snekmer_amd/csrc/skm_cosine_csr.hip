@@ -969,6 +969,8 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
                 SKM_GRAM(7);
             else if (gabl == 8)
                 SKM_GRAM(8);
+            else if (gabl == 9)
+                SKM_GRAM(9);
             else if (gabl == 3) {  // phase stamps (exact results, slower): read with skm_debug_gram_phases
                 unsigned long long zeros[8] = {};
                 SKM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gram_phase_ticks), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice, st));

@@ -182,7 +182,7 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
 #pragma unroll
     for (int q = 0; q < GQ; ++q) {
         pb[q] = pe[q] = 0;
-        if (col[q] != G_SINGLETON) {
+        if (col[q] != G_SINGLETON && GABL != 9) {  // GABL 9 (diagnostic): no column-start gathers, no pair loop
             pb[q] = ycolptr[col[q]];
             pe[q] = ycolptr[col[q] + 1];
             if (GABL == 5)  // diagnostic: half of every list (the visit count of a symmetric half-Gram)

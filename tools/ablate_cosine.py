@@ -41,6 +41,7 @@ cases = [
     ("gram: no lists of 17+", {"SKM_GRAM_ABLATE": "6"}),
     ("gram: no lists of 5-16", {"SKM_GRAM_ABLATE": "7"}),
     ("gram: no lists of 1-4", {"SKM_GRAM_ABLATE": "8"}),
+    ("gram: no column-start gathers, no pair loop", {"SKM_GRAM_ABLATE": "9"}),
     ("gram shape 16x2 (exact)", {"SKM_GRAM_SHAPE": "1"}),
     ("gram shape 16x1 (exact)", {"SKM_GRAM_SHAPE": "2"}),
     ("gram shape 32x1 (exact)", {"SKM_GRAM_SHAPE": "3"}),
