@@ -366,12 +366,37 @@ def main():
     ctx.profile_enable(False)
     note(f"timed region: {elapsed / args.steps * 1e3:.3f} ms/step on rank {rank}")
 
+    shard_check = None
     if dist is not None:
         import torch
 
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if sharded:
+        # After the timed region every rank checks rows of ITS block against the single-GPU path on its own device
+        # (same kernels, whole batch vectorized locally, no communication): the exchange (RCCL transport included)
+        # must give bit-identical rows.  64 rows spread over the block; rank 0 reports the worst rank.
+        ref = engine.Pipeline(ctx, lut, args.k)
+        ref.vectorize(engine.SeqBatch(ctx, res, off))
+        lo_r, hi_r = bounds[rank]
+        ld_r = (n_total + 3) // 4 * 4
+        rows_chk = np.unique(np.linspace(lo_r, hi_r - 1, 64).astype(np.int64)) if hi_r > lo_r else np.zeros(0, np.int64)
+        bad = 0
+        for r in rows_chk:
+            want = ref.cosine(row0=int(r), row1=int(r) + 1).download(n_total)
+            got = pipe.out.download(n_total, offset=int(r - lo_r) * ld_r)
+            bad += int((want != got).sum())
+        del ref
+        nbad = np.asarray([bad], dtype=np.int64)
+        if dist is not None:
+            tb = torch.tensor(nbad)
+            dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+            nbad = tb.numpy()
+        shard_check = {"rows_checked_per_rank": int(len(rows_chk)), "ranks": world, "cells_different": int(nbad[0]),
+                       "what": "rows of every rank's block of the timed result against the single-GPU pipeline run on that rank "
+                               "(bit for bit)"}
+        note(f"sharded result check: {shard_check['cells_different']} cells differ over {world} rank(s)")
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -428,6 +453,8 @@ def main():
                 "whole_step_frac": rows_local * ld * 4 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
         }
+        if shard_check is not None:
+            line["sharded_result_check"] = shard_check
         if world == 1 and not sharded and not args.no_extras:
             extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
         if world == 1 and not args.no_cpu_baseline:
