@@ -30,6 +30,9 @@ import time
 
 import numpy as np
 
+# BASELINE.json's metric, verbatim
+BASELINE_METRIC = "sequences/sec vectorize+pairwise-cosine, 100k\u00d7300aa k=12; 1/2/4/8 GPU"
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -413,7 +416,7 @@ def main():
         if live_traffic and not live_traffic[0]:
             traffic_note = f"{traffic_note} (live pass: {live_traffic[1]})"
         line = {
-            "metric": "sequences/sec vectorize+pairwise-cosine, 100k x 300aa k=12",
+            "metric": BASELINE_METRIC,
             "value": n_total / (elapsed / args.steps),
             "unit": "sequences/s",
             "n_gpus": world,
