@@ -126,6 +126,12 @@ def cpu_baseline(alphabet_name, k, seed, points, budget_s, n_sparse):
                "EXTRAPOLATED_sequences_per_s_at_100k": float(1e5 / (a * 1e10 + b * 1e5)) if a * 1e10 + b * 1e5 > 0 else None,
                "note": "extrapolation only: the dense float64 N x |basis| arrays of the reference "
                        "(rules/kmerize.smk:112) need ~170 GB at N = 10k, so the path cannot run at the benchmarked size"}
+    if not points:
+        return {"value": sparse_one["value"], "unit": "sequences/s", "cores": 1, "kind": "port", "sample": sparse_one["sample"],
+                "note": "multi-rank run: only the sparse C restatement is timed here; the reference-equivalent numpy points and "
+                        "their fit are a rank-0 leg of the 1-GPU run (python3 bench.py)",
+                "sparse_all_cores": sparse_all, "sparse_one_core": sparse_one, "host_cores_visible": os.cpu_count(),
+                "host_cores_used_for_all_cores": threads}
     head = good[-1] if good else {"n": 0, "sequences_per_s": 0.0, "seconds": 0.0}
     return {
         "value": head["sequences_per_s"],
@@ -207,7 +213,7 @@ def live_pmc_traffic(args, budget_s=150.0):
     """HBM bytes per launch of the dominant kernel, measured in THIS run: two child processes of this script under
     `rocprofv3 --pmc WRITE_SIZE` and `rocprofv3 --pmc FETCH_SIZE` (separate passes, as MI355X_MICROARCH.md
     prescribes; values are KiB per dispatch, FETCH_SIZE doubled for gfx950's wide streaming reads).  Called before
-    this process touches the GPU; rocprofv3 launches python3 directly.  Returns (bytes or None, note)."""
+    this process touches the GPU; rocprofv3 launches this interpreter's own binary (sys.executable) directly.  Returns (bytes or None, note)."""
     import csv
     import re
     import shutil
@@ -226,7 +232,7 @@ def live_pmc_traffic(args, budget_s=150.0):
             if left < 20:
                 return None, "live PMC passes ran out of their time budget"
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "-o", "p", "--",
-                   "python3", os.path.abspath(__file__), "--pmc-child", "--n", str(args.n), "--length", str(args.length),
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--n", str(args.n), "--length", str(args.length),
                    "--k", str(args.k), "--alphabet", args.alphabet]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=left)
@@ -248,6 +254,39 @@ def live_pmc_traffic(args, budget_s=150.0):
     w, f = got["WRITE_SIZE"], got["FETCH_SIZE"]
     return w[0] + 2.0 * f[0], (f"measured in this run: rocprofv3 --pmc WRITE_SIZE ({w[0] / 1e9:.2f} GB/launch, {w[1]} launches) and "
                                f"--pmc FETCH_SIZE (2 x {f[0] / 1e9:.3f} GB), separate child passes, {time.perf_counter() - t0:.0f} s")
+
+
+def self_launch(n_ranks: int) -> int:
+    """Run this script as `n_ranks` ranks under torch.distributed.run (one process per GPU, 127.0.0.1 rendezvous on a
+    free port) and relay rank 0's JSON line.  The child is a fresh interpreter started with subprocess (no exec of a
+    process that has used the GPU: this parent never opens the device).  Returns the launcher's exit code."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    note("self-launch: " + " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for raw in proc.stdout:
+        text = raw.decode(errors="replace").rstrip("\n")
+        if text.startswith("{") and '"metric"' in text:
+            line = text
+        elif text:
+            sys.stderr.write(text + "\n")
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+    if rc != 0:
+        note(f"self-launch: the {n_ranks}-rank job exited with code {rc}")
+    return rc
 
 
 def main():
@@ -281,13 +320,17 @@ def main():
         pmc_child(args, seed)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python3 bench.py --gpus N` without a launcher: start the ranks ourselves, BEFORE anything in this process
+        # touches the GPU (the parent never does: it relays the one JSON line and the exit code)
+        sys.exit(self_launch(args.gpus))
+
     real_stdout = reserve_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        note(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is used")
         args.gpus = world
 
     from snekmer_amd import _hip, alphabet, engine
@@ -318,6 +361,12 @@ def main():
 
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    ndev = _hip.device_count()
+    if sharded and 0 < ndev <= local_rank:
+        # fewer GPUs than ranks (a 1-GPU box asked for --gpus 2): share devices, so that the failure is RCCL's own
+        # refusal of two ranks on one device and not an argument error
+        note(f"rank {rank}: {ndev} GPU(s) visible for {world} ranks; using device {local_rank % ndev}")
+        local_rank %= ndev
     ctx = _hip.Context(local_rank)
     lut = alphabet.build_lut(args.alphabet)
     res, off, _ = synth_families(args.n, args.length, family=100, seed=seed)
@@ -458,10 +507,16 @@ def main():
         }
         if shard_check is not None:
             line["sharded_result_check"] = shard_check
+        if sharded and pipe.mode == "distributed":
+            line["stage_rooflines"] = sharded_stage_rooflines(engine, args, pipe, prof, world, int(off[hi] - off[lo]), rows_local)
+            line["exchange"] = dict(pipe.sizes, collectives_per_step=4,
+                                    rccl_ms_per_step={k: v[1] / args.steps for k, v in prof.items() if k.startswith("rccl_")})
         if world == 1 and not sharded and not args.no_extras:
             extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
-        if world == 1 and not args.no_cpu_baseline:
-            pts = [int(x) for x in args.cpu_points.split(",") if x]
+        if not args.no_cpu_baseline:
+            # the reference-equivalent numpy points are a rank-0, N=1 leg (3 minutes of host time); a multi-rank run
+            # carries the sparse C restatement only (seconds) and says so
+            pts = [int(x) for x in args.cpu_points.split(",") if x] if world == 1 else []
             note(f"CPU baseline leg (bounded to {args.cpu_budget_s:.0f} s)")
             line["cpu_baseline"] = cpu_baseline(args.alphabet, args.k, seed, pts, args.cpu_budget_s, args.cpu_sparse_n)
         note("done")
@@ -470,6 +525,54 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sharded_stage_rooflines(engine, args, pipe, prof, world, residues_local, rows_local):
+    """Rank 0's stages of one sharded step (dist.ShardedPipeline, distributed basis): algorithmic bytes / measured
+    time.  Device stages are priced against HBM; the two RCCL exchanges against the per-rank xGMI egress (one link
+    per peer, ~153 GB/s each: MI355X_MICROARCH.md)."""
+    z = pipe.sizes
+    loc, own = z["local_entries"], z["owned_entries"]
+    cb = 4 if pipe.code_bits == 32 else 8
+    kb = engine.key_bits(pipe.lut.nsym, pipe.k)
+    passes = min((kb + 8) // 9, (kb + 7) // 8)
+    n = pipe.n_total
+    ld = (n + 3) // 4 * 4
+    # pairs of this rank's rows: every shared entry walks its column's posting list once
+    col = pipe.x.colidx.download(loc)
+    cp = pipe.basis.colptr.download(z["columns"] + 1).astype(np.int64)
+    ok = col != 0xFFFFFFFF
+    pairs = int((cp[1:] - cp[:-1])[col[ok].astype(np.int64)].sum())
+    xgmi = 153.0 * max(world - 1, 1)
+    table = [
+        ("k_count_short", "hbm", residues_local + loc * (cb + 4), "1 B/residue read + (code,count) per distinct k-mer written"),
+        ("k_compact_rows", "hbm", loc * 2 * (cb + 4), "padded rows -> tight CSR"),
+        ("k_bucket_keys", "hbm", loc * (cb + 4 + 8 + 1), "entries read; posting word + owner byte written"),
+        ("rocprim_radix_sort_owner", "hbm", loc * 7, "one pass over the owner bytes (histogram read, key read + written, index written)"),
+        ("k_partition_gather", "hbm", loc * (4 + 2 * (cb + 8)), "index read; code + posting word gathered and written in owner order"),
+        ("k_row_norms", "hbm", loc * 4, "counts read"),
+        ("rccl_alltoallv", "xgmi", z["alltoall_bytes_out"], "entries leaving this rank (code + posting word), one xGMI link per peer"),
+        ("rocprim_radix_sort_owned_codes", "hbm", own * passes * 2 * (cb + 4), f"{passes} Onesweep passes x (key + index)"),
+        ("rocprim_scan_shared_kmers", "hbm", own * (cb + 8), "sorted keys read, scan written"),
+        ("k_bucket_emit", "hbm", own * (cb + 12) + z["owned_postings"] * 16 + z["owned_columns"] * (8 + cb),
+         "sorted keys/indices/scan read; posting word gathered + written per shared entry; column start + table slot per column"),
+        ("rccl_allgatherv", "xgmi", z["allgather_bytes_in"] // max(world - 1, 1),
+         "this rank's postings/starts/table/norms to every peer (bytes per link)"),
+        ("k_colidx_lookup", "hbm", loc * (cb + 4) + loc * (cb + 4), "codes read, column ids written, one table probe (key + value) per entry"),
+        ("k_gram_sparse", "hbm", pairs * 8, "every (row, posting) pair of this rank's rows reads one 8-byte posting"),
+        ("k_cosine_write", "hbm", rows_local * ld * 4, "this rank's float32 row block"),
+    ]
+    out = []
+    for name, bound, nbytes, what in table:
+        cnt, ms = prof.get(name, (0, 0.0))
+        if not cnt:
+            continue
+        per_step = ms / args.steps
+        peak = HBM_PEAK_GBS if bound == "hbm" else (153.0 if name == "rccl_allgatherv" else xgmi)
+        gbs = nbytes / (per_step * 1e-3) / 1e9 if per_step > 0 else 0.0
+        out.append({"kernel": name, "bound": bound, "algorithmic_bytes_per_step": int(nbytes), "ms_per_step": per_step,
+                    "achieved_GBps": gbs, "peak_GBps": peak, "frac": gbs / peak, "bytes_are": what})
+    return out
 
 
 def stage_rooflines(ctx, engine, args, pipe, prof, residues_total):

@@ -207,8 +207,9 @@ int skm_row_norms_csr(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const ui
  * (pass X's own postings for the square N x N case).  Writes
  *   out[(i-row0)*ld + j] = <x_i, y_j> * x_rnorm[i] * y_rnorm[j]   for i in [row0,row1), j in [0,m)
  * with the integer dot product exact (int32) and the scaling in float32.
- * mode 0 = similarity; mode 1 = cosine distance as sklearn's pairwise_distances gives it
- * (1 - s clipped to [0,2]; exact 0 where i == j, square case only).
+ * mode 0 = similarity; mode 1 = cosine distance as sklearn's pairwise_distances(X) / cosine_distances(X, X)
+ * gives it (1 - s clipped to [0,2]; exact 0 where i == j: Y IS X); mode 2 = cosine distance between two
+ * different matrices, sklearn's cosine_distances(X, Y): the same values without the diagonal rule.
  * post_bits: 64 (d_ypost = uint64 words row | count << 32; d_ypostcnt ignored) or 32 (the
  * SKM_BASIS_POST32 form with its d_ypostcnt side array).
  * An X entry with d_xcolidx == 0xFFFFFFFF means "k-mer of this row only" (SKM_BASIS_ELIDE_SINGLETONS):
@@ -231,6 +232,21 @@ int skm_hamming_similarity_from_gram(skm_ctx *ctx, int64_t n, int64_t m, int64_t
  * 0 when both rows are empty.  Same in-place convention as skm_hamming_similarity_from_gram. */
 int skm_jaccard_distance_from_gram(skm_ctx *ctx, int64_t n, int64_t m, const float *d_xcount, const float *d_ycount,
                                    float *d_out, int64_t ld);
+
+/* The same two measures for ANY matrix, in float64 (what the reference returns).  snekmer/score.py:149-172 is
+ * called by default with metric="jaccard" on a k-mer COUNT matrix (its docstring), i.e.
+ * 1 - scipy hamming(x, y) = 1 - #{c: x_ic != y_jc} / ncols; scripts/cluster_cluster.py:189-190 calls scipy's
+ * Jaccard distance, |a xor b| / |a or b| on the non-zero patterns (pass the 0/1 pattern, d_equal NULL).  Inputs are two
+ * exact sparse Grams (skm_cosine_csr with unit norms, float32 cells holding integers < 2^24):
+ *   d_both[i][j]  = #{c: x_ic != 0 and y_jc != 0}   (Gram of the 0/1 pattern)
+ *   d_equal[i][j] = #{c: x_ic == y_jc != 0}          (Gram of the 0/1 matrix whose columns are the distinct
+ *                                                    (column, value) pairs); NULL for 0/1 input (equal == both)
+ * and the non-zeros per row d_xnnz[n], d_ynnz[m]: the rows differ on xnnz + ynnz - both - equal columns.
+ * kind 0: out = 1 - differ / ncols; kind 1: out = differ / (xnnz + ynnz - both), 0 when both rows are empty;
+ * kind 2: out = differ / ncols (the hamming distance itself). */
+int skm_setsim_f64(skm_ctx *ctx, int kind, int64_t n, int64_t m, int64_t ncols, const uint32_t *d_xnnz,
+                   const uint32_t *d_ynnz, const float *d_both, const float *d_equal, int64_t ld, double *d_out,
+                   int64_t ld_out);
 
 /* Apply epilogue (snekmer/rules/apply.smk:312-328, rules/learn.smk:831-849): for every row of a
  * score matrix the two largest entries and their columns, i.e. np.argsort(-S, axis=1)[:, :2] with

@@ -171,6 +171,20 @@ def hamming_similarity(X) -> np.ndarray:
     return out
 
 
+def jaccard_distance(X) -> np.ndarray:
+    """scipy's pdist(X, "jaccard") + squareform as snekmer/scripts/cluster_cluster.py:189-190 calls it.  scipy
+    (1.15, the installed un-pinned dependency) reads numeric rows as booleans (non-zero = True):
+    |a xor b| / |a or b|, 0 for two empty rows."""
+    nz = np.asarray(X) != 0
+    n = nz.shape[0]
+    out = np.zeros((n, n), dtype=np.float64)
+    for i in range(n):
+        num = (nz ^ nz[i]).sum(axis=1).astype(np.float64)
+        den = (nz | nz[i]).sum(axis=1).astype(np.float64)
+        out[i] = np.where(den > 0, num / np.maximum(den, 1.0), 0.0)
+    return out
+
+
 def apply_epilogue(totals, counts, names: Sequence[str], confidence: Optional[Dict[float, float]] = None):
     """rules/apply.smk:278-328 (same logic at rules/learn.smk:811-849): cosine of the family totals
     against the query counts, the two best families per query by ``np.argsort(-S)``, Score = top1,

@@ -90,6 +90,7 @@ _SIGNATURES = {
         [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, C.c_int, _p, _p, _i64, _i64, C.c_int, _p, _i64],
     ),
     "skm_hamming_similarity_from_gram": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _i64]),
+    "skm_setsim_f64": (C.c_int, [_p, C.c_int, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _p, _i64]),
     "skm_row_top2": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p]),
     "skm_csr_group_sum": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _p, _p, C.POINTER(_i64)]),
     "skm_gram_neighbors": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _p, _p, C.c_int, _p, _i64, _i64, _i64, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)]),
@@ -205,7 +206,9 @@ class DeviceArray:
 
 
 class Context:
-    """One device + one HIP stream (skm_ctx)."""
+    """One device + one HIP stream (skm_ctx).  Not re-entrant: one host thread at a time per context (the
+    small-batch arena of engine.recode_host / kmer_codes_host is per context and unguarded); distinct contexts may be
+    used from distinct threads."""
 
     def __init__(self, device: int = 0):
         self.lib = load_library()
@@ -219,7 +222,11 @@ class Context:
         self.device = device
 
     def close(self):
+        """Free the context.  Pinned host memory handed out by host_alloc (the small-batch arena of engine.py
+        included) is freed with it: numpy views a caller kept over it are dangling afterwards, and any later call on
+        this context raises."""
         if getattr(self, "handle", None) is not None:
+            self.__dict__.pop("_arena", None)  # its views point into the pinned memory freed below
             for ptr in self.__dict__.pop("_pinned", []):
                 self.lib.skm_host_free(self.handle, _p(ptr))
             self.lib.skm_destroy(self.handle)
@@ -302,6 +309,8 @@ class Context:
 
     # -- raw entry points (thin; shapes are the callers' business)
     def call(self, name: str, *args):
+        if self.handle is None:
+            raise HipError(-1, f"{name}: the context is closed")
         _check(self.lib, getattr(self.lib, name)(self.handle, *args))
 
 

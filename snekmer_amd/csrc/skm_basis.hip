@@ -234,6 +234,35 @@ __global__ void k_setsim_from_gram(int64_t n, int64_t m, float inv_cols, const f
     }
 }
 
+// float64 forms for ANY matrix (counts, real values): both = #{c: x_ic != 0 and y_jc != 0}, equal = #{c: x_ic == y_jc != 0}
+// (null for 0/1 input, where equal == both), xn / yn = non-zeros per row.  Columns on which two rows differ:
+// xn + yn - both - equal.  KIND 0: 1 - hamming distance, count / ncols in double as scipy's hamming does;
+// KIND 1: differ / #{c: x_ic != 0 or y_jc != 0}, 0 for two empty rows (scipy's Jaccard distance when fed the 0/1 pattern);
+// KIND 2: the hamming distance itself.
+template <int KIND>
+__global__ void k_setsim_f64(int64_t n, int64_t m, double ncols, const uint32_t *__restrict__ xn,
+                             const uint32_t *__restrict__ yn, const float *__restrict__ both,
+                             const float *__restrict__ equal, int64_t ld, double *__restrict__ out, int64_t ld_out)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m)
+        return;
+    const double cj = (double)yn[j];
+    for (int64_t i = blockIdx.y; i < n; i += gridDim.y) {
+        const double b = (double)both[i * ld + j];
+        const double e = equal ? (double)equal[i * ld + j] : b;
+        const double differ = (double)xn[i] + cj - b - e;
+        if (KIND == 0) {
+            out[i * ld_out + j] = 1.0 - differ / ncols;
+        } else if (KIND == 2) {
+            out[i * ld_out + j] = differ / ncols;
+        } else {
+            const double uni = (double)xn[i] + cj - b;
+            out[i * ld_out + j] = uni > 0.0 ? differ / uni : 0.0;
+        }
+    }
+}
+
 template <typename T>
 __global__ void k_gather_columns(int64_t rows, int64_t ncols_out, const T *__restrict__ in, int64_t ld_in,
                                  const uint32_t *__restrict__ src, T *__restrict__ out)
@@ -856,6 +885,28 @@ extern "C" int skm_jaccard_distance_from_gram(skm_ctx *ctx, int64_t n, int64_t m
     SKM_PROF(ctx, "k_setsim_from_gram");
     k_setsim_from_gram<1><<<grid, BLK, 0, ctx->stream>>>(n, m, 0.0f, d_xcount, d_ycount, d_out, ld);
     return skm_check_launch("k_setsim_from_gram");
+}
+
+extern "C" int skm_setsim_f64(skm_ctx *ctx, int kind, int64_t n, int64_t m, int64_t ncols, const uint32_t *d_xnnz,
+                              const uint32_t *d_ynnz, const float *d_both, const float *d_equal, int64_t ld, double *d_out,
+                              int64_t ld_out)
+{
+    SKM_REQUIRE(ctx && kind >= 0 && kind <= 2 && n >= 0 && m >= 0 && ncols > 0 && ld >= m && ld_out >= m, SKM_E_BADARG,
+                "skm_setsim_f64: bad argument");
+    SKM_REQUIRE(ncols < ((int64_t)1 << 24), SKM_E_OVERFLOW, "skm_setsim_f64: 2^24 columns or more (float32 Gram cells would round)");
+    if (n == 0 || m == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_xnnz && d_ynnz && d_both && d_out, SKM_E_BADARG, "skm_setsim_f64: null array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    dim3 grid((unsigned)skm_ceil_div(m, BLK), (unsigned)(n < 1024 ? n : 1024));
+    SKM_PROF(ctx, "k_setsim_f64");
+    if (kind == 0)
+        k_setsim_f64<0><<<grid, BLK, 0, ctx->stream>>>(n, m, (double)ncols, d_xnnz, d_ynnz, d_both, d_equal, ld, d_out, ld_out);
+    else if (kind == 1)
+        k_setsim_f64<1><<<grid, BLK, 0, ctx->stream>>>(n, m, (double)ncols, d_xnnz, d_ynnz, d_both, d_equal, ld, d_out, ld_out);
+    else
+        k_setsim_f64<2><<<grid, BLK, 0, ctx->stream>>>(n, m, (double)ncols, d_xnnz, d_ynnz, d_both, d_equal, ld, d_out, ld_out);
+    return skm_check_launch("k_setsim_f64");
 }
 
 extern "C" int skm_gather_columns(skm_ctx *ctx, int64_t rows, int64_t ncols_out, int elem_bytes, const void *d_in,

@@ -71,6 +71,10 @@ struct skm_ctx {
 };
 
 int skm_ws(skm_ctx *ctx, int slot, size_t bytes, void **out);
+// similarity -> distance in place over a float32 block: out = clamp(1 - out, 0, 2), no diagonal rule (the epilogue of
+// mode 2 of skm_cosine_csr / skm_cosine_dense_i8: sklearn's cosine_distances(X, Y) with Y another matrix than X);
+// defined in skm_cosine_csr.hip
+int skm_similarity_to_distance(skm_ctx *ctx, int64_t rows, int64_t m, float *d_out, int64_t ld);
 
 // RAII bracket that records start/stop events around a launch when profiling is on.
 struct skm_prof_scope {

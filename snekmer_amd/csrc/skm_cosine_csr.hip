@@ -1027,19 +1027,49 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
 }
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void k_similarity_to_distance(int64_t rows, int64_t m, float *__restrict__ out, int64_t ld)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m)
+        return;
+    for (int64_t i = blockIdx.y; i < rows; i += gridDim.y)
+        out[i * ld + j] = fminf(fmaxf(1.0f - out[i * ld + j], 0.0f), 2.0f);
+}
+}  // namespace
+
+int skm_similarity_to_distance(skm_ctx *ctx, int64_t rows, int64_t m, float *d_out, int64_t ld)
+{
+    if (rows <= 0 || m <= 0)
+        return SKM_OK;
+    dim3 grid((unsigned)skm_ceil_div(m, 256), (unsigned)(rows < 4096 ? rows : 4096));
+    SKM_PROF(ctx, "k_similarity_to_distance");
+    k_similarity_to_distance<<<grid, 256, 0, ctx->stream>>>(rows, m, d_out, ld);
+    return skm_check_launch("k_similarity_to_distance");
+}
+
 extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
                               const uint32_t *d_xcounts, const float *d_xrnorm, int64_t m, int64_t ncols,
                               const uint32_t *d_ycolptr, const void *d_ypost, int post_bits, const uint32_t *d_ypostcnt,
                               const float *d_yrnorm, int64_t row0, int64_t row1, int mode, float *d_out, int64_t ld)
 {
     SKM_REQUIRE(post_bits == 64 || post_bits == 32, SKM_E_BADARG, "skm_cosine_csr: post_bits must be 32 or 64");
+    SKM_REQUIRE(mode >= 0 && mode <= 2, SKM_E_BADARG, "skm_cosine_csr: mode must be 0, 1 or 2");
+    // mode 2 (distance between two DIFFERENT matrices: no diagonal rule) = the similarity block, then 1 - s clamped, the
+    // same float operations the fused mode-1 epilogue applies
+    const int kmode = mode == 2 ? 0 : mode;
+    int rc;
     if (post_bits == 32) {
         SKM_REQUIRE(m <= ((int64_t)1 << 24), SKM_E_BADARG, "skm_cosine_csr: 32-bit postings hold rows < 2^24");
-        return cosine_csr_impl<uint32_t>(ctx, n, d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, ncols, d_ycolptr,
-                                         (const uint32_t *)d_ypost, d_ypostcnt, d_yrnorm, row0, row1, mode, d_out, ld);
+        rc = cosine_csr_impl<uint32_t>(ctx, n, d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, ncols, d_ycolptr,
+                                       (const uint32_t *)d_ypost, d_ypostcnt, d_yrnorm, row0, row1, kmode, d_out, ld);
+    } else {
+        rc = cosine_csr_impl<uint64_t>(ctx, n, d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, ncols, d_ycolptr,
+                                       (const uint64_t *)d_ypost, nullptr, d_yrnorm, row0, row1, kmode, d_out, ld);
     }
-    return cosine_csr_impl<uint64_t>(ctx, n, d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, ncols, d_ycolptr,
-                                     (const uint64_t *)d_ypost, nullptr, d_yrnorm, row0, row1, mode, d_out, ld);
+    if (rc == SKM_OK && mode == 2)
+        rc = skm_similarity_to_distance(ctx, row1 - row0, m, d_out, ld);
+    return rc;
 }
 
 #ifdef SKM_DIAG

@@ -825,9 +825,23 @@ extern "C" int skm_count_dense(skm_ctx *ctx, const uint8_t *h_rank, int nsym, in
     return SKM_OK;
 }
 
+static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim, const int8_t *d_x, const int8_t *d_y,
+                                const float *d_xrnorm, const float *d_yrnorm, int mode, float *d_out, int64_t ld);
+
 extern "C" int skm_cosine_dense_i8(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim, const int8_t *d_x,
                                    const int8_t *d_y, const float *d_xrnorm, const float *d_yrnorm, int mode,
                                    float *d_out, int64_t ld)
+{
+    SKM_REQUIRE(mode >= 0 && mode <= 2, SKM_E_BADARG, "skm_cosine_dense_i8: mode must be 0, 1 or 2");
+    // mode 2: distance between two different matrices (no diagonal rule), see skm_cosine_csr
+    int rc = cosine_dense_i8_impl(ctx, n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, mode == 2 ? 0 : mode, d_out, ld);
+    if (rc == SKM_OK && mode == 2)
+        rc = skm_similarity_to_distance(ctx, n, m, d_out, ld);
+    return rc;
+}
+
+static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim, const int8_t *d_x, const int8_t *d_y,
+                                const float *d_xrnorm, const float *d_yrnorm, int mode, float *d_out, int64_t ld)
 {
     SKM_REQUIRE(ctx && n >= 0 && m >= 0 && kdim >= 0, SKM_E_BADARG, "skm_cosine_dense_i8: bad argument");
     SKM_REQUIRE(kdim % 64 == 0, SKM_E_BADARG, "skm_cosine_dense_i8: kdim (%lld) must be a multiple of 64", (long long)kdim);

@@ -242,6 +242,7 @@ class ShardedPipeline:
         self.rnorm = None
         self.out = None
         self.nnz_total = 0
+        self.sizes = {}
         self.x = None  # the CSR view the cosine kernels read rows [lo, hi) from
         if basis == "replicated":
             cap = total_residues + 1
@@ -321,6 +322,14 @@ class ShardedPipeline:
         ctx.call("skm_concat_colptr", G, ncols.ctypes.data_as(_p), npost.ctypes.data_as(_p), _p(a_start.ptr),
                  _p(b.colptr.ptr))
         self.basis = b
+        # sizes of this step, for reporting (bench.py's per-stage rooflines)
+        self.sizes = {"local_entries": int(loc.nnz), "owned_entries": nrecv, "owned_columns": int(ncols[me]),
+                      "owned_postings": int(npost[me]), "owned_table_slots": int(tsize[me]), "columns": tot_cols,
+                      "postings": tot_post, "table_slots": tot_slots,
+                      "alltoall_bytes_out": int((cmat[me, :].sum() - cmat[me, me]) * (cb + 8)),
+                      "alltoall_bytes_in": int((cmat[:, me].sum() - cmat[me, me]) * (cb + 8)),
+                      "allgather_bytes_in": int((tot_post - npost[me]) * 8 + (tot_cols - ncols[me]) * 4
+                                                + (tot_slots - tsize[me]) * (cb + 4) + (self.n_total - nloc) * 4)}
         # 5. columns of the local rows; the shard as rows [lo, hi) of an N-row matrix
         colidx = self._need("colidx", loc.nnz, np.uint32)
         ctx.call("skm_colidx_lookup", self.code_bits, G, _i64(loc.nnz), _p(loc.codes.ptr), tsize.ctypes.data_as(_p),

@@ -164,8 +164,9 @@ def _cosine_f64(ctx, X, Y, mode):
 
 
 def cosine_similarity(X, Y=None, mode: int = 0, ctx=None, path: str = "auto", dtype=np.float64) -> np.ndarray:
-    """Cosine similarity between the rows of X and the rows of Y (Y=None: X with itself), [n_x, n_y],
-    float64 like sklearn's (pass dtype=np.float32 to keep the device's float32 block of the count
+    """Cosine similarity (mode 0) or sklearn's cosine distance (mode 1: 1 - s clipped to [0, 2], with an exact-zero
+    diagonal when Y is None or Y is X, as sklearn.metrics.pairwise.cosine_distances) between the rows of X and the
+    rows of Y (Y=None: X with itself), [n_x, n_y], float64 like sklearn's (pass dtype=np.float32 to keep the device's float32 block of the count
     paths without the widening copy).
     Count matrices: exact integer dot products scaled in float32 (|err| <= ~3e-7); `path` "auto" picks
     the i8 MFMA GEMM for dense ndarrays over a small basis with counts <= 127 and the sparse kernels
@@ -176,6 +177,10 @@ def cosine_similarity(X, Y=None, mode: int = 0, ctx=None, path: str = "auto", dt
     ctx = ctx or _hip.default_context()
     if path not in ("auto", "sparse", "dense", "f64"):
         raise ValueError("path must be 'auto', 'sparse', 'dense' or 'f64'")
+    if mode not in (0, 1):
+        raise ValueError("mode must be 0 (similarity) or 1 (distance)")
+    if Y is X:  # sklearn: cosine_distances zeroes the diagonal `if X is Y or Y is None`
+        Y = None
     X = _plain(X)
     Y = None if Y is None else _plain(Y)
     counts = _is_count_matrix(X) and (Y is None or _is_count_matrix(Y))
@@ -183,6 +188,8 @@ def cosine_similarity(X, Y=None, mode: int = 0, ctx=None, path: str = "auto", dt
         return _cosine_f64(ctx, X, Y, mode).astype(dtype, copy=False)
     if not counts:
         raise ValueError(f"path={path!r} takes count matrices (non-negative integers); use path='f64' or 'auto'")
+    if mode == 1 and Y is not None:
+        mode = 2  # distance between two different matrices: no diagonal rule (include/snekmer_hip.h)
     return _cosine_counts(ctx, X, Y, mode, path).astype(dtype, copy=False)
 
 
@@ -218,52 +225,98 @@ def connection_matrix_from_features(feature_matrix, metric="jaccard"):
         return cosine_similarity(feature_matrix, None, mode=1)
     if metric == "jaccard":
         return hamming_similarity(feature_matrix)
+    if metric == "hamming":
+        return _set_measure(feature_matrix, 2)
     raise NotImplementedError(
-        f"metric={metric!r}: the MI355X hot path implements 'cosine' and the reference's 'jaccard' "
-        "(= 1 - hamming) branches of snekmer/score.py:166-171"
+        f"metric={metric!r}: the MI355X hot path implements 'cosine', 'hamming' and the reference's default 'jaccard' "
+        "(= 1 - hamming) branch of snekmer/score.py:166-171; no Snekmer rule passes another metric"
     )
 
 
 def jaccard_distance(feature_matrix, ctx=None) -> np.ndarray:
-    """Square Jaccard distance matrix of a binary feature matrix, what
-    ``squareform(pdist(X, "jaccard"))`` gives in snekmer/scripts/cluster_cluster.py:189-190 (the
-    branch used when the optional BSF package is absent)."""
-    return _set_measure(feature_matrix, "jaccard", ctx)
+    """Square Jaccard distance matrix, what ``squareform(pdist(X, "jaccard"))`` gives in
+    snekmer/scripts/cluster_cluster.py:189-190 (the branch used when the optional BSF package is absent):
+    |a xor b| / |a or b| on the rows' non-zero patterns (scipy reads numeric rows as booleans), 0 for two empty
+    rows.  float64."""
+    A = _plain(feature_matrix)
+    if hasattr(A, "toarray"):
+        A = A.toarray()
+    A = np.asarray(A)
+    if A.dtype.kind == "f" and not np.all(np.isfinite(A)):
+        raise ValueError("Input contains NaN or infinity.")
+    return _set_measure(A != 0, 1, ctx)
 
 
 def hamming_similarity(feature_matrix, ctx=None) -> np.ndarray:
     """What the reference's metric="jaccard" branch really computes (snekmer/score.py:166-168):
-    ``1 - pairwise_distances(X, metric="hamming")`` = fraction of columns on which two rows agree.
-    Implemented for the binary presence matrices that branch is used with (``vecs``); the exact
-    intersection sizes come from the sparse Gram kernels with unit norms."""
-    return _set_measure(feature_matrix, "hamming", ctx)
+    ``1 - pairwise_distances(X, metric="hamming")`` = fraction of columns on which two rows are EQUAL, for any
+    matrix: the k-mer count matrix the docstring names, the binary ``vecs``, or real-valued features.  float64,
+    the same arithmetic as scipy's hamming (count / columns in double)."""
+    return _set_measure(feature_matrix, 0, ctx)
 
 
-def _set_measure(feature_matrix, kind: str, ctx=None) -> np.ndarray:
+def _pattern_and_value_csr(ctx, A):
+    """(0/1 pattern CSR, CSR over distinct (column, value) pairs or None when A is 0/1, non-zeros per row)."""
+    rows, cols = np.nonzero(A)
+    vals = A[rows, cols]
+    n = A.shape[0]
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=n), out=indptr[1:])
+
+    def csr(colids):
+        nnz = int(colids.size)
+        c = engine.CountsCSR(ctx, n, nnz, 32, ctx.to_device(indptr), ctx.to_device(np.zeros(max(nnz, 1), dtype=np.uint32)),
+                             ctx.to_device(np.ones(max(nnz, 1), dtype=np.uint32)), None)
+        c.colidx = ctx.to_device(colids.astype(np.uint32) if nnz else np.zeros(1, np.uint32))
+        return c
+
+    pattern = csr(cols)
+    binary = A.dtype == bool or not vals.size or bool(np.all(vals == 1))
+    if binary:
+        return pattern, None, 0, np.diff(indptr).astype(np.uint32)
+    # one column per distinct (column, value) pair: two rows share such a column iff they hold the SAME non-zero value
+    _, vrank = np.unique(vals, return_inverse=True)
+    key = cols.astype(np.int64) * (int(vrank.max()) + 1) + vrank
+    uniq, pair_col = np.unique(key, return_inverse=True)
+    if uniq.size >= 2**32 - 1:
+        raise OverflowError("2^32 distinct (column, value) pairs or more")
+    return pattern, csr(pair_col), int(uniq.size), np.diff(indptr).astype(np.uint32)
+
+
+def _set_measure(feature_matrix, kind: int, ctx=None) -> np.ndarray:
     import ctypes as C
 
     from . import _hip
 
     ctx = ctx or _hip.default_context()
-    A = np.asarray(feature_matrix)
+    A = _plain(feature_matrix)
+    if hasattr(A, "toarray"):
+        A = A.toarray()
+    A = np.asarray(A)
     if A.ndim != 2:
         raise ValueError("expected a 2-D feature matrix")
-    if A.dtype != bool and np.any((A != 0) & (A != 1)):
-        raise NotImplementedError(f"the {kind} measure is implemented for binary (0/1 or bool) matrices only")
-    Ab = (A != 0).astype(np.uint8)
-    n, ncols = Ab.shape
+    if A.dtype.kind not in "buif":
+        A = A.astype(np.float64)  # sklearn / scipy convert to double too; raises for non-numeric input
+    if A.dtype.kind == "f" and not np.all(np.isfinite(A)):
+        raise ValueError("Input contains NaN or infinity.")
+    n, ncols = A.shape
     if ncols == 0:
         raise ValueError("feature matrix has no columns")
-    x, _ = _as_count_csr(ctx, Ab)
+    if n == 0:
+        return np.zeros((0, 0), dtype=np.float64)
+    pattern, valued, nvalcols, nnz_row = _pattern_and_value_csr(ctx, A)
     ones = ctx.to_device(np.ones(n + 4, dtype=np.float32))
-    colptr, post = engine.transpose(ctx, n, x.nnz, ncols, x.rowptr, x.colidx, x.counts)
     ld = (n + 3) // 4 * 4
-    out = engine.cosine_matrix(ctx, x, ones, n, ncols, colptr, post, ones, mode=0, ld=ld)  # exact |a & b|
-    sizes = ctx.to_device(np.concatenate([Ab.sum(axis=1), np.zeros(4)]).astype(np.float32))
-    if kind == "hamming":
-        ctx.call("skm_hamming_similarity_from_gram", C.c_int64(n), C.c_int64(n), C.c_int64(ncols), C.c_void_p(sizes.ptr),
-                 C.c_void_p(sizes.ptr), C.c_void_p(out.ptr), C.c_int64(ld))
-    else:
-        ctx.call("skm_jaccard_distance_from_gram", C.c_int64(n), C.c_int64(n), C.c_void_p(sizes.ptr), C.c_void_p(sizes.ptr),
-                 C.c_void_p(out.ptr), C.c_int64(ld))
-    return out.download().reshape(max(n, 1), max(ld, 1))[:n, :n]
+
+    def gram(x, width):  # exact integer Gram in float32 cells (< 2^24: checked by skm_setsim_f64)
+        colptr, post = engine.transpose(ctx, n, x.nnz, width, x.rowptr, x.colidx, x.counts)
+        return engine.cosine_matrix(ctx, x, ones, n, width, colptr, post, ones, mode=0, ld=ld)
+
+    both = gram(pattern, ncols)
+    equal = gram(valued, nvalcols) if valued is not None else None
+    d_nnz = ctx.to_device(np.concatenate([nnz_row, np.zeros(4, dtype=np.uint32)]))
+    out = ctx.empty((n, n), np.float64)
+    ctx.call("skm_setsim_f64", kind, C.c_int64(n), C.c_int64(n), C.c_int64(ncols), C.c_void_p(d_nnz.ptr), C.c_void_p(d_nnz.ptr),
+             C.c_void_p(both.ptr), C.c_void_p(equal.ptr if equal is not None else None), C.c_int64(ld), C.c_void_p(out.ptr),
+             C.c_int64(n))
+    return out.download().reshape(n, n)

@@ -7,20 +7,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# skm_cosine_csr routes outputs of at most 1024 columns to the cursor kernel and larger ones to the neighbour-list
+# kernels; SKM_COSINE_PATH=lists / cursor force one of them (all exact).  Tests marked `cosine_paths` run once per
+# routing: "default" is the product's own dispatch (no variable set), the other two cover the kernel the default
+# would not pick at the test's size.  Unmarked tests run the default dispatch.
+COSINE_PATHS = ("default", "lists", "cursor")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    config.addinivalue_line("markers", "cosine_paths: run under every routing of skm_cosine_csr (default / lists / cursor)")
 
 
-@pytest.fixture(autouse=True, scope="session")
-def _list_path_for_small_outputs():
-    """Outputs of at most 1024 columns take the cursor kernel by default (the apply case).  Most parity tests
-    are that small, so the suite pins the neighbour-list path (the one the benchmarked sizes run); the tests
-    that exercise the cursor kernel select it explicitly."""
-    old = os.environ.get("SKM_COSINE_PATH")
-    os.environ["SKM_COSINE_PATH"] = "lists"
-    yield
-    if old is None:
-        os.environ.pop("SKM_COSINE_PATH", None)
+def pytest_generate_tests(metafunc):
+    if metafunc.definition.get_closest_marker("cosine_paths") and "_cosine_path" in metafunc.fixturenames:
+        metafunc.parametrize("_cosine_path", COSINE_PATHS, indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def _cosine_path(request, monkeypatch):
+    path = getattr(request, "param", "default")
+    if path == "default":
+        monkeypatch.delenv("SKM_COSINE_PATH", raising=False)
     else:
-        os.environ["SKM_COSINE_PATH"] = old
+        monkeypatch.setenv("SKM_COSINE_PATH", path)
+    return path

@@ -274,11 +274,12 @@ def score_round(ctx, seed):
     Df = skm.score.connection_matrix_from_features(Xf, metric="cosine")
     assert np.abs(Df - pairwise_distances(Xf, metric="cosine")).max() <= 1e-12, f"{tag}: cosine distance, real-valued"
     Bm = X > 0
-    H = skm.score.connection_matrix_from_features(Bm)  # metric="jaccard": 1 - hamming upstream
-    assert np.abs(H - (1 - pairwise_distances(Bm, metric="hamming"))).max() <= 1e-6, f"{tag}: 1 - hamming"
-    if n >= 2:
-        J = skm.score.jaccard_distance(Bm)
-        assert np.abs(J - squareform(pdist(Bm, "jaccard"))).max() <= 1e-6, f"{tag}: jaccard distance"
+    for M, what in ((Bm, "binary"), (X, "counts"), (np.round(Xf, 1), "real-valued")):
+        H = skm.score.connection_matrix_from_features(M)  # metric="jaccard": 1 - hamming upstream
+        assert (H == 1 - pairwise_distances(M, metric="hamming")).all(), f"{tag}: 1 - hamming, {what}"
+        if n >= 2:
+            J = skm.score.jaccard_distance(M)
+            assert (J == squareform(pdist(M, "jaccard"))).all(), f"{tag}: jaccard distance, {what}"
     return tag
 
 

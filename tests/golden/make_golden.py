@@ -503,10 +503,49 @@ def extra(ref_root):
     print("extra fixtures written: g12_apply_*.npz, g13_float_features.npz, g14_reference_kmers_pickle.json")
 
 
+def hamming_counts(ref_root):
+    """G15: the DEFAULT call of score.connection_matrix_from_features (metric="jaccard" -> 1 - hamming distance,
+    snekmer/score.py:166-168) on the input its docstring names, a k-mer COUNT matrix, and on a real-valued one; plus
+    scipy's Jaccard distance (scripts/cluster_cluster.py:189-190) on the same non-binary matrices."""
+    from scipy.spatial.distance import pdist, squareform
+
+    A, V, S, U = import_reference(ref_root)
+    g9 = np.load(os.path.join(HERE, "g9_connection.npz"))
+    X = g9["X"]  # counts 0..3, one all-zero row
+    demo_dir = os.path.join(ref_root, "resources", "tutorial", "demo_example", "input")
+    records = []
+    for f in sorted(x for x in os.listdir(demo_dir) if x.endswith(".faa")):
+        records += read_fasta(os.path.join(demo_dir, f))
+    out = run_rule(V, A, records, "hydro", 14)
+    counts = run_counts(out["seqs"], out["kmerlist"])  # 52 x 4941, counts up to 13
+    rng = np.random.default_rng(15)
+    # real-valued: few distinct values per column so that equal non-zero cells exist; a zero row; negative values
+    F = rng.choice(np.asarray([0.0, 0.0, 0.0, 0.25, -1.5, 2.0, 1e-3]), size=(31, 47))
+    F[7] = 0.0
+    F[9] = F[8]
+    np.savez_compressed(
+        os.path.join(HERE, "g15_hamming_counts.npz"),
+        F=F,
+        default_x=S.connection_matrix_from_features(X),
+        default_demo_counts=S.connection_matrix_from_features(counts),
+        default_float=S.connection_matrix_from_features(F),
+        default_lengthnorm=S.connection_matrix_from_features(U.to_feature_matrix([list(r) for r in counts], length_array=out["lengths"])),
+        demo_lengths=out["lengths"],
+        jaccard_x=squareform(pdist(X, "jaccard")),
+        jaccard_demo_counts=squareform(pdist(counts, "jaccard")),
+        jaccard_float=squareform(pdist(F, "jaccard")),
+        demo_counts_checksum=np.asarray([counts.sum(), (counts > 0).sum(), counts.max()]),
+    )
+    print("g15_hamming_counts.npz written")
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     root = args[0] if args else "/root/reference"
     if "--extra-only" in sys.argv:
         extra(root)
+    elif "--g15-only" in sys.argv:
+        hamming_counts(root)
     else:
         main(root)
+        hamming_counts(root)

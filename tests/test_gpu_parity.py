@@ -215,6 +215,7 @@ def test_vectorize_fasta_writes_reference_formats(ctx, tmp_path):
 
 
 # ------------------------------------------------------------------ a13 / a14 cosine
+@pytest.mark.cosine_paths
 @pytest.mark.parametrize("tag", ["hydro_k14_mf0", "standard_k8_mf0", "red6_k8_mf0", "hydro_k20_mf0", "solvacc_k8_mf0", "None_k3_mf0"])
 def test_cosine_matches_sklearn_goldens(ctx, tag):
     import scipy.sparse as sp
@@ -236,6 +237,7 @@ def test_cosine_matches_sklearn_goldens(ctx, tag):
     assert np.abs(R - g["cosine_rect"]).max() <= COS_TOL
 
 
+@pytest.mark.cosine_paths
 @pytest.mark.parametrize("name,k", [("red6", 12), ("standard", 12), ("hydro", 20)])
 def test_pipeline_matches_synthetic_goldens(ctx, name, k):
     from snekmer_amd import alphabet as A
@@ -254,6 +256,7 @@ def test_pipeline_matches_synthetic_goldens(ctx, name, k):
     assert (S == S2).all()
 
 
+@pytest.mark.cosine_paths
 def test_cosine_medium_vs_oracle_all_modes(ctx):
     from snekmer_amd import alphabet as A
     from snekmer_amd import engine
@@ -297,6 +300,7 @@ def test_cosine_medium_vs_oracle_all_modes(ctx):
     assert np.abs(D - refD).max() <= COS_TOL and (np.diag(D) == 0).all()
 
 
+@pytest.mark.cosine_paths
 def test_connection_matrix_and_feature_matrix_goldens(ctx):
     import snekmer_amd as skm
 
@@ -311,15 +315,57 @@ def test_connection_matrix_and_feature_matrix_goldens(ctx):
     np.fill_diagonal(exp, 0.0)
     assert Df.dtype == np.float64 and np.abs(Df - exp).max() <= 1e-12
     J = skm.score.connection_matrix_from_features(g["X"] > 0)  # default metric="jaccard" (= 1 - hamming upstream)
-    assert np.abs(J - g["jaccard"]).max() <= 1e-6
+    assert J.dtype == np.float64 and np.abs(J - g["jaccard"]).max() <= 1e-12
     J2 = skm.score.connection_matrix_from_features((g["X"] > 0).astype(float), metric="jaccard")
     assert (J2 == J).all()
+    # G15: the DEFAULT call on the input the reference's docstring names, a k-mer count matrix (score.py:149-168),
+    # on the demo FASTA's count matrix (52 x 4941, counts to 13), on real-valued and length-normalised features
+    g15 = gnpz("g15_hamming_counts.npz")
+    assert np.abs(skm.score.connection_matrix_from_features(g["X"]) - g15["default_x"]).max() <= 1e-12
+    g3 = gnpz("g3_demo_hydro_k14_mf0.npz")
+    counts = csr_to_dense(g3["counts_rowptr"], g3["counts_col"], g3["counts_val"], len(g3["kmerlist"]))
+    assert [counts.sum(), (counts > 0).sum(), counts.max()] == g15["demo_counts_checksum"].tolist()
+    H = skm.score.connection_matrix_from_features(counts)
+    assert H.dtype == np.float64 and (H == g15["default_demo_counts"]).all()  # same arithmetic as scipy: equal bits
+    assert (skm.score.connection_matrix_from_features(g15["F"]) == g15["default_float"]).all()
+    Fn = skm.utils.to_feature_matrix([list(r) for r in counts], length_array=g15["demo_lengths"])
+    assert (skm.score.connection_matrix_from_features(Fn) == g15["default_lengthnorm"]).all()
+    assert (skm.score.connection_matrix_from_features(counts, metric="hamming") == 1.0 - g15["default_demo_counts"]).sum() > 0
+    assert np.abs(skm.score.connection_matrix_from_features(counts, metric="hamming") - (1.0 - g15["default_demo_counts"])).max() <= 1e-15
+    # scipy's Jaccard distance on the same non-binary matrices (cluster_cluster.py:189-190 passes binary rows)
+    for key, M in (("jaccard_x", g["X"]), ("jaccard_demo_counts", counts), ("jaccard_float", g15["F"])):
+        assert (skm.score.jaccard_distance(M) == g15[key]).all(), key
     with pytest.raises(NotImplementedError):
-        skm.score.connection_matrix_from_features(g["X"], metric="jaccard")  # non-binary counts
+        skm.score.connection_matrix_from_features(g["X"], metric="chebyshev")
+    with pytest.raises(ValueError):
+        skm.score.connection_matrix_from_features(np.asarray([[1.0, np.nan], [0.0, 1.0]]))
     for case in gjson("g7_feature_matrix.json"):
         rows, kl = skm.vectorize.make_feature_matrix([np.asarray(v, dtype=str) for v in case["vecs"]], case["min_filter"])
         assert [str(x) for x in kl] == case["kmerlist"]
         assert [r.tolist() for r in rows] == case["rows"]
+
+
+@pytest.mark.cosine_paths
+def test_cosine_distance_diagonal_rule_follows_sklearn(ctx):
+    """mode 1 = sklearn's cosine_distances: the diagonal is forced to zero only `if X is Y or Y is None`.  A count
+    matrix and a float matrix with the same values must agree, square and rectangular, on every device path."""
+    from sklearn.metrics.pairwise import cosine_distances
+
+    from snekmer_amd.score import cosine_similarity
+
+    rng = np.random.default_rng(3)
+    X = (rng.random((40, 60)) < 0.2) * rng.integers(1, 9, size=(40, 60))
+    X[5] = 0  # a zero row: distance 1 to everything; its own diagonal cell is 0 only in the square case
+    Y = X[:25].copy()  # other object, same leading rows: cells (i, i) are NOT a diagonal
+    for path in ("sparse", "dense", "auto"):
+        D = cosine_similarity(X, Y, mode=1, ctx=ctx, path=path)
+        assert np.abs(D - cosine_distances(X, Y)).max() <= COS_TOL, path
+        assert D[5, 5] == 1.0  # two zero rows of different matrices
+        for sq in (cosine_similarity(X, None, mode=1, ctx=ctx, path=path), cosine_similarity(X, X, mode=1, ctx=ctx, path=path)):
+            assert np.abs(sq - cosine_distances(X)).max() <= COS_TOL and (np.diag(sq) == 0).all(), path
+    Df = cosine_similarity(X.astype(np.float64) + 0.0, Y * 1.0, mode=1, ctx=ctx, path="f64")
+    assert np.abs(Df - cosine_distances(X, Y)).max() <= 1e-12 and Df[5, 5] == 1.0
+    assert np.abs(Df - cosine_similarity(X, Y, mode=1, ctx=ctx)).max() <= COS_TOL
 
 
 # ------------------------------------------------------------------ BASELINE sizes: properties
@@ -436,6 +482,7 @@ def _check_dense_symmetric(ctx, rng, n, kdim):
     assert (out.download().reshape(out.shape)[:n, :n].astype(np.int64) == G).all()
 
 
+@pytest.mark.cosine_paths
 @pytest.mark.parametrize("name,k", [("hydro", 12), ("solvacc", 7), ("hydro", 14)])
 def test_dense_pipeline_matches_sparse_pipeline_and_oracle(ctx, name, k):
     from snekmer_amd import alphabet as A
@@ -464,6 +511,7 @@ def test_dense_pipeline_matches_sparse_pipeline_and_oracle(ctx, name, k):
 
 
 # ------------------------------------------------------------------ RCCL path, one rank
+@pytest.mark.cosine_paths
 @pytest.mark.parametrize("mode", ["distributed", "replicated"])
 def test_sharded_pipeline_over_rccl_single_rank_equals_pipeline(ctx, mode):
     """The multi-GPU step (count shard -> exchange over RCCL: all-to-all + all-gathers of the
@@ -755,6 +803,7 @@ def test_sharded_pipeline_two_ranks_on_one_gpu_equals_pipeline(ctx, tmp_path, mo
     assert covered == n
 
 
+@pytest.mark.cosine_paths
 def test_overlapped_cosine_schedule_equals_default(ctx, monkeypatch):
     """SKM_COSINE_OVERLAP=1 (row blocks; lists built on one CU-masked stream while the previous block
     is written on another) must give the default schedule's matrix bit for bit."""
@@ -838,6 +887,7 @@ def test_config5_hydro_k20_full_basis_stress(ctx):
 
 
 # ------------------------------------------------------------------ learn/apply chain (next rows)
+@pytest.mark.cosine_paths
 @pytest.mark.parametrize("tag", ["hydro_k14_mf0", "standard_k8_mf0", "solvacc_k8_mf0"])
 def test_group_sum_cosine_vs_totals_and_top2(ctx, tag):
     from snekmer_amd import alphabet as A
@@ -932,6 +982,7 @@ def test_kmerbasis_transform_and_harmonize_match_reference_fixture(ctx):
 
 
 # ------------------------------------------------------------------ degenerate inputs
+@pytest.mark.cosine_paths
 def test_degenerate_batches(ctx):
     from snekmer_amd import alphabet as A
     from snekmer_amd import engine
@@ -968,6 +1019,7 @@ def test_degenerate_batches(ctx):
 
 
 # ------------------------------------------------------------------ real proteome (reference CI data)
+@pytest.mark.cosine_paths
 def test_real_proteome_rule_outputs_and_cosine(ctx):
     """UP000322080 (3 383 proteins, up to 2 478 aa) at the reference's CI config k=8, alphabet 2:
     rule outputs against the reference-generated fixture; cosine through the sparse kernels (every
@@ -1079,6 +1131,7 @@ def test_gram_neighbors_and_topk_vs_oracle(ctx):
         assert np.abs(np.sort(row[got])[::-1] - row[order][: len(got)]).max() <= COS_TOL
 
 
+@pytest.mark.cosine_paths
 def test_jaccard_distance_matches_scipy_golden(ctx):
     """cluster's distance matrix (scripts/cluster_cluster.py:189-190, non-BSF branch)."""
     import snekmer_amd as skm
@@ -1087,7 +1140,7 @@ def test_jaccard_distance_matches_scipy_golden(ctx):
     vecs = np.unpackbits(g3["vecs_bits"], axis=1)[:, : g3["vecs_shape"][1]]
     D = skm.score.jaccard_distance(vecs)
     ref = gnpz("g11_jaccard_demo_hydro_k14.npz")["jaccard_distance"]
-    assert D.shape == ref.shape and np.abs(D - ref).max() <= 1e-6 and (np.diag(D) == 0).all()
+    assert D.shape == ref.shape and np.abs(D - ref).max() <= 1e-15 and (np.diag(D) == 0).all()
     E = skm.score.jaccard_distance(np.zeros((3, 5)))
     assert (E == 0).all()
 
@@ -1179,6 +1232,7 @@ def test_c_abi_error_codes_and_messages(ctx):
     assert lib.skm_create(99, C.byref(out)) == -1 and b"out of range" in lib.skm_last_error()
 
 
+@pytest.mark.cosine_paths
 def test_posting_formats_agree_incl_saturated_counts(ctx):
     """32-bit posting words (row | min(count,255) << 24 + side array for saturated counts) against the
     64-bit form, on a batch with k-mers repeated hundreds of times inside one sequence."""
@@ -1219,6 +1273,7 @@ def test_posting_formats_agree_incl_saturated_counts(ctx):
 
 
 # ------------------------------------------------------------------ f1: fused apply epilogue vs the reference rule body
+@pytest.mark.cosine_paths
 @pytest.mark.parametrize("tag,name,k", [("standard_k12", "standard", 12), ("hydro_k14", "hydro", 14), ("solvacc_k8", "solvacc", 8)])
 def test_apply_epilogue_matches_reference_rule_golden(ctx, tag, name, k):
     """G12: rules/apply.smk:278-328 run with the real sklearn / pandas (tests/golden/make_golden.py) on
@@ -1481,6 +1536,7 @@ def test_config4_one_rank_share_125k_rows_vs_1m(ctx):
 
 
 # ------------------------------------------------------------------ fused vectorize (no host synchronisation)
+@pytest.mark.cosine_paths
 @pytest.mark.parametrize("name,k", [("red6", 12), ("standard", 12), ("hydro", 20), ("hydro", 3), ("hydro", 32)])
 def test_fused_vectorize_equals_the_three_call_form(ctx, name, k):
     """skm_vectorize_csr (count + basis/postings + norms in one call, sizes left on the device) against
@@ -1529,6 +1585,7 @@ def test_fused_vectorize_equals_the_three_call_form(ctx, name, k):
     assert (tail == np.iinfo(tail.dtype).max).all()
 
 
+@pytest.mark.cosine_paths
 @pytest.mark.parametrize("seqs", [["MKV", "", "XXXXXXXXXXXXXXXXXXXX", "*"], ["MKVLAAGIWSTCMKVLAAGIWSTC"],
                                   ["MKVLAAGIWSTCDE", "MKVLAAGIWSTCDE", "XX"]])
 def test_fused_vectorize_degenerate_batches(ctx, seqs):

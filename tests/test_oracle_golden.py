@@ -161,6 +161,20 @@ def test_g9_connection_matrix():
     np.testing.assert_allclose(ref_path.hamming_similarity(g["X"] > 0), g["jaccard"], atol=1e-13)
 
 
+def test_g15_hamming_and_jaccard_on_count_and_real_matrices():
+    """G15: the reference's default connection_matrix_from_features(counts) and scipy's Jaccard distance on
+    non-binary matrices, against the oracle's restatements."""
+    from helpers import csr_to_dense
+
+    g, g15 = gnpz("g9_connection.npz"), gnpz("g15_hamming_counts.npz")
+    g3 = gnpz("g3_demo_hydro_k14_mf0.npz")
+    counts = csr_to_dense(g3["counts_rowptr"], g3["counts_col"], g3["counts_val"], len(g3["kmerlist"]))
+    for M, hk, jk in ((g["X"], "default_x", "jaccard_x"), (counts, "default_demo_counts", "jaccard_demo_counts"),
+                      (g15["F"], "default_float", "jaccard_float")):
+        np.testing.assert_allclose(ref_path.hamming_similarity(M), g15[hk], atol=1e-15)
+        np.testing.assert_allclose(ref_path.jaccard_distance(M), g15[jk], atol=1e-15)
+
+
 def test_g10_real_proteome_oracle():
     """The reference's own CI proteome (.test/input_learnapp, k=8, alphabet 2 = solvacc)."""
     g = gnpz("g10_proteome_solvacc_k8.npz")

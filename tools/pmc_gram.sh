@@ -11,7 +11,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" 
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
   [ -n "$PMC_PASSES" ] && [ $i -gt $PMC_PASSES ] && break
-  rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc_gram_${TAG}_$i -o g -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/pmc_gram_${TAG}_$i.err || echo "pass $i failed"
+  rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc_gram_${TAG}_$i -o g -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-live-pmc > /dev/null 2> $R/gpurun_out/pmc_gram_${TAG}_$i.err || echo "pass $i failed"
 done
 echo "== $TAG"
 python3 $R/tools/pmc_summary.py $R/gpurun_out/ k_gram_sparse | awk '/^k_gram_sparse$/{f=1;next} /^k_/{f=0} f'
