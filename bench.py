@@ -615,6 +615,97 @@ def stage_rooflines(ctx, engine, args, pipe, prof, residues_total):
     return out, {"shared_entries": shared, "pairs": pairs}
 
 
+def skewed_workload(ctx, engine, alphabet, args, pipe, line):
+    """The same step on snekmer_amd.synth.synth_skewed (Zipf family sizes up to 5000, log-normal lengths 50-5000,
+    indels, low-complexity inserts) at the benchmark's N: where the kernels tuned on uniform families of 100 fall
+    off.  Parity of this generator's output: tests/test_gpu_parity.py::test_skewed_workload_20k_vs_oracle."""
+    import ctypes as C
+
+    from snekmer_amd.synth import BASE_SEED, synth_skewed
+
+    n = args.n
+    t0 = time.perf_counter()
+    res, off, fam = synth_skewed(n, seed=BASE_SEED + 12)
+    gen_s = time.perf_counter() - t0
+    batch = engine.SeqBatch(ctx, res, off)
+    p = engine.Pipeline(ctx, alphabet.build_lut(args.alphabet), args.k)
+    p.out = pipe.out  # share the 40 GB result buffer
+    for _ in range(2):
+        p.step(batch)
+    ctx.sync()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    reps = 5
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        p.step(batch)
+    ctx.sync()
+    dt = (time.perf_counter() - t1) / reps
+    prof = ctx.profile_dump()
+    ctx.profile_enable(False)
+    st = (C.c_int64 * 3)()
+    ctx.call("skm_cosine_csr_stats", st)
+    lens = np.diff(off)
+    sizes = np.bincount(fam)
+    uniform = line.get("stage_ms_per_step", {})
+    stages = {k: v[1] / reps for k, v in prof.items()}
+    out = {
+        "workload": f"synth_skewed({n}): family sizes Zipf(1.6) 1..{int(sizes.max())} ({len(sizes)} families, "
+                    f"{int((sizes == 1).sum())} singletons), lengths {int(lens.min())}..{int(lens.max())} (median {int(np.median(lens))}), "
+                    f"2 % indels, 5 % low-complexity inserts; {args.alphabet} k={args.k}",
+        "residues": int(off[-1]), "nnz": p.csr.nnz, "basis_columns": p.basis.ncols, "generator_s": gen_s,
+        "ms_per_step": dt * 1e3, "sequences_per_s": n / dt, "residues_per_s": int(off[-1]) / dt,
+        "rows_sent_to_large_table_pass": int(st[0]), "strips_left_to_cursor_kernel": int(st[1]),
+        "neighbour_list_words": int(st[2]),
+        "stage_ms_per_step": stages,
+        "stage_vs_uniform_families": {k: (v / uniform[k] if uniform.get(k) else None) for k, v in stages.items()},
+    }
+    p.out = None
+    return out
+
+
+def api_vectorize_fasta(args, seed):
+    """What a Snekmer user sees: kmerize.vectorize_fasta (the body of rules/kmerize.smk:67-142) on a synthetic FASTA
+    FILE, host time included, split into parse (threaded C reader -> packed residues), device work that produces
+    integers (H2D, counts, basis, first-seen order, count matrix in kmerlist order, D2H), string formatting on the
+    device (reduced sequences and the k-mer strings of the basis as numpy '<U' arrays, D2H) and the compressed
+    .npz write.  SURVEY 8(d): 'parse time reported separately'."""
+    import tempfile
+
+    from snekmer_amd import kmerize
+    from snekmer_amd.synth import synth_families, to_records, write_fasta
+
+    out = {"what": "snekmer_amd.kmerize.vectorize_fasta(path, alphabet, k): FASTA file -> kmerlist / ids / seqs / lengths / "
+                   "CSR counts in kmerlist order (the sparse .npz contract); second call of two", "runs": []}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for n in (10000, 100000):
+            res, off, _ = synth_families(n, args.length, family=100, seed=seed)
+            path = os.path.join(tmp, f"synth_{n}.fasta")
+            write_fasta(path, to_records(res, off))
+            rec = None
+            for rep in range(2):
+                tm = {}
+                t0 = time.perf_counter()
+                r = kmerize.vectorize_fasta(path, args.alphabet, args.k, dense=False, timings=tm)
+                wall = time.perf_counter() - t0
+                rec = {"n": n, "file_bytes": os.path.getsize(path), "basis_columns": int(len(r["kmerlist"])),
+                       "entries": int(len(r["counts_val"])), "parse_s": tm.get("parse_s", 0.0), "pack_s": 0.0,
+                       "gpu_s": tm.get("gpu_s", 0.0), "decode_s": tm.get("decode_s", 0.0), "wall_s_without_write": wall,
+                       "sequences_per_s": n / wall, "residues_per_s": int(off[-1]) / wall,
+                       "result_bytes": int(sum(v.nbytes for v in r.values()))}
+                del r
+            tm = {}
+            t0 = time.perf_counter()
+            kmerize.vectorize_fasta(path, args.alphabet, args.k, sparse_npz_out=os.path.join(tmp, f"out_{n}.npz"), timings=tm)
+            rec["write_s"] = tm.get("write_s", 0.0)
+            rec["npz_bytes"] = os.path.getsize(os.path.join(tmp, f"out_{n}.npz"))
+            rec["sequences_per_s_with_write"] = n / (time.perf_counter() - t0)
+            out["runs"].append(rec)
+            note(f"api_vectorize_fasta n={n}: {rec['sequences_per_s']:.0f} seq/s without the write "
+                 f"(parse {rec['parse_s']:.3f} gpu {rec['gpu_s']:.3f} decode {rec['decode_s']:.3f} s), write {rec['write_s']:.1f} s")
+    return out
+
+
 def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed):
     """Measurements taken after the timed region, on the same GPU in the same run."""
     import ctypes as C
@@ -676,6 +767,11 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
         }
         pipe7.out = None
         del pipe7
+
+    line["skewed_workload"] = skewed_workload(ctx, engine, alphabet, args, pipe, line)
+    note("extras: skewed_workload")
+    line["api_vectorize_fasta"] = api_vectorize_fasta(args, seed)
+    note("extras: api_vectorize_fasta")
 
     # BASELINE configs[1]: 10k sequences, same alphabet and k
     res2, off2, _ = synth_families(10000, args.length, family=100, seed=BASE_SEED + 1)

@@ -220,6 +220,11 @@ int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint
                    const float *d_yrnorm, int64_t row0, int64_t row1, int mode, float *d_out,
                    int64_t ld);
 
+/* Reporting only: how the last neighbour-list skm_cosine_csr call of this context distributed its rows.
+ * h_out3[0] = rows whose neighbours overflowed the first pass's table (large-table pass), [1] = 8-row strips left
+ * to the cursor kernel, [2] = neighbour-list words in use (fixed slots included).  Synchronises the stream. */
+int skm_cosine_csr_stats(skm_ctx *ctx, int64_t *h_out3);
+
 /* The reference's metric="jaccard" branch (snekmer/score.py:166-168) is 1 - hamming distance on the
  * binary presence matrix: 1 - (|a| + |b| - 2|a&b|) / ncols.  Given d_out holding the exact
  * intersection sizes |a&b| (skm_cosine_csr on a 0/1 CSR with all norms = 1), rewrite it in place.
@@ -425,6 +430,41 @@ int skm_colidx_lookup(skm_ctx *ctx, int code_bits, int nbuckets, int64_t nnz, co
  * are the local shard (d_local[nloc + 1]): lets skm_cosine_csr / skm_gram_neighbors run on a shard
  * with global row numbers. */
 int skm_embed_rowptr(skm_ctx *ctx, int64_t n_total, int64_t lo, int64_t nloc, const int64_t *d_local, int64_t *d_rowptr);
+
+/* ---- data formats either side of the path ---------------------------- *
+ * HOST functions, no GPU and no context: a threaded FASTA reader replacing the
+ * `for f in SeqIO.parse(fasta, "fasta")` loops of snekmer/rules/kmerize.smk:90-129.  Biopython's
+ * SimpleFastaParser semantics on a text-mode handle: lines end at "\n", "\r\n" or a lone "\r"; text before the
+ * first line starting with '>' is skipped; id = first whitespace-delimited word of the header ("" if none); the
+ * sequence = the record's lines, each without trailing whitespace, joined, with every ' ' and '\r' removed.
+ * skm_fasta_index sizes the outputs; *out_flags bit 0 = the buffer holds bytes >= 0x80 (a text handle would
+ * decode them as UTF-8: the caller must take its text-mode path).  nthreads < 1 = all hardware threads.
+ * skm_fasta_parse fills h_out_residues[nresidues] (records back to back), h_out_offsets[nrecords + 1] and the byte
+ * span of every id inside h_buf. */
+int skm_fasta_index(const uint8_t *h_buf, int64_t len, int nthreads, int64_t *out_nrecords, int64_t *out_nresidues,
+                    int *out_flags);
+int skm_fasta_parse(const uint8_t *h_buf, int64_t len, int nthreads, int64_t nrecords, int64_t nresidues,
+                    uint8_t *h_out_residues, int64_t *h_out_offsets, int64_t *h_out_id_begin, int32_t *h_out_id_len);
+
+/* Ragged byte rows -> fixed-width UCS-4 rows, zero padded: d_out[i * width + j] = d_bytes[d_off[i] + j] for
+ * j < d_len[i].  Viewed as numpy '<U{width}' this is the `seqs` array of reduced strings the rule stores
+ * (snekmer/rules/kmerize.smk:121-127,136) without a per-record Python string (bytes are latin-1 code points). */
+int skm_rows_to_utf32(skm_ctx *ctx, const uint8_t *d_bytes, const int64_t *d_off, const int32_t *d_len, int64_t n,
+                      int64_t width, uint32_t *d_out);
+
+/* Integer k-mer codes -> k class letters each, UCS-4 (numpy '<U{k}'): the `kmerlist` array of the rule
+ * (snekmer/rules/kmerize.smk:102-106,134).  h_letters[nsym]: class letters in rank order; d_index (optional)
+ * selects and orders the codes: d_out[i] = letters of d_codes[d_index[i]] (first-seen order, min_filter). */
+int skm_decode_kmers_utf32(skm_ctx *ctx, int code_bits, int nsym, int k, const uint8_t *h_letters, const void *d_codes,
+                           const uint32_t *d_index, int64_t n, uint32_t *d_out);
+
+/* The count matrix in `kmerlist` column order (what snekmer/rules/learn.smk:359-383 rebuilds per sequence in
+ * Python): every CSR entry's column id c becomes d_colmap[c]; entries whose column maps to 0xFFFFFFFF (filtered
+ * by min_filter, or absent from an explicit basis) or whose id is >= ncols are dropped; order within a row is
+ * kept.  d_out_rowptr[n + 1]; d_out_col / d_out_val sized for the input's entry count.  Host-synchronous. */
+int skm_csr_remap_columns(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const uint32_t *d_colidx,
+                          const uint32_t *d_counts, const uint32_t *d_colmap, int64_t ncols, int64_t *d_out_rowptr,
+                          uint32_t *d_out_col, uint32_t *d_out_val, int64_t *h_out_nnz);
 
 #ifdef __cplusplus
 }

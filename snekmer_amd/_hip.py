@@ -90,6 +90,7 @@ _SIGNATURES = {
         [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, C.c_int, _p, _p, _i64, _i64, C.c_int, _p, _i64],
     ),
     "skm_hamming_similarity_from_gram": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _i64]),
+    "skm_cosine_csr_stats": (C.c_int, [_p, _p]),
     "skm_setsim_f64": (C.c_int, [_p, C.c_int, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _p, _i64]),
     "skm_row_top2": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p]),
     "skm_csr_group_sum": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _p, _p, C.POINTER(_i64)]),
@@ -104,6 +105,11 @@ _SIGNATURES = {
     "skm_cosine_dense_f64": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, C.c_int, _p, _i64]),
     "skm_matrix_row_stats": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p]),
     "skm_apply_top2": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p]),
+    "skm_fasta_index": (C.c_int, [_p, _i64, C.c_int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_int)]),
+    "skm_fasta_parse": (C.c_int, [_p, _i64, C.c_int, _i64, _i64, _p, _p, _p, _p]),
+    "skm_rows_to_utf32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p]),
+    "skm_decode_kmers_utf32": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p, _p, _p, _i64, _p]),
+    "skm_csr_remap_columns": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _p, _p, _p, C.POINTER(_i64)]),
     "skm_comm_unique_id": (C.c_int, [_p]),
     "skm_comm_init": (C.c_int, [_p, C.c_int, C.c_int, _p]),
     "skm_comm_destroy": (C.c_int, [_p]),

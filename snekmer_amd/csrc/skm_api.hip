@@ -6,18 +6,7 @@
 
 #include "skm_common.h"
 
-static thread_local char g_err[1024] = "";
-
-void skm_set_error(const char *fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-}
-
 extern "C" int skm_abi_version(void) { return SKM_ABI_VERSION; }
-extern "C" const char *skm_last_error(void) { return g_err; }
 
 extern "C" int skm_device_count(int *h_count)
 {

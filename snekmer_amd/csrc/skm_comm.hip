@@ -247,55 +247,7 @@ extern "C" int skm_alltoallv(skm_ctx *ctx, const void *d_send, const int64_t *h_
 // piece lands at its final offset (no padded scratch, no unpack pass).  The byte ranges come from two
 // pure host functions, exported so that tests can execute the same plan without RCCL.
 
-extern "C" int skm_plan_alltoallv(int nranks, int narrays, const int64_t *h_elem_bytes, const int64_t *h_send_counts,
-                                  const int64_t *h_recv_counts, skm_p2p_op *out_ops)
-{
-    SKM_REQUIRE(nranks >= 1 && nranks <= SKM_MAX_RANKS && narrays >= 1 && narrays <= SKM_MAX_ARRAYS && h_elem_bytes &&
-                    h_send_counts && h_recv_counts && out_ops,
-                SKM_E_BADARG, "skm_plan_alltoallv: bad argument");
-    for (int a = 0; a < narrays; ++a) {
-        SKM_REQUIRE(h_elem_bytes[a] > 0, SKM_E_BADARG, "skm_plan_alltoallv: element size of array %d", a);
-        int64_t soff = 0, roff = 0;
-        for (int p = 0; p < nranks; ++p) {
-            SKM_REQUIRE(h_send_counts[p] >= 0 && h_recv_counts[p] >= 0, SKM_E_BADARG, "skm_plan_alltoallv: negative count for rank %d", p);
-            skm_p2p_op &op = out_ops[p * narrays + a];
-            op.peer = p;
-            op.array = a;
-            op.send_off = soff;
-            op.send_bytes = h_send_counts[p] * h_elem_bytes[a];
-            op.recv_off = roff;
-            op.recv_bytes = h_recv_counts[p] * h_elem_bytes[a];
-            soff += op.send_bytes;
-            roff += op.recv_bytes;
-        }
-    }
-    return SKM_OK;
-}
-
-extern "C" int skm_plan_allgatherv(int nranks, int rank, int narrays, const int64_t *h_elem_bytes, const int64_t *h_counts,
-                                   skm_p2p_op *out_ops)
-{
-    SKM_REQUIRE(nranks >= 1 && nranks <= SKM_MAX_RANKS && rank >= 0 && rank < nranks && narrays >= 1 &&
-                    narrays <= SKM_MAX_ARRAYS && h_elem_bytes && h_counts && out_ops,
-                SKM_E_BADARG, "skm_plan_allgatherv: bad argument");
-    for (int a = 0; a < narrays; ++a) {
-        SKM_REQUIRE(h_elem_bytes[a] > 0, SKM_E_BADARG, "skm_plan_allgatherv: element size of array %d", a);
-        int64_t roff = 0;
-        for (int p = 0; p < nranks; ++p) {
-            const int64_t cnt = h_counts[a * nranks + p];
-            SKM_REQUIRE(cnt >= 0, SKM_E_BADARG, "skm_plan_allgatherv: negative count (array %d, rank %d)", a, p);
-            skm_p2p_op &op = out_ops[p * narrays + a];
-            op.peer = p;
-            op.array = a;
-            op.send_off = 0;  // every peer gets this rank's whole contribution
-            op.send_bytes = h_counts[a * nranks + rank] * h_elem_bytes[a];
-            op.recv_off = roff;
-            op.recv_bytes = cnt * h_elem_bytes[a];
-            roff += op.recv_bytes;
-        }
-    }
-    return SKM_OK;
-}
+// (skm_plan_alltoallv / skm_plan_allgatherv: skm_host.cpp)
 
 namespace {
 // Executes a plan: the self pieces are device copies, the rest one RCCL group.

@@ -8,9 +8,7 @@
 #include <string>
 #include <vector>
 
-#include "snekmer_hip.h"
-
-void skm_set_error(const char *fmt, ...);
+#include "skm_host.h"
 
 #define SKM_HIP(expr)                                                                        \
     do {                                                                                     \
@@ -19,21 +17,6 @@ void skm_set_error(const char *fmt, ...);
             skm_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
             return SKM_E_HIP;                                                                \
         }                                                                                    \
-    } while (0)
-
-#define SKM_REQUIRE(cond, code, ...)   \
-    do {                               \
-        if (!(cond)) {                 \
-            skm_set_error(__VA_ARGS__); \
-            return (code);             \
-        }                              \
-    } while (0)
-
-#define SKM_TRY(expr)          \
-    do {                       \
-        int _s = (expr);       \
-        if (_s != SKM_OK)      \
-            return _s;         \
     } while (0)
 
 // Grow-only scratch slots.  Every entry point draws its temporaries from fixed slots so that,

@@ -1027,6 +1027,32 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
 }
 }  // namespace
 
+// How the last list-path skm_cosine_csr call on this context distributed its rows (reporting only: bench.py's skewed
+// workload): h_out[0] = rows whose neighbours did not fit the first pass's table (sent to the large-table pass),
+// h_out[1] = 8-row strips left to the cursor kernel (a row overflowed the large table too), h_out[2] = neighbour-list
+// entries written.  Synchronises the stream.
+extern "C" int skm_cosine_csr_stats(skm_ctx *ctx, int64_t *h_out3)
+{
+    SKM_REQUIRE(ctx && h_out3, SKM_E_BADARG, "skm_cosine_csr_stats: bad argument");
+    h_out3[0] = h_out3[1] = h_out3[2] = 0;
+    if (!ctx->ws[WS_SMALL] || ctx->ws_bytes[WS_SMALL] < 4096)
+        return SKM_OK;
+    SKM_HIP(hipSetDevice(ctx->device));
+    uint8_t host[16 + 4 * 16];
+    SKM_HIP(hipMemcpyAsync(host, (uint8_t *)ctx->ws[WS_SMALL] + 2048, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    SKM_HIP(hipStreamSynchronize(ctx->stream));
+    unsigned long long ent;
+    uint32_t fb, over[16];
+    memcpy(&ent, host, 8);
+    memcpy(&fb, host + 8, 4);
+    memcpy(over, host + 12, sizeof(over));
+    for (int b = 0; b < 16; ++b)
+        h_out3[0] += over[b];
+    h_out3[1] = fb;
+    h_out3[2] = (int64_t)ent;
+    return SKM_OK;
+}
+
 namespace {
 __global__ __launch_bounds__(256) void k_similarity_to_distance(int64_t rows, int64_t m, float *__restrict__ out, int64_t ld)
 {

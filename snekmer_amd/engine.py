@@ -390,6 +390,47 @@ def cosine_matrix(ctx, x: CountsCSR, x_rnorm, m: int, ncols: int, colptr, post, 
     return out
 
 
+def reduced_strings(ctx, batch: SeqBatch, lut: AlphabetLUT, timings: Optional[dict] = None) -> np.ndarray:
+    """a3 for a whole batch as the numpy '<U{w}' array the rule stores (`seqs`, rules/kmerize.smk:121-127,136): the
+    recoded bytes become UCS-4 rows on the device (skm_rows_to_utf32), no per-record Python string."""
+    n = batch.n
+    if n == 0:
+        return np.array([], dtype=str)
+    d_bytes = ctx.empty(batch.total + 64, np.uint8)
+    d_len = ctx.empty(n, np.int32)
+    ctx.call("skm_recode", _ptr(lut.translate), _ptr(batch.d_seq), _ptr(batch.d_off), _i64(n), _ptr(d_bytes), _ptr(d_len))
+    width = max(int(d_len.download(n).max()), 1)  # numpy's width for all-empty strings is 1
+    d_out = ctx.empty((n, width), np.uint32)
+    ctx.call("skm_rows_to_utf32", _ptr(d_bytes), _ptr(batch.d_off), _ptr(d_len), _i64(n), _i64(width), _ptr(d_out))
+    return d_out.download().reshape(n, width).view(f"<U{width}").ravel()
+
+
+def decode_kmers(ctx, lut: AlphabetLUT, k: int, d_codes, count: int, d_index=None) -> np.ndarray:
+    """Codes resident on the device -> numpy '<U{k}' k-mer strings (skm_decode_kmers_utf32); `d_index` (uint32, device)
+    selects and orders them."""
+    if count == 0:
+        return np.array([], dtype=str)
+    letters = np.frombuffer(lut.letters.encode("latin-1"), dtype=np.uint8)
+    bits = 32 if np.dtype(d_codes.dtype).itemsize == 4 else 64
+    d_out = ctx.empty((count, k), np.uint32)
+    ctx.call("skm_decode_kmers_utf32", bits, lut.nsym, k, _ptr(letters), _ptr(d_codes), _ptr(d_index), _i64(count), _ptr(d_out))
+    return d_out.download().reshape(count, k).view(f"<U{k}").ravel()
+
+
+def csr_remap_columns(ctx, csr: CountsCSR, d_colmap, ncols: int):
+    """(rowptr int64[n+1], col uint32[nnz'], val uint32[nnz']) on the host: the entries of `csr` whose column maps
+    through `d_colmap` to a real column, re-labelled, row order kept (skm_csr_remap_columns)."""
+    n = csr.n
+    cap = max(csr.nnz, 1)
+    d_rowptr = ctx.empty(n + 1, np.int64)
+    d_col, d_val = ctx.empty(cap, np.uint32), ctx.empty(cap, np.uint32)
+    nnz = _i64(0)
+    ctx.call("skm_csr_remap_columns", _i64(n), _ptr(csr.rowptr), _ptr(csr.colidx), _ptr(csr.counts), _ptr(d_colmap), _i64(ncols),
+             _ptr(d_rowptr), _ptr(d_col), _ptr(d_val), C.byref(nnz))
+    nz = int(nnz.value)
+    return d_rowptr.download(n + 1), d_col.download(nz), d_val.download(nz)
+
+
 def csr_to_dense(ctx, n: int, rowptr, colidx, counts, ncols_out: int, colmap=None, presence: bool = False,
                  dtype=np.float64) -> _hip.DeviceArray:
     code = {np.dtype(np.float64): 0, np.dtype(np.float32): 1, np.dtype(np.int8): 2}[np.dtype(dtype)]

@@ -13,24 +13,66 @@ from typing import Dict, List, Tuple
 import numpy as np
 
 
+_SPACE = " \t\n\r\x0b\x0c\x1c\x1d\x1e\x1f"
+
+
 def read_fasta(path: str) -> List[Tuple[str, str]]:
-    """(id, sequence) per record: id = header up to the first whitespace."""
+    """(id, sequence) per record, as ``Bio.SeqIO.parse(path, "fasta")`` yields ``record.id`` / ``str(record.seq)``
+    (Biopython's SimpleFastaParser: text before the first '>' line is skipped; id = first word of the header; the
+    sequence = the record's lines without their trailing whitespace, joined, with every space and '\\r' removed).
+    Text-mode reference implementation; `read_fasta_packed` is the fast form."""
     records: List[Tuple[str, str]] = []
     name, chunks = None, []
     with open(path) as fh:
         for line in fh:
-            line = line.rstrip("\r\n")
             if line.startswith(">"):
                 if name is not None:
-                    records.append((name, "".join(chunks)))
-                header = line[1:].split()
+                    records.append((name, "".join(chunks).replace(" ", "").replace("\r", "")))
+                header = line[1:].split(None, 1)
                 name = header[0] if header else ""
                 chunks = []
             elif name is not None:
-                chunks.append(line.strip())
+                chunks.append(line.rstrip())
     if name is not None:
-        records.append((name, "".join(chunks)))
+        records.append((name, "".join(chunks).replace(" ", "").replace("\r", "")))
     return records
+
+
+def read_fasta_packed(path: str, threads: int = 0):
+    """FASTA file -> (ids '<U' array, residues uint8[total], offsets int64[n+1]): the packed layout the device entry
+    points take, produced by the C library's threaded reader (skm_fasta_index / skm_fasta_parse: host code, no GPU)
+    instead of a per-record Python loop.  Same records as `read_fasta`; files with non-ASCII bytes (which a text
+    handle decodes as UTF-8) take the text-mode path."""
+    import ctypes as C
+
+    from . import _hip
+    from .utils import pack_sequences
+
+    lib = _hip.load_library()
+    with open(path, "rb") as fh:
+        buf = np.frombuffer(fh.read(), dtype=np.uint8)
+    p = C.c_void_p
+    nrec, nres, flags = C.c_int64(0), C.c_int64(0), C.c_int(0)
+    _hip._check(lib, lib.skm_fasta_index(buf.ctypes.data_as(p), buf.size, threads, C.byref(nrec), C.byref(nres), C.byref(flags)))
+    if flags.value & 1:
+        recs = read_fasta(path)
+        res, off = pack_sequences([s for _, s in recs])
+        return (np.asarray([r[0] for r in recs], dtype=str) if recs else np.array([], dtype=str)), res, off
+    n = nrec.value
+    res = np.empty(nres.value, dtype=np.uint8)
+    off = np.zeros(n + 1, dtype=np.int64)
+    idb, idl = np.zeros(max(n, 1), dtype=np.int64), np.zeros(max(n, 1), dtype=np.int32)
+    _hip._check(lib, lib.skm_fasta_parse(buf.ctypes.data_as(p), buf.size, threads, n, nres.value, res.ctypes.data_as(p),
+                                         off.ctypes.data_as(p), idb.ctypes.data_as(p), idl.ctypes.data_as(p)))
+    if n == 0:
+        return np.array([], dtype=str), res, off
+    idb, idl = idb[:n], idl[:n]
+    width = max(int(idl.max()), 1)
+    # ids as a '<U{width}' array: gather the spans into a zero-padded UCS-4 matrix (ASCII bytes are code points)
+    cols = np.arange(width, dtype=np.int64)
+    take = np.minimum(idb[:, None] + cols[None, :], max(buf.size - 1, 0))
+    ids = np.where(cols[None, :] < idl[:, None], buf[take] if buf.size else 0, 0).astype(np.uint32)
+    return np.ascontiguousarray(ids).view(f"<U{width}").ravel(), res, off
 
 
 def read_kmers(filename: str) -> List[str]:

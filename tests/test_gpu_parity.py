@@ -829,22 +829,22 @@ def test_overlapped_cosine_schedule_equals_default(ctx, monkeypatch):
 
 
 # ------------------------------------------------------------------ BASELINE full sizes
-def _sampled_row_check(ctx, name, k, n, seed_idx, nsample=48, family=100, full_stats=False):
+def _sampled_row_check(ctx, name, k, n, seed_idx, nsample=48, family=100, full_stats=False, packed=None):
     from snekmer_amd import alphabet as A
     from snekmer_amd import engine
     from snekmer_amd.synth import synth_families
 
     orc = _oracle()
     lut = A.build_lut(name)
-    res, off, fam = synth_families(n, 300, family=family, seed=20250523 + seed_idx)
+    res, off = packed if packed is not None else synth_families(n, 300, family=family, seed=20250523 + seed_idx)[:2]
     batch = engine.SeqBatch(ctx, res, off)
     pipe = engine.Pipeline(ctx, lut, k)
     out = pipe.step(batch)
     ld = out.shape[1]
-    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off, threads=0)
     rowptr, codes, counts, _ = pipe.csr.host()
     assert (rowptr == o_rowptr).all() and (codes.astype(np.uint64) == o_codes).all() and (counts == o_counts).all()
-    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
+    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first, threads=0)
     assert pipe.basis.ncols == len(ob)
     # Pipeline elides k-mers seen in one sequence only: their entries carry 0xFFFFFFFF
     exp_col = np.where(odf[ocol] > 1, ocol, np.uint32(0xFFFFFFFF))
@@ -868,6 +868,19 @@ def _sampled_row_check(ctx, name, k, n, seed_idx, nsample=48, family=100, full_s
         assert np.abs(rowsum - o_sum).max() <= 2e-6 * max(1.0, float(o_sum.max()))
         assert abs(float(rowsum.sum()) - float(o_sum.sum())) <= 1e-6 * float(o_sum.sum())
     return pipe
+
+
+@pytest.mark.parametrize("name,k", [("red6", 12), ("standard", 12), ("hydro", 14)])
+def test_skewed_workload_20k_vs_oracle(ctx, name, k):
+    """synth_skewed: Zipf family sizes up to 5000 (rows with thousands of neighbours: the neighbour-list slots
+    overflow into the large-table pass and the cursor kernel), log-normal lengths 50-5000 (every count kernel size
+    class), indels, low-complexity runs (counts > 1, long posting lists).  Counts, basis and column ids bit-exact
+    against the C oracle, sampled rows <= 1e-5, and the whole matrix's per-row non-zero counts and row sums."""
+    from snekmer_amd.synth import synth_skewed
+
+    res, off, fam = synth_skewed(20000, seed=20250523 + 11)
+    assert np.bincount(fam).max() == 5000 and np.diff(off).max() > 1500
+    _sampled_row_check(ctx, name, k, 20000, seed_idx=11, nsample=64, full_stats=True, packed=(res, off))
 
 
 def test_config3_full_size_100k_red6_k12(ctx):

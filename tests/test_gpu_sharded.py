@@ -4,11 +4,13 @@ byte plans with device copies.  The reference has no distributed layer (one Snak
 snekmer/rules/kmerize.smk:57-65); the bar is bit-identity with the single-GPU pipeline, which the parity suite pins
 against the oracle at the same sizes (test_gpu_parity.py: config 3 and config 4).
 """
+import sys
+
 import numpy as np
 import pytest
 
 from helpers import ensure_red6
-from inproc_world import run_world
+from inproc_world import progress, run_world
 
 pytestmark = pytest.mark.gpu
 
@@ -128,11 +130,17 @@ def test_config4_sharded_code_path_8_ranks_1m_sequences(ctx):
         pytest.skip("needs ~120 GB of HBM (8 ranks' buffers on one device)")
     lut, k, n, world, topk = A.build_lut("red6"), 12, 1_000_000, 8, 10
     check = (0, 3, 7)
+    import faulthandler
+
+    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)  # a stuck run says where (pytest shows stderr on failure)
+    progress("config 4: generating 1 M sequences")
     res, off, _ = synth_families(n, 300, family=100, seed=20250523 + 3)
     bounds = shard_bounds(n, world)
 
     def extra(rank, rctx, sp, shard):
+        progress("shard resident; step_topk")
         idx, val, nb = sp.step_topk(shard, topk, cap_entries=(bounds[rank][1] - bounds[rank][0]) * 4000)
+        progress(f"step_topk done: {sp.sizes}")
         out = {"nnz": sp.nnz_total, "ncols": sp.basis.ncols, "shared": sp.basis.ncols_shared, "local_nnz": sp.local.nnz,
                "overflow": nb.overflow_rows, "entries": nb.total}
         if rank in check:
@@ -140,6 +148,7 @@ def test_config4_sharded_code_path_8_ranks_1m_sequences(ctx):
         return out
 
     results, tw = _run_sharded(world, lut, k, res, off, bounds, extra)
+    progress("8 ranks done; single-GPU reference")
     ref = engine.Pipeline(ctx, lut, k)
     ref.vectorize(engine.SeqBatch(ctx, res, off))
     b = ref.basis
@@ -160,6 +169,8 @@ def test_config4_sharded_code_path_8_ranks_1m_sequences(ctx):
         idx, val = engine.neighbors_topk(ctx, nb, ref.rnorm, ref.rnorm, topk, exclude_self=True)
         _assert_topk_equal(idx, val, r["idx"], r["val"])
         del nb
+        progress(f"rank {rank}'s block equal")
+    faulthandler.cancel_dump_traceback_later()
     # the exchange moved what the design says it moves: every entry once (12 B, 7/8 of them off-rank) in the
     # all-to-all, then 7 copies of every owner's arrays in the all-gather
     assert tw.bytes_moved > ref.csr.nnz * 12 * 7 // 8
