@@ -143,14 +143,18 @@ int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int flags, int64_
                     uint64_t *d_total, uint64_t *d_firstkey, uint32_t *d_fs_order,
                     uint32_t *d_colptr, void *d_post, uint32_t *d_postcnt);
 
-/* The whole pre-cosine path of the square cosine in ONE call that never waits for the device: skm_count_csr +
+/* The whole pre-cosine path of the square cosine in ONE call with no data-dependent read-back: skm_count_csr +
  * skm_basis_build(SKM_BASIS_ELIDE_SINGLETONS, postings) + skm_row_norms_csr, i.e. the body of
  * rules/kmerize.smk:89-104 + rules/learn.smk:359-383 as the cosine stage needs it.  Sizes that depend on the data stay
  * on the device: the entry count is d_rowptr[n], the number of basis columns *d_ncols (device int64); every launch is
  * sized by total_residues.  Outputs as documented for the three calls it replaces, capacity cap_entries >
  * total_residues each (d_colptr: cap_entries + 1); d_codes past the entry count is filled with the all-ones sentinel;
- * d_rnorm / d_normsq are optional.  Nothing here is host-synchronous: read d_rowptr[n] / *d_ncols with
- * skm_memcpy_d2h when the host needs them.  n >= 1 and total_residues >= 1. */
+ * d_rnorm / d_normsq are optional.  No result is read back (read d_rowptr[n] / *d_ncols with skm_memcpy_d2h when the
+ * host needs them).  ONE host wait remains per call: the 28-byte size-class histogram of the sequences (which count
+ * kernels to launch for sequences of more than 512 windows) is awaited on an event recorded right behind the
+ * classification kernel, after the common-case count kernel has been queued; the event is stream-ordered, so a
+ * caller that queued other work on this context before the call waits for that work too.  n >= 1 and
+ * total_residues >= 1. */
 int skm_vectorize_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits, const uint8_t *d_seq,
                       const int64_t *d_off, int64_t n, int64_t total_residues, int64_t cap_entries, int64_t *d_rowptr,
                       void *d_codes, uint32_t *d_counts, void *d_basis, uint32_t *d_colidx, uint32_t *d_colptr,
@@ -193,6 +197,10 @@ int skm_widen_i8_u32(skm_ctx *ctx, int64_t count, const int8_t *d_in, uint32_t *
 
 /* Largest count in a CSR (host-synchronous): the int8 dense path needs it to be <= 127. */
 int skm_csr_max_count(skm_ctx *ctx, int64_t nnz, const uint32_t *d_counts, uint32_t *h_max);
+/* The same without a host wait: the largest count among the entries [0, d_rowptr[n]) is left in *d_out_max (device);
+ * cap_entries bounds the launch.  For callers that must not stall between stages (engine.DensePipeline). */
+int skm_csr_max_count_dev(skm_ctx *ctx, int64_t n, int64_t cap_entries, const int64_t *d_rowptr, const uint32_t *d_counts,
+                          uint32_t *d_out_max);
 
 /* ---- a13/a14: cosine ----------------------------------------------------------------------- */
 /* 1/||row|| (float32; 1.0 for an all-zero row, as sklearn's normalize does) and optionally the

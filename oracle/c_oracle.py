@@ -23,7 +23,8 @@ def build() -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        # SKM_ORACLE_LIB: another build of the same source (the -fsanitize build of `make -C oracle asan`)
+        _LIB = C.CDLL(os.environ.get("SKM_ORACLE_LIB") or build())
         _LIB.orc_count_csr.restype = C.c_int64
         _LIB.orc_basis.restype = C.c_int64
         _LIB.orc_count_csr_mt.restype = C.c_int64

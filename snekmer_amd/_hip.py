@@ -84,6 +84,7 @@ _SIGNATURES = {
     "skm_widen_u8_u32": (C.c_int, [_p, _i64, _p, _p]),
     "skm_widen_i8_u32": (C.c_int, [_p, _i64, _p, _p]),
     "skm_csr_max_count": (C.c_int, [_p, _i64, _p, C.POINTER(C.c_uint32)]),
+    "skm_csr_max_count_dev": (C.c_int, [_p, _i64, _i64, _p, _p, _p]),
     "skm_row_norms_csr": (C.c_int, [_p, _i64, _p, _p, _p, _p]),
     "skm_cosine_csr": (
         C.c_int,

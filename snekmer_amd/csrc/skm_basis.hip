@@ -304,6 +304,21 @@ __global__ void k_max_u32(int64_t n, const uint32_t *__restrict__ v, unsigned in
         atomicMax(out, mx);
 }
 
+// the same over the entries [0, rowptr[n]) of a CSR whose entry count only the device knows
+__global__ void k_max_u32_dev(const int64_t *__restrict__ rowptr, int64_t n, const uint32_t *__restrict__ v, unsigned int *out)
+{
+    const int64_t nnz = rowptr[n];
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned int mx = 0;
+    for (; i < nnz; i += stride)
+        mx = max(mx, v[i]);
+    for (int o = 32; o > 0; o >>= 1)
+        mx = max(mx, (unsigned int)__shfl_down(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx)
+        atomicMax(out, mx);
+}
+
 __global__ void k_pair_work(int64_t ncols, const uint32_t *__restrict__ colptr, unsigned long long *out)
 {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -976,6 +991,19 @@ extern "C" int skm_csr_max_count(skm_ctx *ctx, int64_t nnz, const uint32_t *d_co
     SKM_HIP(hipStreamSynchronize(ctx->stream));
     *h_max = *(uint32_t *)ctx->h_pinned;
     return SKM_OK;
+}
+
+extern "C" int skm_csr_max_count_dev(skm_ctx *ctx, int64_t n, int64_t cap_entries, const int64_t *d_rowptr,
+                                     const uint32_t *d_counts, uint32_t *d_out_max)
+{
+    SKM_REQUIRE(ctx && n >= 0 && cap_entries >= 0 && d_rowptr && d_out_max, SKM_E_BADARG, "skm_csr_max_count_dev: bad argument");
+    SKM_HIP(hipSetDevice(ctx->device));
+    SKM_HIP(hipMemsetAsync(d_out_max, 0, 4, ctx->stream));
+    if (cap_entries == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_counts, SKM_E_BADARG, "skm_csr_max_count_dev: null counts");
+    k_max_u32_dev<<<skm_grid_cap(ctx, skm_ceil_div(cap_entries, BLK), 8), BLK, 0, ctx->stream>>>(d_rowptr, n, d_counts, d_out_max);
+    return skm_check_launch("k_max_u32_dev");
 }
 
 extern "C" int skm_pair_work(skm_ctx *ctx, int64_t ncols, const uint32_t *d_colptr, uint64_t *h_pairs)

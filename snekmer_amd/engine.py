@@ -80,8 +80,8 @@ class CountsCSR:
     def code_dtype(self):
         return np.uint32 if self.code_bits == 32 else np.uint64
 
-    # The entry count may live on the device only (vectorize_fused leaves it in rowptr[n] and never waits for
-    # the GPU): it is fetched, once, when the host first asks for it.
+    # The entry count may live on the device only (vectorize_fused leaves it in rowptr[n] and reads no result
+    # back): it is fetched, once, when the host first asks for it.
     @property
     def nnz(self) -> int:
         if self._nnz is None:
@@ -295,9 +295,11 @@ def build_basis(ctx, csr: CountsCSR, nsym: int, k: int, stats: bool = False, fir
 
 def vectorize_fused(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int, csr: Optional[CountsCSR] = None,
                     basis: Optional[Basis] = None, rnorm=None):
-    """count_csr + build_basis(elide_singletons, postings) + row_norms in one call that never waits for the GPU
+    """count_csr + build_basis(elide_singletons, postings) + row_norms in one call that reads no result back
     (skm_vectorize_csr): sizes that depend on the data (entry count, number of columns) stay on the device and are
-    fetched lazily by `CountsCSR.nnz` / `Basis.ncols`.  Returns (csr, basis, rnorm); pass the previous ones to reuse
+    fetched lazily by `CountsCSR.nnz` / `Basis.ncols`.  One host wait per call remains inside the library (the
+    sequences' size-class histogram, awaited behind the classification kernel: include/snekmer_hip.h), so the host
+    runs at most one step ahead of the device.  Returns (csr, basis, rnorm); pass the previous ones to reuse
     their buffers."""
     if batch.n < 1 or batch.total < 1:
         raise ValueError("vectorize_fused needs a non-empty batch")
@@ -432,9 +434,10 @@ def csr_remap_columns(ctx, csr: CountsCSR, d_colmap, ncols: int):
 
 
 def csr_to_dense(ctx, n: int, rowptr, colidx, counts, ncols_out: int, colmap=None, presence: bool = False,
-                 dtype=np.float64) -> _hip.DeviceArray:
+                 dtype=np.float64, out=None) -> _hip.DeviceArray:
     code = {np.dtype(np.float64): 0, np.dtype(np.float32): 1, np.dtype(np.int8): 2}[np.dtype(dtype)]
-    out = ctx.empty((max(n, 1), max(ncols_out, 1)), dtype)
+    if out is None or out.shape != (max(n, 1), max(ncols_out, 1)) or out.dtype != np.dtype(dtype):
+        out = ctx.empty((max(n, 1), max(ncols_out, 1)), dtype)
     ctx.call("skm_csr_to_dense", _i64(n), _ptr(rowptr), _ptr(colidx), _ptr(counts), _ptr(colmap), _i64(ncols_out),
              1 if presence else 0, code, _ptr(out), _i64(max(ncols_out, 1)))
     return out
@@ -533,18 +536,28 @@ class DensePipeline:
         self.ctx, self.lut, self.k = ctx, lut, k
         self.space = space
         self.kdim = (space + 127) // 128 * 128  # K-step of the LDS-DMA MFMA kernel
-        self.csr = self.rnorm = self.dense = self.out = None
+        self.csr = self.rnorm = self.dense = self.out = self._d_max = None
 
     def step(self, batch: SeqBatch, mode: int = 0):
+        """count -> int8 operand -> norms -> symmetric MFMA GEMM.  Every buffer is reused between steps and no stage
+        waits for another through the host: the largest count (which decides whether int8 holds the operand) stays on
+        the device and is read once, after the GEMM has been queued."""
         ctx = self.ctx
         self.csr = count_csr(ctx, batch, self.lut, self.k, out=self.csr)
-        if csr_max_count(ctx, self.csr) > 127:
-            raise OverflowError("a k-mer count exceeds 127: int8 dense path not applicable")
         n = self.csr.n
+        if self._d_max is None:
+            self._d_max = ctx.zeros(1, np.uint32)
+        ctx.call("skm_csr_max_count_dev", _i64(n), _i64(self.csr.nnz), _ptr(self.csr.rowptr), _ptr(self.csr.counts), _ptr(self._d_max))
         self.rnorm = row_norms(ctx, n, self.csr.rowptr, self.csr.counts, out=self.rnorm)
         # codes double as column ids of the full basis
-        self.dense = csr_to_dense(ctx, n, self.csr.rowptr, self.csr.codes, self.csr.counts, self.kdim, dtype=np.int8)
-        self.out = cosine_dense_i8(ctx, n, n, self.kdim, self.dense, self.dense, self.rnorm, self.rnorm, mode=mode)
+        self.dense = csr_to_dense(ctx, n, self.csr.rowptr, self.csr.codes, self.csr.counts, self.kdim, dtype=np.int8, out=self.dense)
+        ld = (n + 3) // 4 * 4
+        if self.out is None or self.out.shape != (max(n, 1), max(ld, 1)):
+            self.out = None
+            self.out = ctx.empty((max(n, 1), max(ld, 1)), np.float32)
+        cosine_dense_i8(ctx, n, n, self.kdim, self.dense, self.dense, self.rnorm, self.rnorm, mode=mode, out=self.out, ld=ld)
+        if int(self._d_max.download(1)[0]) > 127:
+            raise OverflowError("a k-mer count exceeds 127: int8 dense path not applicable")
         return self.out
 
 
@@ -557,7 +570,7 @@ class Pipeline:
 
     def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int, post32: bool = False, fused: bool = True):
         self.ctx, self.lut, self.k = ctx, lut, k
-        self.fused = fused  # skm_vectorize_csr (one call, no host synchronisation) instead of the three-call form
+        self.fused = fused  # skm_vectorize_csr (one call, no result read back) instead of the three-call form
         # 4-byte posting words (batches under 2^24 sequences): half the posting bytes, but measured SLOWER
         # end to end on MI355X (k_gram_sparse is bound by instruction issue and the decode costs
         # instructions: 1.90 vs 1.75 ms at BASELINE configs[2]), so it is opt-in
@@ -569,7 +582,8 @@ class Pipeline:
 
     def vectorize(self, batch: SeqBatch) -> CountsCSR:
         if self.fused and not self.post32 and batch.n >= 1 and batch.total >= 1:
-            # one call, no host round trip: the host runs ahead of the GPU through the whole step
+            # one call, no size read back: within a step the host runs ahead of the GPU (one wait per call remains,
+            # for the size-class histogram: see vectorize_fused)
             self.csr, self.basis, self.rnorm = vectorize_fused(self.ctx, batch, self.lut, self.k, csr=self.csr,
                                                                basis=self.basis, rnorm=self.rnorm)
             return self.csr

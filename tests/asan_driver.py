@@ -1,0 +1,123 @@
+"""Run as a child process by tests/test_sanitizers.py with libasan preloaded: the oracle's golden-vector tests on the
+-fsanitize=address,undefined build of oracle/kmer_oracle.c (SKM_ORACLE_LIB), then the product's host-only translation
+unit (snekmer_amd/csrc/skm_host.cpp built the same way): the exchange byte plans against their host statements in
+snekmer_amd/dist.py and the threaded FASTA reader against the text-mode reader.  Any sanitizer report aborts the
+process (non-zero exit); the parent also scans stderr."""
+import ctypes as C
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class P2POp(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("array", C.c_int32), ("send_off", C.c_int64), ("send_bytes", C.c_int64),
+                ("recv_off", C.c_int64), ("recv_bytes", C.c_int64)]
+
+
+def check_plans(lib):
+    from snekmer_amd.dist import plan_allgatherv_host, plan_alltoallv_host
+
+    rng = np.random.default_rng(0)
+    p = C.c_void_p
+    for world in range(1, 9):
+        for _ in range(20):
+            na = int(rng.integers(1, 6))
+            eb = rng.choice([1, 4, 8, 12], size=na).astype(np.int64)
+            cmat = rng.integers(0, 1000, size=(world, world)).astype(np.int64)
+            cmat[rng.random((world, world)) < 0.2] = 0
+            plans = []
+            for me in range(world):
+                ops = (P2POp * (world * na))()
+                sc, rc = np.ascontiguousarray(cmat[me, :]), np.ascontiguousarray(cmat[:, me])
+                assert lib.skm_plan_alltoallv(world, na, eb.ctypes.data_as(p), sc.ctypes.data_as(p), rc.ctypes.data_as(p), ops) == 0
+                want = plan_alltoallv_host(eb, sc, rc)
+                for q in range(world):
+                    for a in range(na):
+                        o = ops[q * na + a]
+                        assert (o.send_off, o.send_bytes, o.recv_off, o.recv_bytes) == want[q][a]
+                plans.append(ops)
+            for a_ in range(world):  # pairing: what a sends to b is what b expects from a
+                for b_ in range(world):
+                    for a in range(na):
+                        assert plans[a_][b_ * na + a].send_bytes == plans[b_][a_ * na + a].recv_bytes
+            counts = rng.integers(0, 500, size=(na, world)).astype(np.int64)
+            for me in range(world):
+                ops = (P2POp * (world * na))()
+                assert lib.skm_plan_allgatherv(world, me, na, eb.ctypes.data_as(p), counts.ctypes.data_as(p), ops) == 0
+                want = plan_allgatherv_host(me, eb, counts)
+                for q in range(world):
+                    for a in range(na):
+                        o = ops[q * na + a]
+                        assert (o.send_off, o.send_bytes, o.recv_off, o.recv_bytes) == want[q][a]
+    # argument errors leave a message, not a crash
+    ops = (P2POp * 4)()
+    assert lib.skm_plan_alltoallv(0, 1, None, None, None, ops) == -1
+    lib.skm_last_error.restype = C.c_char_p
+    assert b"skm_plan_alltoallv" in lib.skm_last_error()
+
+
+def read_packed(lib, blob, threads):
+    buf = np.frombuffer(blob, dtype=np.uint8)
+    p = C.c_void_p
+    nrec, nres, flags = C.c_int64(0), C.c_int64(0), C.c_int(0)
+    assert lib.skm_fasta_index(buf.ctypes.data_as(p), C.c_int64(buf.size), threads, C.byref(nrec), C.byref(nres), C.byref(flags)) == 0
+    n = nrec.value
+    res = np.empty(nres.value, dtype=np.uint8)  # exactly sized: an overrun is a heap-buffer-overflow report
+    off = np.zeros(n + 1, dtype=np.int64)
+    idb, idl = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int32)
+    assert lib.skm_fasta_parse(buf.ctypes.data_as(p), C.c_int64(buf.size), threads, C.c_int64(n), C.c_int64(nres.value),
+                               res.ctypes.data_as(p), off.ctypes.data_as(p), idb.ctypes.data_as(p), idl.ctypes.data_as(p)) == 0
+    ids = [blob[int(b):int(b) + int(l)].decode("ascii") for b, l in zip(idb, idl)]
+    return ids, res, off, flags.value
+
+
+def check_fasta(lib):
+    from snekmer_amd import io
+    from snekmer_amd.utils import pack_sequences
+    from test_fasta_reader import HAND
+
+    rng = np.random.default_rng(2)
+    soup = list(b"ACDEFGHIKLMNPQRSTVWY*X \t\r\n\n\n>>> ab\x0b\x0c\x1c")
+    blobs = list(HAND) + [bytes(rng.choice(soup, size=int(rng.integers(0, 600))).tolist()) for _ in range(300)]
+    big = [b"pre\n" * 300000]
+    aa = list(b"ACDEFGHIKLMNPQRSTVWY")
+    for i in range(6000):
+        big.append(b">s%d d\n" % i)
+        s = bytes(rng.choice(aa, size=int(rng.integers(0, 900))).tolist())
+        for j in range(0, len(s), 60):
+            big.append(s[j:j + 60] + (b"\r\n", b"\n", b"\r")[i % 3])
+    blobs.append(b"".join(big))
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "x.fa")
+        for blob in blobs:
+            with open(path, "wb") as fh:
+                fh.write(blob)
+            recs = io.read_fasta(path)
+            want_res, want_off = pack_sequences([s for _, s in recs])
+            for th in (1, 4):
+                ids, res, off, flags = read_packed(lib, blob, th)
+                assert flags == 0 and ids == [r[0] for r in recs]
+                assert (off == want_off).all() and (res == want_res).all()
+
+
+def main():
+    import pytest
+
+    rc = pytest.main([os.path.join(ROOT, "tests", "test_oracle_golden.py"), "-q", "-x", "-p", "no:cacheprovider"])
+    if rc != 0:
+        return int(rc)
+    lib = C.CDLL(os.environ["SKM_HOST_ASAN_LIB"])
+    check_plans(lib)
+    check_fasta(lib)
+    print("ASAN_DRIVER_OK")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -304,3 +304,22 @@ def test_c_plans_of_the_grouped_collectives_match_the_host_statements():
     z = np.zeros(2, np.int64)
     assert lib.skm_plan_alltoallv(2, 1, np.asarray([0], np.int64).ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p),
                                   z.ctypes.data_as(C.c_void_p), bad) == -1
+
+
+def test_bench_self_launches_its_ranks_without_a_launcher():
+    """`python3 bench.py --gpus 2` with no WORLD_SIZE in the environment must start its own ranks (a fresh
+    torch.distributed.run child, before anything touches a GPU) and hand back the job's exit code.  Without a GPU the
+    ranks fail loudly (HipUnavailable: no CPU fallback); the point here is that the failure comes from the ranks and
+    not from argument handling."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""  # also on a GPU box this test stays a CPU test
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "self-launch" in r.stderr and "--nproc-per-node=2" in r.stderr
+    assert "HipUnavailable" in r.stderr and "rank" in r.stderr.lower()
+    assert '"metric"' not in r.stdout

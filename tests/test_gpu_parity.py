@@ -879,7 +879,7 @@ def test_skewed_workload_20k_vs_oracle(ctx, name, k):
     from snekmer_amd.synth import synth_skewed
 
     res, off, fam = synth_skewed(20000, seed=20250523 + 11)
-    assert np.bincount(fam).max() == 5000 and np.diff(off).max() > 1500
+    assert np.bincount(fam).max() > 1536 and np.diff(off).max() > 1500  # rows beyond the list slots; every size class
     _sampled_row_check(ctx, name, k, 20000, seed_idx=11, nsample=64, full_stats=True, packed=(res, off))
 
 

@@ -25,16 +25,21 @@ def ctx():
 
 
 def _canonical_lists(start, length, jj, dot):
-    """Neighbour lists -> (row-of-entry, j, dot) with every row's entries sorted by j."""
+    """Neighbour lists -> one sorted uint64 word per entry, (row << 47 | j << 27 | dot): equal arrays <=> the same
+    neighbour set with the same exact dot for every row.  A single-key sort (no argsort): the 1 M-sequence blocks hold
+    more than 10^8 entries."""
     length = length.astype(np.int64)
-    assert (length != 0xFFFFFFFF).all()
+    assert (length != 0xFFFFFFFF).all() and len(length) < (1 << 17)
     tot = int(length.sum())
     first = np.cumsum(length) - length
     src = np.repeat(start.astype(np.int64) - first, length) + np.arange(tot, dtype=np.int64)
-    rows = np.repeat(np.arange(len(length), dtype=np.int64), length)
-    j, d = jj[src].astype(np.int64), dot[src]
-    order = np.lexsort((j, rows))
-    return rows, j[order], d[order]
+    key = np.repeat(np.arange(len(length), dtype=np.uint64) << np.uint64(47), length)
+    j, d = jj[src], dot[src]
+    assert tot == 0 or (int(j.max()) < (1 << 20) and 0 < int(d.min()) and int(d.max()) < (1 << 27))
+    key |= j.astype(np.uint64) << np.uint64(27)
+    key |= d.astype(np.uint64)
+    key.sort()
+    return (key,)
 
 
 def _assert_topk_equal(idx_a, val_a, idx_b, val_b):
@@ -119,7 +124,7 @@ def test_config4_sharded_code_path_8_ranks_1m_sequences(ctx):
     the all-gather plan, look up the columns of their rows and produce exact neighbour lists + top-10 of their row
     block against all 1 M sequences.  Against the single-GPU pipeline on the same batch (itself pinned to the oracle
     at this size by test_config4_one_rank_share_125k_rows_vs_1m): norms of all rows, entry / column totals, and for
-    the blocks of ranks 0, 3 and 7 every neighbour set, every exact integer dot and the top-10."""
+    the blocks of ranks 0 and 5 every neighbour set, every exact integer dot and the top-10."""
     from snekmer_amd import alphabet as A
     from snekmer_amd import engine
     from snekmer_amd.dist import shard_bounds
@@ -129,7 +134,7 @@ def test_config4_sharded_code_path_8_ranks_1m_sequences(ctx):
     if mem < 200 * 2**30:
         pytest.skip("needs ~120 GB of HBM (8 ranks' buffers on one device)")
     lut, k, n, world, topk = A.build_lut("red6"), 12, 1_000_000, 8, 10
-    check = (0, 3, 7)
+    check = (0, 5)
     import faulthandler
 
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)  # a stuck run says where (pytest shows stderr on failure)
