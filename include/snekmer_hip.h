@@ -261,6 +261,16 @@ int skm_setsim_f64(skm_ctx *ctx, int kind, int64_t n, int64_t m, int64_t ncols, 
                    const uint32_t *d_ynnz, const float *d_both, const float *d_equal, int64_t ld, double *d_out,
                    int64_t ld_out);
 
+/* The `else` branch of snekmer/score.py:169-171, pairwise_distances(X, metric=m), for dense float64 matrices
+ * X [n x k] (row stride ldx) and Y [m x k] (pass X itself for the square case: the diagonal is then an exact zero,
+ * as squareform(pdist(X)) / euclidean_distances(X) give).  metric: 0 cityblock (manhattan, l1), 1 sqeuclidean,
+ * 2 euclidean (l2), 3 chebyshev, 4 canberra, 5 braycurtis, 6 minkowski (exponent p); scipy's boolean
+ * dissimilarities on x != 0, y != 0: 10 dice, 11 rogerstanimoto, 12 russellrao, 13 sokalmichener, 14 sokalsneath,
+ * 15 yule (0/0 gives nan, as scipy's C implementation does).  cosine, hamming and jaccard have their own entry
+ * points above.  No Snekmer rule passes these metrics; tutorial-scale matrices. */
+int skm_pairwise_f64(skm_ctx *ctx, int metric, double p, int64_t n, int64_t m, int64_t k, const double *d_x, int64_t ldx,
+                     const double *d_y, int64_t ldy, double *d_out, int64_t ld);
+
 /* Apply epilogue (snekmer/rules/apply.smk:312-328, rules/learn.smk:831-849): for every row of a
  * score matrix the two largest entries and their columns, i.e. np.argsort(-S, axis=1)[:, :2] with
  * ties broken towards the lower column.  d_idx[2*i+{0,1}], d_val[2*i+{0,1}]; with m == 1 the

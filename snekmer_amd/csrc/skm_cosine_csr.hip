@@ -15,13 +15,17 @@
 //                      of the row's non-zeros (each posting read once, next lists' loads in flight)
 //                      and accumulate v*v' in an LDS hash table keyed by the neighbour row; the
 //                      row's (j, exact int32 dot) entries go to the row's slot of a global list.
-//   k_gram_sparse_big  the same with an 8192-slot table and room for 4096 non-zeros, for the rows
-//                      the first pass flags (more than 1536 neighbours or 512 distinct k-mers).
+//   k_cosine_heavy     the rows the first pass flags (more than 1536 neighbours or 512 distinct k-mers: members
+//                      of families of thousands, low-complexity k-mers, long sequences): Gram and write fused,
+//                      one workgroup per row, products added with plain LDS atomics into the dense 32768-column
+//                      tile the writer uses anyway; no hash table, so no neighbour capacity.
+//   k_gram_sparse_big  the list-producing form for such rows (8192-slot table, 4096 non-zeros): used by
+//                      skm_gram_neighbors, whose output IS the lists.
 //   k_cosine_write     workgroup per output row, pure streaming writer: per 4096-column step it
 //                      drops the step's neighbour entries into a zeroed LDS tile, scales to float32
 //                      (mode 1: cosine distance) and stores 16 B per lane.  Dominant kernel.
 //   k_cosine_strip     exact for ANY density, the fallback for strips the kernels above cannot
-//                      hold (> 4096 neighbours or distinct k-mers in a row, > 2^20 output columns):
+//                      hold (more than 2048 shared k-mers in a row) and the default for narrow outputs:
 //                      a workgroup owns 8 output rows and walks the columns in chunks of 1024 with
 //                      dense int32 LDS accumulators; every non-zero holds a cursor into its
 //                      (sorted) posting list and adds v*v' for the postings that fall into the
@@ -50,6 +54,7 @@ constexpr int TB = 256;
 constexpr int Q = 10;  // register-resident tasks per thread -> Q*TB = 2560 tasks per strip
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t G_DONE_ROW = 0xFFFFFFFEu;  // g_len of a row k_cosine_heavy has already written
 
 // ------------------------------------------------------------------------------- sparse Gram
 #include "skm_gram_kernel.h"
@@ -263,6 +268,8 @@ __global__ __launch_bounds__(WTB) void k_cosine_write(const uint64_t *__restrict
     const int64_t r = rbase + blockIdx.x;  // row of the workgroup, counted from row0 (a launch covers rows rbase...)
     const int64_t i = row0 + r;
     const uint32_t len = g_len[r];
+    if (len == G_DONE_ROW)  // written by k_cosine_heavy (Gram and write fused for rows with thousands of neighbours)
+        return;
     if (len == G_OVERFLOW) {
         // the row exceeded the sparse kernels' capacities: leave its strip to the cursor kernel
         // (cursor strips are 8 rows; fb_flag makes sure a strip is listed once, since the cursor
@@ -352,6 +359,208 @@ __global__ __launch_bounds__(WTB) void k_cosine_write(const uint64_t *__restrict
             }
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------- heavy rows: Gram + write fused
+// Rows the first sparse pass cannot hold (more than 512 non-zeros, or more than 1536 neighbours: members of families
+// of thousands, low-complexity k-mers shared by thousands of rows, long sequences) used to go through an 8192-slot
+// hash pass with one workgroup per CU that walks one posting list at a time (measured on synth_skewed at 100 k rows:
+// 1.6 us per row, and again 1.6 us per row in the cursor kernel for what overflowed that table or the list space:
+// 295 ms per step against 11 ms on uniform families).  Such a row has thousands of non-zero cells, so its products
+// go straight into the dense LDS tile the streaming writer uses anyway: one workgroup per row, 32768 columns per step;
+// per step every wave takes posting lists in turn and walks the part of each list that falls into the step's column
+// range with lane-consecutive loads (postings are sorted by row, a cursor per list remembers where the previous step
+// stopped; 256 postings per wave and round for lists of more than 64, four lists per wave and round for the short
+// ones), adding v * v' with plain LDS atomics: no hash, no probe, no capacity other than the number of the row's own
+// shared non-zeros (HEAVY_EMAX; rows beyond that stay flagged for the cursor kernel).  The step's tile is then scaled
+// and stored like the writer's.  A row done here gets g_len = G_DONE_ROW: the writer's workgroup for it exits.
+constexpr int HEAVY_CH = 32768, HEAVY_TB = 1024, HEAVY_EMAX = 2048, HEAVY_U = 4;
+
+template <int MODE, bool VEC, typename PW>
+__global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__restrict__ xrowptr,
+                                                           const uint32_t *__restrict__ xcolidx,
+                                                           const uint32_t *__restrict__ xcounts,
+                                                           const float *__restrict__ xrnorm, int64_t m,
+                                                           const uint32_t *__restrict__ ycolptr,
+                                                           const PW *__restrict__ ypost,
+                                                           const uint32_t *__restrict__ ypostcnt,
+                                                           const float *__restrict__ yrnorm, int64_t row0, int64_t rbase,
+                                                           const uint32_t *__restrict__ row_list,
+                                                           const uint32_t *__restrict__ row_count,
+                                                           uint32_t *__restrict__ g_len, float *__restrict__ out, int64_t ld)
+{
+    constexpr int CHH = HEAVY_CH, TBH = HEAVY_TB, NW = HEAVY_TB / 64, U = HEAVY_U;
+    __shared__ __attribute__((aligned(16))) int s_acc[CHH];
+    __shared__ uint32_t s_cur[HEAVY_EMAX], s_end[HEAVY_EMAX], s_val[HEAVY_EMAX];
+    __shared__ uint32_t s_nlong, s_nshort, s_self;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t cnt = *row_count;
+    for (int z = tid; z < CHH / 4; z += TBH)
+        reinterpret_cast<int4 *>(s_acc)[z] = make_int4(0, 0, 0, 0);
+    for (uint32_t idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
+        const int64_t r = rbase + row_list[idx];  // row counted from row0 (g_len, out)
+        const int64_t i = row0 + r;
+        __syncthreads();  // the previous row's tile and lists are no longer in use
+        if (tid == 0) {
+            s_nlong = 0;
+            s_nshort = 0;
+            s_self = 0;
+        }
+        __syncthreads();
+        // ---- the row's shared non-zeros -> (cursor, end, count); lists of more than 64 postings are stored from the
+        // front of the arrays, the others from the back
+        const int64_t e0 = xrowptr[i], e1 = xrowptr[i + 1];
+        uint32_t self = 0;
+        for (int64_t t0 = e0; t0 < e1; t0 += TBH) {  // whole-wave iterations (ballots)
+            const int64_t t = t0 + tid;
+            uint32_t pb = 0, pe = 0, v = 0;
+            if (t < e1) {
+                const uint32_t c = xcolidx[t];
+                v = xcounts[t] & 0x0FFFFFFFu;
+                if (c == NONE)
+                    self += v * v;  // a k-mer of this row only (ELIDE_SINGLETONS)
+                else {
+                    pb = ycolptr[c];
+                    pe = ycolptr[c + 1];
+                }
+            }
+            const bool is_long = pe - pb > 64u, is_short = pe > pb && !is_long;
+            const unsigned long long bl = __ballot(is_long), bs = __ballot(is_short);
+            uint32_t basel = 0, bases = 0;
+            if (lane == 0) {
+                if (bl)
+                    basel = atomicAdd(&s_nlong, (uint32_t)__popcll(bl));
+                if (bs)
+                    bases = atomicAdd(&s_nshort, (uint32_t)__popcll(bs));
+            }
+            basel = __shfl(basel, 0);
+            bases = __shfl(bases, 0);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            uint32_t slot = 0xFFFFFFFFu;
+            if (is_long)
+                slot = basel + (uint32_t)__popcll(bl & below);
+            else if (is_short)
+                slot = (uint32_t)HEAVY_EMAX - 1u - (bases + (uint32_t)__popcll(bs & below));
+            // (on overflow the counters keep counting, nothing is stored out of range, and the row is skipped below)
+            if (slot < (uint32_t)HEAVY_EMAX) {
+                s_cur[slot] = pb;
+                s_end[slot] = pe;
+                s_val[slot] = v;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            self += __shfl_xor(self, o);
+        if (lane == 0 && self)
+            atomicAdd(&s_self, self);
+        __syncthreads();
+        const uint32_t nlong = s_nlong, nshort = s_nshort;
+        if (nlong + nshort > (uint32_t)HEAVY_EMAX)  // uniform: the row stays flagged (cursor kernel)
+            continue;
+        const float ri = xrnorm[i];
+        for (int64_t j0 = 0; j0 < m; j0 += CHH) {
+            const uint32_t j0u = (uint32_t)j0;
+            const uint32_t j1u = (uint32_t)min(j0 + (int64_t)CHH, m);
+            // ---- long lists: one wave per list, U loads per lane and round
+            for (uint32_t l = (uint32_t)wid; l < nlong; l += NW) {
+                uint32_t p = s_cur[l];
+                const uint32_t pe = s_end[l], v = s_val[l];
+                while (p < pe) {
+                    PW pw[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t at = p + (uint32_t)(u * 64 + lane);
+                        pw[u] = ypost[at < pe ? at : pe - 1u];
+                    }
+                    uint32_t took = 0;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t at = p + (uint32_t)(u * 64 + lane);
+                        const uint32_t j = posting<PW>::row(pw[u]);
+                        const bool in = at < pe && j < j1u;
+                        if (in)
+                            atomicAdd(&s_acc[j - j0u], (int)(v * posting<PW>::count(pw[u], ypostcnt, at)));
+                        took += (uint32_t)__popcll(__ballot(in));
+                    }
+                    p += took;
+                    if (took < (uint32_t)(U * 64))
+                        break;  // the list's part of this column range is done (or the list is)
+                }
+                if (lane == 0)
+                    s_cur[l] = p;
+            }
+            // ---- short lists (at most 64 postings): four lists per wave and round, 16 lanes each
+            for (uint32_t l0 = (uint32_t)wid * 4u; l0 < nshort; l0 += NW * 4u) {
+                const uint32_t l = l0 + (uint32_t)(lane >> 4), gl = (uint32_t)(lane & 15);
+                const bool have = l < nshort;
+                const uint32_t slot = (uint32_t)HEAVY_EMAX - 1u - (have ? l : 0u);
+                uint32_t p = s_cur[slot];
+                const uint32_t pe = have ? s_end[slot] : 0u, v = s_val[slot];
+                bool active = have;
+                for (int round = 0; round < 4; ++round) {  // 4 x 16 >= 64 postings; every lane runs the same rounds
+                    const uint32_t at = p + gl;
+                    const bool ok = active && at < pe;
+                    const PW pw = ypost[ok ? at : 0u];  // posting 0 exists: the row has a non-empty list
+                    const uint32_t j = posting<PW>::row(pw);
+                    const bool in = ok && j < j1u;
+                    if (in)
+                        atomicAdd(&s_acc[j - j0u], (int)(v * posting<PW>::count(pw, ypostcnt, at)));
+                    const unsigned long long bal = __ballot(in);
+                    const uint32_t took = (uint32_t)__popcll((bal >> (lane & 48)) & 0xFFFFull);
+                    p += took;
+                    active = active && took == 16u && p < pe;
+                    if (!__any(active))
+                        break;
+                }
+                if (have && gl == 0)
+                    s_cur[slot] = p;
+            }
+            if (tid == 0 && (uint32_t)i >= j0u && (uint32_t)i < j1u && s_self)
+                atomicAdd(&s_acc[(uint32_t)i - j0u], (int)s_self);
+            __syncthreads();
+            // ---- scale, store, clear (the writer's store shape: 16-byte non-temporal stores, 1 KiB per wave instruction)
+#pragma unroll
+            for (int q = 0; q < CHH / 4 / TBH; ++q) {
+                const int z = tid + q * TBH;
+                const int64_t jc = j0 + 4 * (int64_t)z;
+                if (jc >= m)
+                    break;
+                const int4 a = reinterpret_cast<int4 *>(s_acc)[z];
+                reinterpret_cast<int4 *>(s_acc)[z] = make_int4(0, 0, 0, 0);
+                float rj[4] = {0.f, 0.f, 0.f, 0.f};
+                if (VEC && jc + 3 < m) {
+                    const float4 t4 = *reinterpret_cast<const float4 *>(yrnorm + jc);
+                    rj[0] = t4.x, rj[1] = t4.y, rj[2] = t4.z, rj[3] = t4.w;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (jc + u < m)
+                            rj[u] = yrnorm[jc + u];
+                }
+                float o[4] = {(float)a.x * ri * rj[0], (float)a.y * ri * rj[1], (float)a.z * ri * rj[2], (float)a.w * ri * rj[3]};
+                if (MODE == 1) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float d = fminf(fmaxf(1.0f - o[u], 0.0f), 2.0f);
+                        o[u] = (jc + u == i) ? 0.0f : d;
+                    }
+                }
+                float *dst = out + r * ld + jc;
+                if (VEC && jc + 3 < m) {
+                    const f32x4 pack = {o[0], o[1], o[2], o[3]};
+                    __builtin_nontemporal_store(pack, reinterpret_cast<f32x4 *>(dst));
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (jc + u < m)
+                            dst[u] = o[u];
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0)
+            g_len[r] = G_DONE_ROW;
     }
 }
 
@@ -981,18 +1190,21 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
 #undef SKM_GRAM
         }
         SKM_TRY(skm_check_launch("k_gram_sparse"));
-        {
-            // rows the small tables cannot hold: 8192 slots and up to 4096 non-zeros, one row per workgroup
-            SKM_PROF_ON(ctx, "k_gram_sparse_big", gs);
-            k_gram_sparse_big<8192, 512, 8, 16, 4, PW><<<skm_grid_cap(ctx, bn, 1), 512, 0, gs>>>(
-                d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0 + b0, row0 + b1, g_ent, cap_ent, g_counter,
-                g_start + b0, g_len + b0, b_over_list, b_over_count, nullptr, nullptr);
-        }
-        SKM_TRY(skm_check_launch("k_gram_sparse_big"));
         if (nblk > 1) {
             SKM_HIP(hipEventRecord(ctx->sync_events[1 + b], gs));
             SKM_HIP(hipStreamWaitEvent(s_w, ctx->sync_events[1 + b], 0));
         }
+        {
+            // rows the first pass could not hold: Gram and write fused, one row per workgroup, dense LDS tile
+            SKM_PROF_ON(ctx, "k_cosine_heavy", s_w);
+#define SKM_HEAVY(MODE, VEC)                                                                                         \
+    k_cosine_heavy<MODE, VEC, PW><<<skm_grid_cap(ctx, bn, 1), HEAVY_TB, 0, s_w>>>(                                   \
+        d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, d_ypost, d_ypostcnt, d_yrnorm, row0, b0, b_over_list, \
+        b_over_count, g_len, d_out, ld)
+            SKM_BY_MODE_VEC(SKM_HEAVY);
+#undef SKM_HEAVY
+        }
+        SKM_TRY(skm_check_launch("k_cosine_heavy"));
         {
             // one output row per workgroup of 1024 threads
             SKM_PROF_ON(ctx, "k_cosine_write", s_w);

@@ -225,12 +225,56 @@ def connection_matrix_from_features(feature_matrix, metric="jaccard"):
         return cosine_similarity(feature_matrix, None, mode=1)
     if metric == "jaccard":
         return hamming_similarity(feature_matrix)
-    if metric == "hamming":
+    if metric in ("hamming", "matching"):
         return _set_measure(feature_matrix, 2)
-    raise NotImplementedError(
-        f"metric={metric!r}: the MI355X hot path implements 'cosine', 'hamming' and the reference's default 'jaccard' "
-        "(= 1 - hamming) branch of snekmer/score.py:166-171; no Snekmer rule passes another metric"
-    )
+    return pairwise_distances(feature_matrix, metric=metric)
+
+
+# metric name -> id of skm_pairwise_f64 (include/snekmer_hip.h)
+PAIRWISE_METRICS = {"cityblock": 0, "manhattan": 0, "l1": 0, "sqeuclidean": 1, "euclidean": 2, "l2": 2, "chebyshev": 3, "canberra": 4,
+                    "braycurtis": 5, "minkowski": 6, "dice": 10, "rogerstanimoto": 11, "russellrao": 12, "sokalmichener": 13,
+                    "sokalsneath": 14, "yule": 15}
+
+
+def pairwise_distances(X, metric: str = "euclidean", p: float = 2.0, ctx=None) -> np.ndarray:
+    """``sklearn.metrics.pairwise_distances(X, metric=metric)`` (the `else` branch of snekmer/score.py:169-171) on the
+    device for the metrics that are sums or maxima over columns (cityblock / manhattan / l1, euclidean / l2,
+    sqeuclidean, chebyshev, canberra, braycurtis, minkowski) and scipy's boolean dissimilarities (dice,
+    rogerstanimoto, russellrao, sokalmichener, sokalsneath, yule; the input read as x != 0); "cosine", "hamming" /
+    "matching" go to their own kernels.  Square float64 matrix with an exact-zero diagonal.  Metrics that need more
+    than the two rows (mahalanobis, seuclidean, correlation, ...) raise NotImplementedError: no Snekmer rule passes
+    them."""
+    import ctypes as C
+
+    from . import _hip
+
+    if metric == "cosine":
+        return cosine_similarity(X, None, mode=1, ctx=ctx)
+    if metric in ("hamming", "matching"):
+        return _set_measure(X, 2, ctx)
+    if metric not in PAIRWISE_METRICS:
+        raise NotImplementedError(
+            f"metric={metric!r}: implemented on the device are 'cosine', 'hamming', the reference's default 'jaccard' "
+            f"(= 1 - hamming) and {sorted(PAIRWISE_METRICS)} (snekmer/score.py:166-171); no Snekmer rule passes another metric")
+    ctx = ctx or _hip.default_context()
+    A = _plain(X)
+    if hasattr(A, "toarray"):
+        raise TypeError("scipy distance metrics do not support sparse matrices.")  # sklearn's message for these metrics
+    A = np.ascontiguousarray(np.asarray(A), dtype=np.float64)
+    if A.ndim != 2:
+        raise ValueError("expected a 2-D feature matrix")
+    if not np.all(np.isfinite(A)):
+        raise ValueError("Input contains NaN or infinity.")
+    n, k = A.shape
+    if k == 0:
+        raise ValueError("feature matrix has no columns")
+    if n == 0:
+        return np.zeros((0, 0), dtype=np.float64)
+    dx = ctx.to_device(A)
+    out = ctx.empty((n, n), np.float64)
+    ctx.call("skm_pairwise_f64", PAIRWISE_METRICS[metric], C.c_double(p), C.c_int64(n), C.c_int64(n), C.c_int64(k), C.c_void_p(dx.ptr),
+             C.c_int64(k), C.c_void_p(dx.ptr), C.c_int64(k), C.c_void_p(out.ptr), C.c_int64(n))
+    return out.download().reshape(n, n)
 
 
 def jaccard_distance(feature_matrix, ctx=None) -> np.ndarray:

@@ -336,7 +336,7 @@ def test_connection_matrix_and_feature_matrix_goldens(ctx):
     for key, M in (("jaccard_x", g["X"]), ("jaccard_demo_counts", counts), ("jaccard_float", g15["F"])):
         assert (skm.score.jaccard_distance(M) == g15[key]).all(), key
     with pytest.raises(NotImplementedError):
-        skm.score.connection_matrix_from_features(g["X"], metric="chebyshev")
+        skm.score.connection_matrix_from_features(g["X"], metric="seuclidean")
     with pytest.raises(ValueError):
         skm.score.connection_matrix_from_features(np.asarray([[1.0, np.nan], [0.0, 1.0]]))
     for case in gjson("g7_feature_matrix.json"):
@@ -366,6 +366,38 @@ def test_cosine_distance_diagonal_rule_follows_sklearn(ctx):
     Df = cosine_similarity(X.astype(np.float64) + 0.0, Y * 1.0, mode=1, ctx=ctx, path="f64")
     assert np.abs(Df - cosine_distances(X, Y)).max() <= 1e-12 and Df[5, 5] == 1.0
     assert np.abs(Df - cosine_similarity(X, Y, mode=1, ctx=ctx)).max() <= COS_TOL
+
+
+def test_connection_matrix_other_sklearn_metrics_match_sklearn(ctx):
+    """The `else` branch of snekmer/score.py:169-171: pairwise_distances(X, metric=m) for the column-sum / column-max
+    metrics and scipy's boolean dissimilarities, against scikit-learn itself (the reference's un-vendored dependency,
+    installed on the GPU box) on a count matrix, a real-valued matrix and shapes that are not tile multiples."""
+    import warnings
+
+    from sklearn.metrics import pairwise_distances
+
+    import snekmer_amd as skm
+    from snekmer_amd.score import PAIRWISE_METRICS
+
+    rng = np.random.default_rng(17)
+    counts = ((rng.random((71, 133)) < 0.3) * rng.integers(1, 6, size=(71, 133))).astype(np.float64)
+    counts[4] = 0
+    counts[9] = counts[8]
+    real = rng.normal(size=(130, 37)) * (rng.random((130, 37)) < 0.7)
+    for X in (counts, real, counts[:1], real[:, :1]):
+        for metric in sorted(PAIRWISE_METRICS) + ["hamming", "matching", "cosine"]:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")  # sklearn's bool-conversion notice, scipy's 0/0
+                want = pairwise_distances(X, metric=metric)
+            got = skm.score.connection_matrix_from_features(X, metric=metric)
+            assert got.dtype == np.float64 and got.shape == want.shape, metric
+            assert (np.isnan(got) == np.isnan(want)).all(), metric
+            tol = COS_TOL if metric == "cosine" and X is counts else 1e-12 * max(1.0, float(np.nanmax(np.abs(want))) if want.size else 1.0)
+            assert np.nanmax(np.abs(got - want), initial=0.0) <= tol, (metric, X.shape)
+    got = skm.score.pairwise_distances(real, metric="minkowski", p=3.0)
+    assert np.abs(got - pairwise_distances(real, metric="minkowski", p=3.0)).max() <= 1e-12
+    with pytest.raises(NotImplementedError):
+        skm.score.connection_matrix_from_features(counts, metric="mahalanobis")
 
 
 # ------------------------------------------------------------------ BASELINE sizes: properties
@@ -868,6 +900,63 @@ def _sampled_row_check(ctx, name, k, n, seed_idx, nsample=48, family=100, full_s
         assert np.abs(rowsum - o_sum).max() <= 2e-6 * max(1.0, float(o_sum.max()))
         assert abs(float(rowsum.sum()) - float(o_sum.sum())) <= 1e-6 * float(o_sum.sum())
     return pipe
+
+
+@pytest.mark.cosine_paths
+@pytest.mark.parametrize("mode", [0, 1])
+def test_heavy_rows_every_list_shape_vs_oracle(ctx, mode):
+    """Rows the first sparse pass cannot hold go to k_cosine_heavy (Gram + write fused over a dense LDS tile): more
+    than 512 non-zeros with posting lists of every shape — 70 copies of a 600-residue sequence (lists of 70 postings:
+    a wave per list), 5 copies of a 700-residue one (short lists: 16 lanes per list), 1700 sequences sharing one
+    low-complexity run (one list of 1700 postings on top of ordinary family rows, more than 1536 neighbours each) —
+    and, beyond the kernel's 2048 shared non-zeros per row, 3 copies of a 3000-residue sequence (left to the cursor
+    kernel).  Whole matrix against the oracle, similarity and distance."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+    from snekmer_amd.utils import pack_sequences
+
+    orc = _oracle()
+    lut = A.build_lut("red6")
+    k = 12
+    rng = np.random.default_rng(8)
+    aa = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+    rnd = lambda L: aa[rng.integers(0, 20, size=L)].tobytes().decode()
+    res, off, _ = synth_families(1800, 300, family=30, seed=9)
+    raw = res.tobytes()
+    seqs = [raw[off[i]:off[i + 1]].decode() for i in range(1800)]
+    seqs = [s[:150] + "KRKRKRKRKRKRKRKRKRKRKRKR" + s[150:] if i < 1700 else s for i, s in enumerate(seqs)]  # one k-mer in 1700 rows
+    a, b_, c = rnd(600), rnd(700), rnd(3000)
+    seqs += [a] * 70 + [b_] * 5 + [c] * 3 + [rnd(900)]  # the last one: long, nothing shared
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    res, off = pack_sequences(seqs)
+    batch = engine.SeqBatch(ctx, res, off)
+    n = batch.n
+    pipe = engine.Pipeline(ctx, lut, k)
+    pipe.vectorize(batch)
+    bs = pipe.basis
+    ld = (n + 3) // 4 * 4
+    S = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, bs.ncols_hint(), bs.colptr, bs.post, pipe.rnorm, mode=mode, ld=ld)
+    S = S.download().reshape(-1, ld)[:n, :n]
+    if os.environ.get("SKM_COSINE_PATH") != "cursor":
+        import ctypes as C
+
+        st = (C.c_int64 * 3)()
+        ctx.call("skm_cosine_csr_stats", st)
+        assert st[0] >= 1700 + 70 + 5 + 3 + 1  # rows handed to the heavy kernel ...
+        assert 1 <= st[1] <= 3                 # ... of which the three 3000-residue copies end in cursor strips
+    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
+    ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), np.arange(n))
+    if mode == 1:
+        ref = np.clip(1.0 - ref, 0, 2)
+        np.fill_diagonal(ref, 0.0)
+    assert np.abs(S - ref).max() <= COS_TOL
+    # a row block that starts inside the batch (what a rank of the sharded pipeline computes) gives the same rows
+    blk = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, bs.ncols_hint(), bs.colptr, bs.post, pipe.rnorm, row0=301, row1=1777,
+                               mode=mode, ld=ld).download().reshape(-1, ld)[: 1777 - 301, :n]
+    assert (blk == S[301:1777]).all()
 
 
 @pytest.mark.parametrize("name,k", [("red6", 12), ("standard", 12), ("hydro", 14)])
