@@ -462,33 +462,64 @@ __global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__rest
         for (int64_t j0 = 0; j0 < m; j0 += CHH) {
             const uint32_t j0u = (uint32_t)j0;
             const uint32_t j1u = (uint32_t)min(j0 + (int64_t)CHH, m);
-            // ---- long lists: one wave per list, U loads per lane and round
-            for (uint32_t l = (uint32_t)wid; l < nlong; l += NW) {
-                uint32_t p = s_cur[l];
-                const uint32_t pe = s_end[l], v = s_val[l];
-                while (p < pe) {
-                    PW pw[U];
+            // ---- long lists: one wave per list, U loads per lane and round; the first round of the wave's next list
+            // is in flight while the current list is added (two register sets used in turn: a copy would wait)
+            if (nlong) {
+                PW buf[2][U];
+                uint32_t lp[2], lpe[2], lv[2];
+                bool lh[2];
+                auto issue = [&](PW(&pw)[U], uint32_t p, uint32_t pe) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const uint32_t at = p + (uint32_t)(u * 64 + lane);
-                        pw[u] = ypost[at < pe ? at : pe - 1u];
+                        pw[u] = ypost[at < pe ? at : (pe ? pe - 1u : 0u)];
                     }
-                    uint32_t took = 0;
+                };
+                auto fetch = [&](int d, uint32_t l) {
+                    lh[d] = l < nlong;
+                    const uint32_t ll = lh[d] ? l : 0u;
+                    lp[d] = s_cur[ll];
+                    lpe[d] = lh[d] ? s_end[ll] : 0u;
+                    lv[d] = s_val[ll];
+                    issue(buf[d], lp[d], lpe[d]);
+                };
+                auto consume = [&](int d, uint32_t l) {
+                    uint32_t p = lp[d];
+                    const uint32_t pe = lpe[d], v = lv[d];
+                    bool loaded = true;
+                    while (p < pe) {
+                        if (!loaded)
+                            issue(buf[d], p, pe);
+                        loaded = false;
+                        uint32_t took = 0;
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const uint32_t at = p + (uint32_t)(u * 64 + lane);
-                        const uint32_t j = posting<PW>::row(pw[u]);
-                        const bool in = at < pe && j < j1u;
-                        if (in)
-                            atomicAdd(&s_acc[j - j0u], (int)(v * posting<PW>::count(pw[u], ypostcnt, at)));
-                        took += (uint32_t)__popcll(__ballot(in));
+                        for (int u = 0; u < U; ++u) {
+                            const uint32_t at = p + (uint32_t)(u * 64 + lane);
+                            const uint32_t j = posting<PW>::row(buf[d][u]);
+                            const bool in = at < pe && j < j1u;
+                            if (in)
+                                atomicAdd(&s_acc[j - j0u], (int)(v * posting<PW>::count(buf[d][u], ypostcnt, at)));
+                            took += (uint32_t)__popcll(__ballot(in));
+                        }
+                        p += took;
+                        if (took < (uint32_t)(U * 64))
+                            break;  // the list's part of this column range is done (or the list is)
                     }
-                    p += took;
-                    if (took < (uint32_t)(U * 64))
-                        break;  // the list's part of this column range is done (or the list is)
+                    if (lane == 0 && lh[d])
+                        s_cur[l] = p;
+                };
+                uint32_t l = (uint32_t)wid;
+                fetch(0, l);
+                while (l < nlong) {  // wave-uniform
+                    fetch(1, l + NW);
+                    consume(0, l);
+                    l += NW;
+                    if (l >= nlong)
+                        break;
+                    fetch(0, l + NW);
+                    consume(1, l);
+                    l += NW;
                 }
-                if (lane == 0)
-                    s_cur[l] = p;
             }
             // ---- short lists (at most 64 postings): four lists per wave and round, 16 lanes each
             for (uint32_t l0 = (uint32_t)wid * 4u; l0 < nshort; l0 += NW * 4u) {

@@ -87,6 +87,8 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     constexpr int GQCAP = 128;  // queue words per wave
     __shared__ uint64_t s_queue[GT / 64][GQCAP];
     __shared__ int s_over;
+    __shared__ uint32_t s_pairs;
+    constexpr int HEAVY_PAIRS = 16 * GMAXD;
     const int tid = threadIdx.x, lane = tid & 63;
     const int rows = (int)min((int64_t)GR, row1 - i0);
     unsigned long long stamp = 0;
@@ -144,8 +146,10 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
         s_fill[tid] = 0;
         s_self[tid] = 0;
     }
-    if (tid == 0)
+    if (tid == 0) {
         s_over = 0;
+        s_pairs = 0;
+    }
     if (tid < NBIN) {
         s_cnt[tid] = 0;
         s_fillc[tid] = 0;
@@ -192,6 +196,22 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     // Lists are binned by length so that every bin gets lane groups of a fitting width (a list
     // of 2 postings on a 32-lane group would leave 30 lanes idle: at 100 k sequences half of the
     // lists have fewer than 5 postings).  Bin c holds t_*[s_off[c] .. s_off[c + 1]).
+    // First pass only (rows with a fixed list slot): a row whose posting lists hold more than HEAVY_PAIRS postings
+    // in total is handed on at once.  It would almost certainly outgrow the table (HEAVY_PAIRS = 16 visits per slot
+    // of capacity), and finding that out by walking costs most of the walk: on a batch with families of thousands
+    // the aborted walks were 13 ms of a 39 ms step.  The pass behind this one is exact for any row, so the rule only
+    // moves work; it never changes a result.
+    if (fixed_stride != 0ull) {
+        uint32_t pairs = 0;
+#pragma unroll
+        for (int q = 0; q < GQ; ++q)
+            pairs += pe[q] - pb[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            pairs += __shfl_xor(pairs, o);
+        if (lane == 0 && pairs)
+            atomicAdd(&s_pairs, pairs);
+    }
     int cls[GQ];
 #pragma unroll
     for (int q = 0; q < GQ; ++q) {
@@ -205,6 +225,10 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
         }
     }
     __syncthreads();
+    if (fixed_stride != 0ull && s_pairs > (uint32_t)HEAVY_PAIRS) {  // uniform for the workgroup
+        flag_rows();
+        return;
+    }
     uint32_t boff[NBIN + 1];
     boff[0] = 0;
 #pragma unroll
