@@ -484,6 +484,13 @@ int skm_csr_remap_columns(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, cons
                           const uint32_t *d_counts, const uint32_t *d_colmap, int64_t ncols, int64_t *d_out_rowptr,
                           uint32_t *d_out_col, uint32_t *d_out_val, int64_t *h_out_nnz);
 
+/* The filter of snekmer/rules/kmerize.smk:102-104 on the device: of the columns in first-seen order
+ * (d_fs_order[ncols], skm_basis_build) keep those whose total occurrence count d_total[column] > min_filter, order
+ * kept: d_keep[0 .. *h_nkeep) = the kept columns (the order of `kmerlist`), d_colmap[column] = its position in
+ * `kmerlist` or 0xFFFFFFFF.  Host-synchronous (one 8-byte read-back). */
+int skm_basis_select(skm_ctx *ctx, int64_t ncols, const uint32_t *d_fs_order, const uint64_t *d_total, uint64_t min_filter,
+                     uint32_t *d_keep, uint32_t *d_colmap, int64_t *h_nkeep);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "skm_rows_to_utf32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p]),
     "skm_decode_kmers_utf32": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p, _p, _p, _i64, _p]),
     "skm_csr_remap_columns": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _p, _p, _p, C.POINTER(_i64)]),
+    "skm_basis_select": (C.c_int, [_p, _i64, _p, _p, C.c_uint64, _p, _p, C.POINTER(_i64)]),
     "skm_comm_unique_id": (C.c_int, [_p]),
     "skm_comm_init": (C.c_int, [_p, C.c_int, C.c_int, _p]),
     "skm_comm_destroy": (C.c_int, [_p]),

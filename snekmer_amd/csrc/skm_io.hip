@@ -122,6 +122,32 @@ __global__ __launch_bounds__(BLK) void k_remap_write(const int64_t *__restrict__
     }
 }
 
+// keep flag of every position of the first-seen order: total occurrences of that column > min_filter
+__global__ __launch_bounds__(BLK) void k_select_flags(int64_t ncols, const uint32_t *__restrict__ order,
+                                                      const uint64_t *__restrict__ total, uint64_t min_filter,
+                                                      uint32_t *__restrict__ flags)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ncols)
+        flags[i] = total[order[i]] > min_filter ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(BLK) void k_select_scatter(int64_t ncols, const uint32_t *__restrict__ order,
+                                                        const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos,
+                                                        uint32_t *__restrict__ keep, uint32_t *__restrict__ colmap)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncols)
+        return;
+    const uint32_t c = order[i];
+    if (flags[i]) {
+        keep[pos[i]] = c;
+        colmap[c] = pos[i];
+    } else {
+        colmap[c] = 0xFFFFFFFFu;
+    }
+}
+
 }  // namespace
 
 // =============================================================================================== C ABI
@@ -201,5 +227,41 @@ extern "C" int skm_csr_remap_columns(skm_ctx *ctx, int64_t n, const int64_t *d_r
     SKM_HIP(hipMemcpyAsync(h, d_out_rowptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     SKM_HIP(hipStreamSynchronize(st));
     *h_out_nnz = *h;
+    return SKM_OK;
+}
+
+extern "C" int skm_basis_select(skm_ctx *ctx, int64_t ncols, const uint32_t *d_fs_order, const uint64_t *d_total,
+                                uint64_t min_filter, uint32_t *d_keep, uint32_t *d_colmap, int64_t *h_nkeep)
+{
+    SKM_REQUIRE(ctx && ncols >= 0 && h_nkeep, SKM_E_BADARG, "skm_basis_select: bad argument");
+    SKM_REQUIRE(ncols < ((int64_t)1 << 32) - 1, SKM_E_OVERFLOW, "skm_basis_select: 2^32 columns or more");
+    *h_nkeep = 0;
+    if (ncols == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_fs_order && d_total && d_keep && d_colmap, SKM_E_BADARG, "skm_basis_select: null array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_A, sizeof(uint32_t) * (size_t)ncols, &p));
+    uint32_t *flags = (uint32_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_B, sizeof(uint32_t) * (size_t)(ncols + 1), &p));
+    uint32_t *pos = (uint32_t *)p;
+    const unsigned grid = (unsigned)skm_ceil_div(ncols, BLK);
+    SKM_PROF(ctx, "k_basis_select");
+    k_select_flags<<<grid, BLK, 0, st>>>(ncols, d_fs_order, d_total, min_filter, flags);
+    SKM_TRY(skm_check_launch("k_select_flags"));
+    {
+        size_t tmp = 0;
+        SKM_HIP(rocprim::exclusive_scan(nullptr, tmp, flags, pos, 0u, (size_t)ncols, rocprim::plus<uint32_t>(), st));
+        SKM_TRY(skm_ws(ctx, WS_ROCPRIM, tmp, &p));
+        SKM_HIP(rocprim::exclusive_scan(p, tmp, flags, pos, 0u, (size_t)ncols, rocprim::plus<uint32_t>(), st));
+    }
+    k_select_scatter<<<grid, BLK, 0, st>>>(ncols, d_fs_order, flags, pos, d_keep, d_colmap);
+    SKM_TRY(skm_check_launch("k_select_scatter"));
+    uint32_t *h = (uint32_t *)ctx->h_pinned;
+    SKM_HIP(hipMemcpyAsync(h, pos + (ncols - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SKM_HIP(hipMemcpyAsync(h + 1, flags + (ncols - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SKM_HIP(hipStreamSynchronize(st));
+    *h_nkeep = (int64_t)h[0] + (int64_t)h[1];
     return SKM_OK;
 }

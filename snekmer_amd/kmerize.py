@@ -84,13 +84,17 @@ def vectorize_packed(
     csr = engine.count_csr(ctx, batch, lut, k, with_firstpos=True)
     b = engine.build_basis(ctx, csr, lut.nsym, k, stats=True, first_seen=True, postings=False)
     B = b.ncols
+    d_keep = None
     if basis is None:
-        order = b.fs_order.download(B).astype(np.int64)          # columns in first-seen order
-        total = b.total.download(B)
-        keep = order[total[order] > min_filter]                 # kmerize.smk:102-104
-        colmap = np.full(max(B, 1), 0xFFFFFFFF, dtype=np.uint32)
-        colmap[keep] = np.arange(keep.size, dtype=np.uint32)
-        ncols_out = int(keep.size)
+        # columns in first-seen order, kept iff total occurrences > min_filter (kmerize.smk:102-104): on the device
+        import ctypes as C
+
+        d_keep = ctx.empty(max(B, 1), np.uint32)
+        d_colmap = ctx.empty(max(B, 1), np.uint32)
+        nkeep = C.c_int64(0)
+        ctx.call("skm_basis_select", C.c_int64(B), C.c_void_p(b.fs_order.ptr), C.c_void_p(b.total.ptr), C.c_uint64(max(int(min_filter), 0)),
+                 C.c_void_p(d_keep.ptr), C.c_void_p(d_colmap.ptr), C.byref(nkeep))
+        ncols_out = int(nkeep.value)  # (a negative min_filter keeps everything, like 0: every total is >= 1)
         kmerlist = None
     else:
         bcodes = b.codes.download(B).astype(np.uint64)
@@ -105,7 +109,7 @@ def vectorize_packed(
         ncols_out = int(len(kmerlist))
         if len(set(kmerlist.tolist())) != len(kmerlist):
             raise NotImplementedError("explicit basis with repeated k-mers is unsupported")
-    d_colmap = ctx.to_device(colmap)
+        d_colmap = ctx.to_device(colmap)
     # additive: integer counts in the kmerlist column order, CSR
     c_rowptr, c_col, c_val = engine.csr_remap_columns(ctx, csr, d_colmap, B)
     vecs = None
@@ -118,7 +122,7 @@ def vectorize_packed(
     # string forms: reduced sequences (kmerize.smk:121-127) and the basis k-mers (kmerize.smk:102-106)
     seqs = engine.reduced_strings(ctx, batch, lut)
     if kmerlist is None:
-        kmerlist = engine.decode_kmers(ctx, lut, k, b.codes, ncols_out, ctx.to_device(keep.astype(np.uint32)) if ncols_out else None)
+        kmerlist = engine.decode_kmers(ctx, lut, k, b.codes, ncols_out, d_keep)
     t2 = time.perf_counter()
     if timings is not None:
         timings["gpu_s"] = timings.get("gpu_s", 0.0) + t1 - t0
