@@ -151,11 +151,13 @@ def vectorize_fasta(
     sparse_npz_out: Optional[str] = None,
     timings: Optional[dict] = None,
     dense: Optional[bool] = None,
+    compressed: bool = True,
 ) -> Dict[str, np.ndarray]:
     """FASTA -> the rule's outputs; optionally writes the ``.npz`` and the pickled KmerVec
     (``.kmers``) exactly as rules/kmerize.smk:132-142 does.  `sparse_npz_out` writes the sparse
     variant (io.save_npz_sparse: CSR counts, no dense matrix); without `npz_out` the dense
-    N x |basis| float64 matrix is then never built.  `dense=False` skips it when nothing is written either.  `timings` (optional
+    N x |basis| float64 matrix is then never built.  `dense=False` skips it when nothing is written either; `compressed=False`
+    writes the ``.npz`` members uncompressed (np.load reads both; the reference compresses, rules/kmerize.smk:132).  `timings` (optional
     dict) receives parse_s / gpu_s / decode_s / write_s."""
     t0 = time.perf_counter()
     ids, res, off = read_fasta_packed(path)
@@ -166,9 +168,9 @@ def vectorize_fasta(
                            timings=timings)
     t0 = time.perf_counter()
     if sparse_npz_out:
-        save_npz_sparse(sparse_npz_out, out)
+        save_npz_sparse(sparse_npz_out, out, compressed=compressed)
     if npz_out:
-        np.savez_compressed(
+        (np.savez_compressed if compressed else np.savez)(
             npz_out, kmerlist=out["kmerlist"], ids=out["ids"], seqs=out["seqs"], vecs=out["vecs"], lengths=out["lengths"]
         )
     if kmers_out:

@@ -37,7 +37,13 @@ def draw_batch(rng, big=False):
             L = int(rng.integers(5000, 22000))
         low = rng.random() < 0.15  # low-complexity family: few distinct residues, many repeated k-mers
         root = AA[rng.integers(0, 3 if low else 20, size=L)]
-        for _ in range(int(rng.integers(20, 90)) if big else int(rng.integers(1, 40))):
+        members = int(rng.integers(20, 90)) if big else int(rng.integers(1, 40))
+        if big and len(seqs) < 3000 and rng.random() < 0.04:
+            # one family of thousands: every member has more neighbours than the first sparse pass holds (1536), so
+            # the rows go through k_cosine_heavy, and skm_gram_neighbors through its large-table tiers
+            members, L = int(rng.integers(1600, 2600)), int(rng.integers(40, 200))
+            root = AA[rng.integers(0, 20, size=L)]
+        for _ in range(members):
             s = root.copy()
             if L:
                 m = rng.random(L) < rng.choice([0.0, 0.02, 0.1, 0.3])
