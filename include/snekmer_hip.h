@@ -54,6 +54,13 @@ const char *skm_last_error(void);
 int skm_device_count(int *h_count);
 int skm_create(int device_id, skm_ctx **out_ctx);
 int skm_destroy(skm_ctx *ctx);
+/* Ordering between two contexts of one process on one device (a context is one stream): skm_event_record marks the
+ * current end of ctx's stream in slot [0, SKM_EVENT_SLOTS); skm_stream_wait makes everything queued on ctx from now
+ * on wait for the mark last recorded in src's slot (no-op if none was).  Neither blocks the host.  Used by
+ * engine.OverlappedPipeline: the next batch is vectorized on a second context while this one's Gram runs. */
+#define SKM_EVENT_SLOTS 8
+int skm_event_record(skm_ctx *ctx, int slot);
+int skm_stream_wait(skm_ctx *ctx, skm_ctx *src, int slot);
 int skm_sync(skm_ctx *ctx); /* host-synchronous */
 int skm_device_info(skm_ctx *ctx, char *h_name, int name_cap, int *h_cus, int64_t *h_mem_bytes);
 

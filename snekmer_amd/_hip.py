@@ -49,6 +49,8 @@ _SIGNATURES = {
     "skm_create": (C.c_int, [C.c_int, C.POINTER(_p)]),
     "skm_destroy": (C.c_int, [_p]),
     "skm_sync": (C.c_int, [_p]),
+    "skm_event_record": (C.c_int, [_p, C.c_int]),
+    "skm_stream_wait": (C.c_int, [_p, _p, C.c_int]),
     "skm_device_info": (C.c_int, [_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_i64)]),
     "skm_malloc": (C.c_int, [_p, C.c_size_t, C.POINTER(_p)]),
     "skm_free": (C.c_int, [_p, _p]),
@@ -284,6 +286,14 @@ class Context:
 
     def sync(self):
         _check(self.lib, self.lib.skm_sync(self.handle))
+
+    def record_event(self, slot: int):
+        """Mark the current end of this context's stream in `slot` (skm_event_record)."""
+        _check(self.lib, self.lib.skm_event_record(self.handle, slot))
+
+    def wait_event(self, src: "Context", slot: int):
+        """Everything queued on this context from now on waits for the mark `src` last recorded in `slot`."""
+        _check(self.lib, self.lib.skm_stream_wait(self.handle, src.handle, slot))
 
     def device_info(self) -> Tuple[str, int, int]:
         name = C.create_string_buffer(256)

@@ -64,12 +64,41 @@ extern "C" int skm_destroy(skm_ctx *ctx)
         hipEventDestroy(ctx->ev_host);
     for (auto e : ctx->sync_events)
         hipEventDestroy(e);
+    for (auto e : ctx->user_events)
+        if (e)
+            hipEventDestroy(e);
     if (ctx->s_writer)
         hipStreamDestroy(ctx->s_writer);
     if (ctx->s_gram)
         hipStreamDestroy(ctx->s_gram);
     hipStreamDestroy(ctx->stream);
     delete ctx;
+    return SKM_OK;
+}
+
+// Ordering between two contexts of one process (each context is one stream): `skm_event_record` marks the current end
+// of this context's stream in one of its SKM_EVENT_SLOTS slots; `skm_stream_wait` makes everything queued on `ctx`
+// from now on wait for the mark last recorded in `src`'s slot.  Neither blocks the host.
+extern "C" int skm_event_record(skm_ctx *ctx, int slot)
+{
+    SKM_REQUIRE(ctx && slot >= 0 && slot < SKM_EVENT_SLOTS, SKM_E_BADARG, "skm_event_record: bad argument");
+    SKM_HIP(hipSetDevice(ctx->device));
+    if (ctx->user_events.empty())
+        ctx->user_events.assign(SKM_EVENT_SLOTS, nullptr);
+    if (!ctx->user_events[slot])
+        SKM_HIP(hipEventCreateWithFlags(&ctx->user_events[slot], hipEventDisableTiming));
+    SKM_HIP(hipEventRecord(ctx->user_events[slot], ctx->stream));
+    return SKM_OK;
+}
+
+extern "C" int skm_stream_wait(skm_ctx *ctx, skm_ctx *src, int slot)
+{
+    SKM_REQUIRE(ctx && src && slot >= 0 && slot < SKM_EVENT_SLOTS, SKM_E_BADARG, "skm_stream_wait: bad argument");
+    SKM_REQUIRE(ctx->device == src->device, SKM_E_BADARG, "skm_stream_wait: contexts on different devices");
+    if (src->user_events.empty() || !src->user_events[slot])
+        return SKM_OK;  // nothing was ever recorded there: nothing to wait for
+    SKM_HIP(hipSetDevice(ctx->device));
+    SKM_HIP(hipStreamWaitEvent(ctx->stream, src->user_events[slot], 0));
     return SKM_OK;
 }
 

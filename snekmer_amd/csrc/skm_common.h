@@ -47,6 +47,7 @@ struct skm_ctx {
     hipStream_t s_writer = nullptr, s_gram = nullptr;
     std::vector<hipEvent_t> sync_events;
     int overlap_state = 0;
+    std::vector<hipEvent_t> user_events;  // skm_event_record slots, created on first use
     // RCCL (loaded lazily with dlopen; see skm_comm.hip)
     void *rccl_lib = nullptr;
     void *comm = nullptr;

@@ -609,3 +609,69 @@ class Pipeline:
     def step(self, batch: SeqBatch):
         self.vectorize(batch)
         return self.cosine()
+
+
+class OverlappedPipeline:
+    """Pipeline for a STREAM of batches: while batch i's cosine runs on the main context, batch i+1 is vectorized on a
+    second context (its own HIP stream and scratch) into a second set of buffers.  The stages in front of the writer
+    are latency- and issue-bound (0.13-0.29 of HBM each), so the next batch's count / sort / scatter
+    fill the machine beside this batch's sparse Gram; the HBM-bound writer then runs as before.  Results are the
+    single-stream Pipeline's, bit for bit (same kernels, same inputs; tests/test_gpu_parity.py).
+
+        pipe = OverlappedPipeline(ctx, lut, k)
+        pipe.prefetch(batch0)
+        for nxt in batches[1:] + [None]:
+            out = pipe.step(nxt)       # cosine of the prefetched batch; vectorize of `nxt` starts beside it
+
+    `out` (float32 [n, ld], HBM) is shared by all steps: consume it (or copy it) before the next step's writer runs,
+    i.e. before calling step() again, exactly as with Pipeline."""
+
+    EV_VEC, EV_COS = 0, 2  # event slots: EV_VEC + set on the side context, EV_COS + set on the main one
+
+    def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int, side_ctx: Optional[_hip.Context] = None):
+        self.ctx, self.lut, self.k = ctx, lut, k
+        self.side = side_ctx or _hip.Context(ctx.device)
+        self.sets = [[None, None, None], [None, None, None]]  # (csr, basis, rnorm) per buffer set
+        self.ready = None   # set holding a vectorized batch that has not been consumed yet
+        self.nxt = 0
+        self.out = None
+        self.csr = self.basis = self.rnorm = None  # the set the last step() consumed
+
+    def prefetch(self, batch: SeqBatch) -> None:
+        """Vectorize `batch` on the side context into the free buffer set."""
+        if self.ready is not None:
+            raise RuntimeError("a prefetched batch is waiting: call step() first")
+        s = self.nxt
+        # the set's previous contents were last read by the cosine two steps ago
+        self.side.wait_event(self.ctx, self.EV_COS + s)
+        if batch.ctx is not self.side and batch.ctx is not self.ctx:
+            raise ValueError("the batch must live on the pipeline's device")
+        csr, basis, rnorm = self.sets[s]
+        self.sets[s] = list(vectorize_fused(self.side, batch, self.lut, self.k, csr=csr, basis=basis, rnorm=rnorm))
+        self.side.record_event(self.EV_VEC + s)
+        self.ready = s
+        self.nxt = 1 - s
+
+    def step(self, next_batch: Optional[SeqBatch] = None):
+        """Cosine of the prefetched batch (queued on the main context), then the prefetch of `next_batch`."""
+        if self.ready is None:
+            raise RuntimeError("nothing prefetched: call prefetch(batch) first")
+        s, self.ready = self.ready, None
+        self.csr, self.basis, self.rnorm = self.sets[s]
+        self.ctx.wait_event(self.side, self.EV_VEC + s)
+        n = self.csr.n
+        ld = (n + 3) // 4 * 4
+        if self.out is None or self.out.shape != (max(n, 1), max(ld, 1)):
+            self.out = None
+            self.out = self.ctx.empty((max(n, 1), max(ld, 1)), np.float32)
+        b = self.basis
+        cosine_matrix(self.ctx, self.csr, self.rnorm, n, b.ncols_hint(), b.colptr, b.post, self.rnorm, out=self.out, ld=ld,
+                      post_bits=b.post_bits, postcnt=b.postcnt)
+        self.ctx.record_event(self.EV_COS + s)
+        if next_batch is not None:
+            self.prefetch(next_batch)
+        return self.out
+
+    def sync(self):
+        self.side.sync()
+        self.ctx.sync()

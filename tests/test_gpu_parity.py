@@ -860,6 +860,38 @@ def test_overlapped_cosine_schedule_equals_default(ctx, monkeypatch):
         assert (got.download(cnt, offset=r0 * ld) == ref.download(cnt, offset=r0 * ld)).all()
 
 
+def test_overlapped_pipeline_equals_pipeline_on_a_stream_of_batches(ctx):
+    """engine.OverlappedPipeline (batch i+1 vectorized on a second context while batch i's cosine runs; two buffer sets,
+    cross-context events) over five different batches of different sizes: every result identical to Pipeline's."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+
+    lut = A.build_lut("red6")
+    batches = []
+    for i, n in enumerate((1500, 2600, 1100, 2600, 40)):
+        res, off, _ = synth_families(n, 300, family=25, seed=300 + i)
+        batches.append(engine.SeqBatch(ctx, res, off))
+    ref = engine.Pipeline(ctx, lut, 12)
+    want = []
+    for b in batches:
+        S = ref.step(b)
+        want.append(S.download().reshape(S.shape)[: b.n, : b.n].copy())
+    pipe = engine.OverlappedPipeline(ctx, lut, 12)
+    with pytest.raises(RuntimeError):
+        pipe.step(batches[0])
+    pipe.prefetch(batches[0])
+    for i, b in enumerate(batches):
+        nxt = batches[i + 1] if i + 1 < len(batches) else None
+        out = pipe.step(nxt)
+        pipe.sync()
+        got = out.download().reshape(out.shape)[: b.n, : b.n]
+        assert (got == want[i]).all(), i
+        assert pipe.csr.nnz == int(pipe.csr.rowptr.download(1, offset=b.n)[0]) and pipe.csr.n == b.n
+    with pytest.raises(RuntimeError):
+        pipe.step(None)
+
+
 # ------------------------------------------------------------------ BASELINE full sizes
 def _sampled_row_check(ctx, name, k, n, seed_idx, nsample=48, family=100, full_stats=False, packed=None):
     from snekmer_amd import alphabet as A

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""tools only: engine.Pipeline (one stream) against engine.OverlappedPipeline (next batch vectorized on a second
+context beside this batch's Gram) on the bench workload: ms per step of each, interleaved, and a bit-for-bit check of
+the result (row sums + non-zero counts of the whole matrix, and 64 rows)."""
+import json
+import sys
+import time
+import os
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from snekmer_amd import _hip, alphabet, engine
+    from snekmer_amd.synth import BASE_SEED, synth_families
+
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    alphabet.register_alphabet("red6", alphabet.RED6_GROUPS)
+    ctx = _hip.Context(0)
+    lut = alphabet.build_lut("red6")
+    res, off, _ = synth_families(n, 300, family=100, seed=BASE_SEED + 2)
+    batch = engine.SeqBatch(ctx, res, off)
+    a = engine.Pipeline(ctx, lut, 12)
+    b = engine.OverlappedPipeline(ctx, lut, 12)
+    b.out = a.step(batch)  # share the 40 GB result buffer
+    ctx.sync()
+    ld = a.out.shape[1]
+    sums_a, nnz_a = engine.matrix_row_stats(ctx, a.out, n, n, ld)
+    rows = np.linspace(0, n - 1, 64).astype(np.int64)
+    want = [a.out.download(n, offset=int(r) * ld) for r in rows]
+    ctx.call("skm_memset", __import__("ctypes").c_void_p(a.out.ptr), 0, __import__("ctypes").c_size_t(a.out.nbytes))
+    b.prefetch(batch)
+    b.step(batch)
+    b.sync()
+    sums_b, nnz_b = engine.matrix_row_stats(ctx, b.out, n, n, ld)
+    same = bool((sums_a == sums_b).all() and (nnz_a == nnz_b).all() and
+                all((b.out.download(n, offset=int(r) * ld) == w).all() for r, w in zip(rows, want)))
+    out = {"n": n, "steps": steps, "identical": same, "runs": []}
+    for rep in range(3):
+        a.step(batch)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            a.step(batch)
+        ctx.sync()
+        ta = (time.perf_counter() - t0) / steps * 1e3
+        b.step(batch)
+        b.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            b.step(batch)
+        b.sync()
+        tb = (time.perf_counter() - t0) / steps * 1e3
+        out["runs"].append({"pipeline_ms": ta, "overlapped_ms": tb})
+    # drain the prefetched batch so that the process ends with nothing queued
+    b.step(None)
+    b.sync()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
