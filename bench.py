@@ -747,6 +747,26 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
     line["overlap_schedule"] = {"ms_per_step": ov_ms, "sequences_per_s": n_total / (ov_ms * 1e-3),
                                 "what": "SKM_COSINE_OVERLAP=1: same step, Gram and writer kernels on two CU-partitioned streams"}
 
+    # engine.OverlappedPipeline: a stream of batches, batch i+1 vectorized on a second context while batch i's cosine runs
+    op = engine.OverlappedPipeline(ctx, pipe.lut, pipe.k)
+    op.out = pipe.out  # share the 40 GB result buffer
+    op.prefetch(batch)
+    op.step(batch)
+    op.sync()
+    t1 = time.perf_counter()
+    for _ in range(10):
+        op.step(batch)
+    op.sync()
+    op_ms = (time.perf_counter() - t1) / 10 * 1e3
+    op.step(None)  # consume the batch still prefetched
+    op.sync()
+    op.out = None
+    del op
+    note("extras: overlapped_pipeline")
+    line["overlapped_pipeline"] = {"ms_per_step": op_ms, "sequences_per_s": n_total / (op_ms * 1e-3),
+                                   "what": "engine.OverlappedPipeline: the next batch's count / sort / scatter run on a second context "
+                                           "(own stream, second buffer set) beside this batch's cosine; results identical to Pipeline's"}
+
     if args.alphabet == "red6":
         # red6 is a benchmark alphabet; the nearest reference alphabet (`standard`,
         # 7^12 needs uint64 codes) is timed next to it on the same sequences

@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def avg(path, counter):
@@ -49,7 +49,7 @@ out = {
              "half of wide streaming reads; for the random 8-byte reads of k_gram_sparse and k_basis_scatter the factor is "
              "uncalibrated: raw and doubled values both given)",
 }
-for k in ("k_cosine_write", "k_gram_sparse", "k_basis_scatter", "k_basis_scatter_fused", "k_compact_rows", "k_head_count", "k_count_short"):
+for k in ("k_cosine_write", "k_cosine_heavy", "k_gram_sparse", "k_basis_scatter", "k_basis_scatter_fused", "k_compact_rows", "k_head_count", "k_count_short"):
     if k not in w or k not in f:
         continue
     out[k] = {"WRITE_SIZE_KiB": w[k][0], "FETCH_SIZE_KiB_raw": f[k][0], "launches_sampled": w[k][1], "write_bytes": w[k][0] * 1024,
