@@ -375,7 +375,7 @@ __global__ __launch_bounds__(WTB) void k_cosine_write(const uint64_t *__restrict
 // ones), adding v * v' with plain LDS atomics: no hash, no probe, no capacity other than the number of the row's own
 // shared non-zeros (HEAVY_EMAX; rows beyond that stay flagged for the cursor kernel).  The step's tile is then scaled
 // and stored like the writer's.  A row done here gets g_len = G_DONE_ROW: the writer's workgroup for it exits.
-constexpr int HEAVY_CH = 32768, HEAVY_TB = 1024, HEAVY_EMAX = 2048, HEAVY_U = 4;
+constexpr int HEAVY_CH = 32768, HEAVY_TB = 1024, HEAVY_EMAX = 2048, HEAVY_U = 4, HEAVY_NG = 4;
 
 template <int MODE, bool VEC, typename PW>
 __global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__restrict__ xrowptr,
@@ -462,63 +462,58 @@ __global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__rest
         for (int64_t j0 = 0; j0 < m; j0 += CHH) {
             const uint32_t j0u = (uint32_t)j0;
             const uint32_t j1u = (uint32_t)min(j0 + (int64_t)CHH, m);
-            // ---- long lists: one wave per list, U loads per lane and round; the first round of the wave's next list
-            // is in flight while the current list is added (two register sets used in turn: a copy would wait)
+            // ---- long lists: a wave takes NG lists at a time and issues the first round of all of them (U loads per lane
+            // and list) before it adds any: one memory round trip per NG lists instead of one per list
             if (nlong) {
-                PW buf[2][U];
-                uint32_t lp[2], lpe[2], lv[2];
-                bool lh[2];
-                auto issue = [&](PW(&pw)[U], uint32_t p, uint32_t pe) {
+                constexpr int NG = HEAVY_NG;
+                for (uint32_t l0 = (uint32_t)wid * NG; l0 < nlong; l0 += NW * NG) {  // wave-uniform
+                    PW buf[NG][U];
+                    uint32_t lp[NG], lpe[NG], lv[NG];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const uint32_t at = p + (uint32_t)(u * 64 + lane);
-                        pw[u] = ypost[at < pe ? at : (pe ? pe - 1u : 0u)];
-                    }
-                };
-                auto fetch = [&](int d, uint32_t l) {
-                    lh[d] = l < nlong;
-                    const uint32_t ll = lh[d] ? l : 0u;
-                    lp[d] = s_cur[ll];
-                    lpe[d] = lh[d] ? s_end[ll] : 0u;
-                    lv[d] = s_val[ll];
-                    issue(buf[d], lp[d], lpe[d]);
-                };
-                auto consume = [&](int d, uint32_t l) {
-                    uint32_t p = lp[d];
-                    const uint32_t pe = lpe[d], v = lv[d];
-                    bool loaded = true;
-                    while (p < pe) {
-                        if (!loaded)
-                            issue(buf[d], p, pe);
-                        loaded = false;
-                        uint32_t took = 0;
+                    for (int g = 0; g < NG; ++g) {
+                        const uint32_t l = l0 + (uint32_t)g;
+                        const bool have = l < nlong;
+                        const uint32_t ll = have ? l : 0u;
+                        lp[g] = s_cur[ll];
+                        lpe[g] = have ? s_end[ll] : 0u;
+                        lv[g] = s_val[ll];
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                            const uint32_t at = p + (uint32_t)(u * 64 + lane);
-                            const uint32_t j = posting<PW>::row(buf[d][u]);
-                            const bool in = at < pe && j < j1u;
-                            if (in)
-                                atomicAdd(&s_acc[j - j0u], (int)(v * posting<PW>::count(buf[d][u], ypostcnt, at)));
-                            took += (uint32_t)__popcll(__ballot(in));
+                            const uint32_t at = lp[g] + (uint32_t)(u * 64 + lane);
+                            buf[g][u] = ypost[at < lpe[g] ? at : (lpe[g] ? lpe[g] - 1u : 0u)];
                         }
-                        p += took;
-                        if (took < (uint32_t)(U * 64))
-                            break;  // the list's part of this column range is done (or the list is)
                     }
-                    if (lane == 0 && lh[d])
-                        s_cur[l] = p;
-                };
-                uint32_t l = (uint32_t)wid;
-                fetch(0, l);
-                while (l < nlong) {  // wave-uniform
-                    fetch(1, l + NW);
-                    consume(0, l);
-                    l += NW;
-                    if (l >= nlong)
-                        break;
-                    fetch(0, l + NW);
-                    consume(1, l);
-                    l += NW;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        uint32_t p = lp[g];
+                        const uint32_t pe = lpe[g], v = lv[g];
+                        bool loaded = true;
+                        while (p < pe) {
+                            if (!loaded) {
+#pragma unroll
+                                for (int u = 0; u < U; ++u) {
+                                    const uint32_t at = p + (uint32_t)(u * 64 + lane);
+                                    buf[g][u] = ypost[at < pe ? at : pe - 1u];
+                                }
+                            }
+                            loaded = false;
+                            uint32_t took = 0;
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const uint32_t at = p + (uint32_t)(u * 64 + lane);
+                                const uint32_t j = posting<PW>::row(buf[g][u]);
+                                const bool in = at < pe && j < j1u;
+                                if (in)
+                                    atomicAdd(&s_acc[j - j0u], (int)(v * posting<PW>::count(buf[g][u], ypostcnt, at)));
+                                took += (uint32_t)__popcll(__ballot(in));
+                            }
+                            p += took;
+                            if (took < (uint32_t)(U * 64))
+                                break;  // the list's part of this column range is done (or the list is)
+                        }
+                        if (lane == 0 && l0 + (uint32_t)g < nlong)
+                            s_cur[l0 + g] = p;
+                    }
                 }
             }
             // ---- short lists (at most 64 postings): four lists per wave and round, 16 lanes each
