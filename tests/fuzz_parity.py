@@ -279,6 +279,19 @@ def score_round(ctx, seed):
     assert np.abs(D - pairwise_distances(X, metric="cosine")).max() <= 1e-5 and (np.diag(D) == 0).all(), f"{tag}: cosine distance"
     Df = skm.score.connection_matrix_from_features(Xf, metric="cosine")
     assert np.abs(Df - pairwise_distances(Xf, metric="cosine")).max() <= 1e-12, f"{tag}: cosine distance, real-valued"
+    import warnings
+
+    from snekmer_amd.score import PAIRWISE_METRICS
+
+    metric = sorted(PAIRWISE_METRICS)[int(rng.integers(0, len(PAIRWISE_METRICS)))]
+    Xm = Xf if rng.random() < 0.5 else X.astype(np.float64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = pairwise_distances(Xm, metric=metric)
+    got = skm.score.connection_matrix_from_features(Xm, metric=metric)
+    assert (np.isnan(got) == np.isnan(want)).all(), f"{tag}: {metric} nan pattern"
+    scale = max(1.0, float(np.nanmax(np.abs(want), initial=0.0)))
+    assert np.nanmax(np.abs(got - want), initial=0.0) <= 1e-11 * scale, f"{tag}: {metric}"
     Bm = X > 0
     for M, what in ((Bm, "binary"), (X, "counts"), (np.round(Xf, 1), "real-valued")):
         H = skm.score.connection_matrix_from_features(M)  # metric="jaccard": 1 - hamming upstream
