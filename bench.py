@@ -664,6 +664,42 @@ def skewed_workload(ctx, engine, alphabet, args, pipe, line):
     return out
 
 
+def real_proteome(ctx, engine, alphabet):
+    """Real sequences: the proteome the reference's CI runs (UP000322080, 3 383 proteins, lengths 30-2 900; a data
+    fixture under tests/golden/data), vectorize + full N x N cosine at the CI's own configuration (solvacc k=8: a
+    3^8 = 6 561-column basis, every row shares k-mers with every other: the dense regime) and at k=12 in a
+    reference alphabet (standard: the sparse regime).  Parity of both: tests/test_gpu_parity.py::test_real_proteome_*."""
+    import ctypes as C
+
+    from snekmer_amd.io import read_fasta_packed
+
+    path = os.path.join(ROOT, "tests", "golden", "data", "UP000322080_2603819.fasta")
+    if not os.path.exists(path):
+        return {"skipped": "fixture not found"}
+    ids, res, off = read_fasta_packed(path)
+    batch = engine.SeqBatch(ctx, res, off)
+    out = {"file": "tests/golden/data/UP000322080_2603819.fasta", "sequences": int(len(ids)), "residues": int(off[-1]),
+           "longest": int(np.diff(off).max()), "runs": []}
+    for name, k in (("solvacc", 8), ("standard", 12)):
+        p = engine.Pipeline(ctx, alphabet.build_lut(name), k)
+        for _ in range(3):
+            p.step(batch)
+        ctx.sync()
+        reps = 20
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            p.step(batch)
+        ctx.sync()
+        dt = (time.perf_counter() - t1) / reps
+        st = (C.c_int64 * 3)()
+        ctx.call("skm_cosine_csr_stats", st)
+        out["runs"].append({"alphabet": name, "k": k, "ms_per_step": dt * 1e3, "sequences_per_s": len(ids) / dt,
+                            "residues_per_s": int(off[-1]) / dt, "nnz": p.csr.nnz, "basis_columns": p.basis.ncols,
+                            "rows_handed_to_k_cosine_heavy": int(st[0]), "strips_left_to_cursor_kernel": int(st[1])})
+        del p
+    return out
+
+
 def api_vectorize_fasta(args, seed):
     """What a Snekmer user sees: kmerize.vectorize_fasta (the body of rules/kmerize.smk:67-142) on a synthetic FASTA
     FILE, host time included, split into parse (threaded C reader -> packed residues), device work that produces
@@ -790,6 +826,8 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
 
     line["skewed_workload"] = skewed_workload(ctx, engine, alphabet, args, pipe, line)
     note("extras: skewed_workload")
+    line["real_proteome"] = real_proteome(ctx, engine, alphabet)
+    note("extras: real_proteome")
     line["api_vectorize_fasta"] = api_vectorize_fasta(args, seed)
     note("extras: api_vectorize_fasta")
 
