@@ -13,7 +13,8 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnekmer_hip.so")
+# SNEKMER_HIP_LIB: another build of the same library (tools/: A/B of compile-time kernel shapes in one GPU-box run)
+LIB_PATH = os.environ.get("SNEKMER_HIP_LIB") or os.path.join(_HERE, "libsnekmer_hip.so")
 
 SKM_OK = 0
 ERRORS = {-1: "BADARG", -2: "NOMEM", -3: "HIP", -4: "OVERFLOW", -5: "UNSUPPORTED", -6: "COMM"}

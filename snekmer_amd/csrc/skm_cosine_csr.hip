@@ -54,6 +54,9 @@ constexpr int TB = 256;
 constexpr int Q = 10;  // register-resident tasks per thread -> Q*TB = 2560 tasks per strip
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef SKM_FIRST_GH
+#define SKM_FIRST_GH 2048
+#endif
 constexpr uint32_t G_DONE_ROW = 0xFFFFFFFEu;  // g_len of a row k_cosine_heavy has already written
 
 // ------------------------------------------------------------------------------- sparse Gram
@@ -1103,7 +1106,9 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     // neighbour lists: row r of the block owns SLOT entries at g_ent[r * SLOT] (all the first pass
     // can produce, and never more than the m neighbours a row can have); the lists of the large-table
     // pass are allocated behind that region
-    const unsigned long long SLOT = (unsigned long long)(m < 1536 ? m : 1536);  // 1536 = the first pass's table capacity
+    constexpr int FIRST_GH = SKM_FIRST_GH;                 // hash slots of the first pass (a row holds 3/4 of them)
+    constexpr long long FIRST_CAP = FIRST_GH / 4 * 3;
+    const unsigned long long SLOT = (unsigned long long)(m < FIRST_CAP ? m : FIRST_CAP);
     const unsigned long long fixed_ent = (unsigned long long)nrows * SLOT;
     const unsigned long long cap_ent = fixed_ent + (unsigned long long)max((int64_t)(1 << 20), nrows * 256);
     void *p;
@@ -1169,13 +1174,13 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
             // one row per workgroup, 2048 slots: 26 KB of LDS -> 6 workgroups per CU
             SKM_PROF_ON(ctx, "k_gram_sparse", gs);
 #define SKM_GRAM(GABL)                                                                                               \
-    k_gram_sparse<GABL, 1, 2048, 256, 2, 32, 2, PW><<<(unsigned)bn, 256, 0, gs>>>(                                   \
+    k_gram_sparse<GABL, 1, FIRST_GH, 256, 2, 32, 2, PW><<<(unsigned)bn, 256, 0, gs>>>(                               \
         d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0 + b0, row0 + b1, SLOT, b0, g_ent, cap_ent, \
         g_counter, g_start + b0, g_len + b0, b_over_list, b_over_count)
 #ifdef SKM_DIAG
             // diagnostic: other lane-group shapes for the lists of 17+ postings (exact results)
 #define SKM_GRAM_SHAPE(GG, UU)                                                                                       \
-    k_gram_sparse<0, 1, 2048, 256, 2, GG, UU, PW><<<(unsigned)bn, 256, 0, gs>>>(                                     \
+    k_gram_sparse<0, 1, FIRST_GH, 256, 2, GG, UU, PW><<<(unsigned)bn, 256, 0, gs>>>(                                 \
         d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0 + b0, row0 + b1, SLOT, b0, g_ent, cap_ent, \
         g_counter, g_start + b0, g_len + b0, b_over_list, b_over_count)
             const char *shape_env = getenv("SKM_GRAM_SHAPE");

@@ -88,7 +88,7 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     __shared__ uint64_t s_queue[GT / 64][GQCAP];
     __shared__ int s_over;
     __shared__ uint32_t s_pairs;
-    constexpr int HEAVY_PAIRS = 16 * GMAXD;
+    constexpr int HEAVY_PAIRS = 24576;  // 16 visits per slot of a 2048-slot table's capacity
     const int tid = threadIdx.x, lane = tid & 63;
     const int rows = (int)min((int64_t)GR, row1 - i0);
     unsigned long long stamp = 0;
@@ -197,8 +197,8 @@ __device__ __forceinline__ void gram_strip(const int64_t i0, const int64_t *__re
     // of 2 postings on a 32-lane group would leave 30 lanes idle: at 100 k sequences half of the
     // lists have fewer than 5 postings).  Bin c holds t_*[s_off[c] .. s_off[c + 1]).
     // First pass only (rows with a fixed list slot): a row whose posting lists hold more than HEAVY_PAIRS postings
-    // in total is handed on at once.  It would almost certainly outgrow the table (HEAVY_PAIRS = 16 visits per slot
-    // of capacity), and finding that out by walking costs most of the walk: on a batch with families of thousands
+    // in total is handed on at once.  It would almost certainly outgrow the table, and finding that out by walking
+    // costs most of the walk: on a batch with families of thousands
     // the aborted walks were 13 ms of a 39 ms step.  The pass behind this one is exact for any row, so the rule only
     // moves work; it never changes a result.
     if (fixed_stride != 0ull) {
