@@ -989,6 +989,16 @@ def test_heavy_rows_every_list_shape_vs_oracle(ctx, mode):
     blk = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, bs.ncols_hint(), bs.colptr, bs.post, pipe.rnorm, row0=301, row1=1777,
                                mode=mode, ld=ld).download().reshape(-1, ld)[: 1777 - 301, :n]
     assert (blk == S[301:1777]).all()
+    # a row stride that is not a multiple of four (scalar stores) and 32-bit posting words: the same values
+    odd = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, bs.ncols_hint(), bs.colptr, bs.post, pipe.rnorm, mode=mode, ld=n + 1)
+    assert (odd.download().reshape(-1, n + 1)[:n, :n] == S).all()
+    p32 = engine.Pipeline(ctx, lut, k, post32=True)
+    p32.vectorize(batch)
+    b32 = p32.basis
+    assert b32.post_bits == 32
+    S32 = engine.cosine_matrix(ctx, p32.csr, p32.rnorm, n, b32.ncols, b32.colptr, b32.post, p32.rnorm, mode=mode, ld=ld,
+                               post_bits=32, postcnt=b32.postcnt)
+    assert (S32.download().reshape(-1, ld)[:n, :n] == S).all()
 
 
 @pytest.mark.parametrize("name,k", [("red6", 12), ("standard", 12), ("hydro", 14)])
