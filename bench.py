@@ -84,7 +84,7 @@ def cpu_baseline(alphabet_name, k, seed, points, budget_s, n_sparse):
 
     # sparse C restatement while the children run (it uses other cores)
     lut = alphabet.build_lut(alphabet_name)
-    threads = c_oracle.host_threads()
+    threads = c_oracle.host_threads(ignore_omp_env=not points)  # multi-rank runs: the launcher pins OMP_NUM_THREADS=1
 
     def sparse(n, nthreads):
         res, off, _ = synth_families(n, 300, family=100, seed=seed)
@@ -269,8 +269,7 @@ def self_launch(n_ranks: int) -> int:
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     note("self-launch: " + " ".join(cmd))
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
     line = None
     for raw in proc.stdout:

@@ -54,9 +54,11 @@ def kmer_codes(rank, nsym, k, seq, off):
     return codes[: len(seq)], nwin
 
 
-def host_threads() -> int:
+def host_threads(ignore_omp_env: bool = False) -> int:
     """Threads the multi-threaded forms use by default: the OpenMP maximum capped by the CPUs this
-    process may run on (cgroup-limited boxes report all host cores to OpenMP)."""
+    process may run on (cgroup-limited boxes report all host cores to OpenMP).  `ignore_omp_env`: do not cap by
+    OMP_NUM_THREADS (torch.distributed.run sets it to 1 for every rank; the `_mt` entry points take their thread
+    count as an argument, so the environment does not bind them)."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:  # pragma: no cover
@@ -70,6 +72,8 @@ def host_threads() -> int:
         pass
     # a one-GPU share of a GPU host is 16 CPUs (the pool's guidance); SKM_HOST_THREADS overrides the cap
     cap = int(os.environ.get("SKM_HOST_THREADS", "16"))
+    if ignore_omp_env:
+        return max(1, min(avail, cap))
     return max(1, min(avail, cap, int(lib().orc_max_threads())))
 
 
