@@ -241,7 +241,9 @@ def pairwise_distances(X, metric: str = "euclidean", p: float = 2.0, ctx=None) -
     device for the metrics that are sums or maxima over columns (cityblock / manhattan / l1, euclidean / l2,
     sqeuclidean, chebyshev, canberra, braycurtis, minkowski) and scipy's boolean dissimilarities (dice,
     rogerstanimoto, russellrao, sokalmichener, sokalsneath, yule; the input read as x != 0); "cosine", "hamming" /
-    "matching" go to their own kernels.  Square float64 matrix with an exact-zero diagonal.  Metrics that need more
+    "matching" go to their own kernels.  Square float64 matrix with an exact-zero diagonal.  "euclidean" / "l2" sum
+    (x - y)^2 directly where sklearn takes sqrt(xx + yy - 2 xy): the two agree to the rounding error of sklearn's
+    expansion (eps * (xx + yy) in the squared distance), and duplicate rows get an exact 0 here.  Metrics that need more
     than the two rows (mahalanobis, seuclidean, correlation, ...) raise NotImplementedError: no Snekmer rule passes
     them."""
     import ctypes as C

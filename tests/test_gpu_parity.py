@@ -393,7 +393,12 @@ def test_connection_matrix_other_sklearn_metrics_match_sklearn(ctx):
             assert got.dtype == np.float64 and got.shape == want.shape, metric
             assert (np.isnan(got) == np.isnan(want)).all(), metric
             tol = COS_TOL if metric == "cosine" and X is counts else 1e-12 * max(1.0, float(np.nanmax(np.abs(want))) if want.size else 1.0)
-            assert np.nanmax(np.abs(got - want), initial=0.0) <= tol, (metric, X.shape)
+            if metric in ("euclidean", "l2"):
+                # sklearn: sqrt(xx + yy - 2 xy) (cancels for close rows); here: the sum of (x - y)^2 taken directly.  They
+                # agree to the expansion's rounding error, absolute in the squared distance: eps * (xx + yy)
+                assert np.abs(got * got - want * want).max(initial=0.0) <= 1e-12 * max(1.0, 2.0 * float((X * X).sum(axis=1).max())), metric
+            else:
+                assert np.nanmax(np.abs(got - want), initial=0.0) <= tol, (metric, X.shape)
     got = skm.score.pairwise_distances(real, metric="minkowski", p=3.0)
     assert np.abs(got - pairwise_distances(real, metric="minkowski", p=3.0)).max() <= 1e-12
     with pytest.raises(NotImplementedError):
