@@ -465,13 +465,15 @@ __global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__rest
         for (int64_t j0 = 0; j0 < m; j0 += CHH) {
             const uint32_t j0u = (uint32_t)j0;
             const uint32_t j1u = (uint32_t)min(j0 + (int64_t)CHH, m);
-            // ---- long lists: a wave takes NG lists at a time and issues the first round of all of them (U loads per lane
-            // and list) before it adds any: one memory round trip per NG lists instead of one per list
+            // ---- long lists: a wave takes NG lists at a time; every round it issues U loads per lane for EACH list of the
+            // group that still has postings in this column range, then adds them: one memory round trip per round of
+            // the whole group (with one list at a time, the second and later rounds of every list were a round trip
+            // each and set the kernel's rate)
             if (nlong) {
                 constexpr int NG = HEAVY_NG;
                 for (uint32_t l0 = (uint32_t)wid * NG; l0 < nlong; l0 += NW * NG) {  // wave-uniform
-                    PW buf[NG][U];
                     uint32_t lp[NG], lpe[NG], lv[NG];
+                    bool act[NG];
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         const uint32_t l = l0 + (uint32_t)g;
@@ -480,43 +482,44 @@ __global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__rest
                         lp[g] = s_cur[ll];
                         lpe[g] = have ? s_end[ll] : 0u;
                         lv[g] = s_val[ll];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const uint32_t at = lp[g] + (uint32_t)(u * 64 + lane);
-                            buf[g][u] = ypost[at < lpe[g] ? at : (lpe[g] ? lpe[g] - 1u : 0u)];
-                        }
+                        act[g] = lp[g] < lpe[g];
                     }
+                    bool any = false;
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        uint32_t p = lp[g];
-                        const uint32_t pe = lpe[g], v = lv[g];
-                        bool loaded = true;
-                        while (p < pe) {
-                            if (!loaded) {
+                    for (int g = 0; g < NG; ++g)
+                        any |= act[g];
+                    while (any) {  // all values here are wave-uniform
+                        PW buf[NG][U];
 #pragma unroll
-                                for (int u = 0; u < U; ++u) {
-                                    const uint32_t at = p + (uint32_t)(u * 64 + lane);
-                                    buf[g][u] = ypost[at < pe ? at : pe - 1u];
-                                }
+                        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const uint32_t at = lp[g] + (uint32_t)(u * 64 + lane);
+                                buf[g][u] = ypost[act[g] && at < lpe[g] ? at : 0u];  // posting 0 exists: nlong > 0
                             }
-                            loaded = false;
+                        }
+                        any = false;
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
                             uint32_t took = 0;
 #pragma unroll
                             for (int u = 0; u < U; ++u) {
-                                const uint32_t at = p + (uint32_t)(u * 64 + lane);
+                                const uint32_t at = lp[g] + (uint32_t)(u * 64 + lane);
                                 const uint32_t j = posting<PW>::row(buf[g][u]);
-                                const bool in = at < pe && j < j1u;
+                                const bool in = act[g] && at < lpe[g] && j < j1u;
                                 if (in)
-                                    atomicAdd(&s_acc[j - j0u], (int)(v * posting<PW>::count(buf[g][u], ypostcnt, at)));
+                                    atomicAdd(&s_acc[j - j0u], (int)(lv[g] * posting<PW>::count(buf[g][u], ypostcnt, at)));
                                 took += (uint32_t)__popcll(__ballot(in));
                             }
-                            p += took;
-                            if (took < (uint32_t)(U * 64))
-                                break;  // the list's part of this column range is done (or the list is)
+                            lp[g] += took;
+                            act[g] = act[g] && took == (uint32_t)(U * 64) && lp[g] < lpe[g];
+                            any |= act[g];
                         }
-                        if (lane == 0 && l0 + (uint32_t)g < nlong)
-                            s_cur[l0 + g] = p;
                     }
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        if (lane == 0 && l0 + (uint32_t)g < nlong)
+                            s_cur[l0 + g] = lp[g];
                 }
             }
             // ---- short lists (at most 64 postings): four lists per wave and round, 16 lanes each
