@@ -19,14 +19,19 @@ def main():
     ctx = _hip.Context(0)
     res, off, _ = synth_skewed(n, seed=BASE_SEED + 12)
     batch = engine.SeqBatch(ctx, res, off)
-    pipe = engine.Pipeline(ctx, alphabet.build_lut("red6"), 12)
+    pipe = engine.Pipeline(ctx, alphabet.build_lut("red6"), 12, post32=os.environ.get("SKM_TOOL_POST32") == "1")
     pipe.step(batch)
     ctx.sync()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(steps):
         pipe.step(batch)
     ctx.sync()
-    print(json.dumps({"n": n, "ms_per_step": (time.perf_counter() - t0) / steps * 1e3}))
+    dt = (time.perf_counter() - t0) / steps * 1e3
+    prof = ctx.profile_dump()
+    print(json.dumps({"n": n, "post_bits": pipe.basis.post_bits, "ms_per_step": dt,
+                      "stages": {k: round(v[1] / steps, 3) for k, v in prof.items() if v[1] / steps > 0.3}}))
 
 
 if __name__ == "__main__":
