@@ -138,6 +138,17 @@ def test_config4_sharded_code_path_8_ranks_1m_sequences(ctx):
     import faulthandler
 
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)  # a stuck run says where (pytest shows stderr on failure)
+    try:
+        _config4_body(ctx, lut, k, n, world, topk, check)
+    finally:
+        faulthandler.cancel_dump_traceback_later()
+
+
+def _config4_body(ctx, lut, k, n, world, topk, check):
+    from snekmer_amd import engine
+    from snekmer_amd.dist import shard_bounds
+    from snekmer_amd.synth import synth_families
+
     progress("config 4: generating 1 M sequences")
     res, off, _ = synth_families(n, 300, family=100, seed=20250523 + 3)
     bounds = shard_bounds(n, world)
@@ -175,7 +186,6 @@ def test_config4_sharded_code_path_8_ranks_1m_sequences(ctx):
         _assert_topk_equal(idx, val, r["idx"], r["val"])
         del nb
         progress(f"rank {rank}'s block equal")
-    faulthandler.cancel_dump_traceback_later()
     # the exchange moved what the design says it moves: every entry once (12 B, 7/8 of them off-rank) in the
     # all-to-all, then 7 copies of every owner's arrays in the all-gather
     assert tw.bytes_moved > ref.csr.nnz * 12 * 7 // 8
