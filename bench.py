@@ -642,7 +642,7 @@ def skewed_workload(ctx, engine, alphabet, args, pipe, line):
     dt = (time.perf_counter() - t1) / reps
     prof = ctx.profile_dump()
     ctx.profile_enable(False)
-    st = (C.c_int64 * 3)()
+    st = (C.c_int64 * 4)()
     ctx.call("skm_cosine_csr_stats", st)
     lens = np.diff(off)
     sizes = np.bincount(fam)
@@ -655,7 +655,7 @@ def skewed_workload(ctx, engine, alphabet, args, pipe, line):
         "residues": int(off[-1]), "nnz": p.csr.nnz, "basis_columns": p.basis.ncols, "generator_s": gen_s,
         "ms_per_step": dt * 1e3, "sequences_per_s": n / dt, "residues_per_s": int(off[-1]) / dt,
         "rows_sent_to_large_table_pass": int(st[0]), "strips_left_to_cursor_kernel": int(st[1]),
-        "neighbour_list_words": int(st[2]),
+        "neighbour_list_entries_behind_fixed_slots": int(st[2]), "wide_strips": int(st[3]),
         "stage_ms_per_step": stages,
         "stage_vs_uniform_families": {k: (v / uniform[k] if uniform.get(k) else None) for k, v in stages.items()},
     }
@@ -690,7 +690,7 @@ def real_proteome(ctx, engine, alphabet):
             p.step(batch)
         ctx.sync()
         dt = (time.perf_counter() - t1) / reps
-        st = (C.c_int64 * 3)()
+        st = (C.c_int64 * 4)()
         ctx.call("skm_cosine_csr_stats", st)
         out["runs"].append({"alphabet": name, "k": k, "ms_per_step": dt * 1e3, "sequences_per_s": len(ids) / dt,
                             "residues_per_s": int(off[-1]) / dt, "nnz": p.csr.nnz, "basis_columns": p.basis.ncols,

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SKM_ABI_VERSION 2
+#define SKM_ABI_VERSION 3
 
 #define SKM_OK 0
 #define SKM_E_BADARG (-1)
@@ -221,7 +221,12 @@ int skm_row_norms_csr(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const ui
  * X: CSR rows [row0,row1) of an n-row matrix; Y: postings (column-major) of an m-row matrix
  * (pass X's own postings for the square N x N case).  Writes
  *   out[(i-row0)*ld + j] = <x_i, y_j> * x_rnorm[i] * y_rnorm[j]   for i in [row0,row1), j in [0,m)
- * with the integer dot product exact (int32) and the scaling in float32.
+ * with the integer dot product exact and the scaling in float32.  Dot products are summed in int32 cells wherever they
+ * provably fit: by Cauchy-Schwarz <x_i, y_j> <= 1 / (x_rnorm[i] * y_rnorm[j]), so row i takes the 32-bit kernels when
+ * x_rnorm[i] * min_j y_rnorm[j] > 2^-31 (decided on the device, no host wait) and otherwise an exact wide form of the
+ * cursor kernel with float64 accumulators - sklearn's own arithmetic: exact below 2^53, float64 rounding beyond, no upper
+ * limit (counts use all 32 bits).  The test presumes the norms ARE the rows' norms (skm_row_norms_csr); callers that
+ * pass other scalings (unit norms to obtain set sizes) must keep their dot products below 2^31 themselves.
  * mode 0 = similarity; mode 1 = cosine distance as sklearn's pairwise_distances(X) / cosine_distances(X, X)
  * gives it (1 - s clipped to [0,2]; exact 0 where i == j: Y IS X); mode 2 = cosine distance between two
  * different matrices, sklearn's cosine_distances(X, Y): the same values without the diagonal rule.
@@ -236,9 +241,10 @@ int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint
                    int64_t ld);
 
 /* Reporting only: how the last neighbour-list skm_cosine_csr call of this context distributed its rows.
- * h_out3[0] = rows whose neighbours overflowed the first pass's table (large-table pass), [1] = 8-row strips left
- * to the cursor kernel, [2] = neighbour-list words in use (fixed slots included).  Synchronises the stream. */
-int skm_cosine_csr_stats(skm_ctx *ctx, int64_t *h_out3);
+ * h_out4[0] = rows whose neighbours overflowed the first pass's table (handed to the fused heavy-row kernel), [1] =
+ * 8-row strips left to the 32-bit cursor kernel, [2] = neighbour-list entries allocated behind the rows' fixed slots,
+ * [3] = 8-row strips that held a wide row (float64 cursor kernel).  Synchronises the stream. */
+int skm_cosine_csr_stats(skm_ctx *ctx, int64_t *h_out4);
 
 /* The reference's metric="jaccard" branch (snekmer/score.py:166-168) is 1 - hamming distance on the
  * binary presence matrix: 1 - (|a| + |b| - 2|a&b|) / ncols.  Given d_out holding the exact
@@ -298,14 +304,15 @@ int skm_csr_group_sum(skm_ctx *ctx, int64_t n, int64_t nnz, const int64_t *d_row
  * whose dense N x M matrix cannot be stored (BASELINE configs[3], 1M x 1M).
  *   d_start[row1-row0], d_len[row1-row0]: position and length of each row's list in d_ent;
  *   d_ent[cap_ent]: entries (j << 32 | dot), order within a row unspecified;
- *   d_len == 0xFFFFFFFF marks a row the kernels could not hold (> 65536 neighbours, or cap_ent
- *   exhausted); *h_overflow_rows counts them, *h_total_entries is the
- *   number of entries written (both host-synchronous). */
+ *   d_len == 0xFFFFFFFF marks a row the kernels could not hold (> 65536 neighbours, cap_ent
+ *   exhausted, or a dot product that may not fit the 32-bit entry: d_xrnorm[i] * min_j d_yrnorm[j] <= 2^-31, the
+ *   test skm_cosine_csr applies); *h_overflow_rows counts them, *h_total_entries is the
+ *   number of entries written (both host-synchronous).  d_xrnorm[n] / d_yrnorm[m]: skm_row_norms_csr of X and Y. */
 int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
                        const uint32_t *d_xcounts, int64_t m, int64_t ncols, const uint32_t *d_ycolptr,
-                       const void *d_ypost, int post_bits, const uint32_t *d_ypostcnt, int64_t row0, int64_t row1,
-                       int64_t cap_ent, uint64_t *d_start, uint32_t *d_len, uint64_t *d_ent,
-                       int64_t *h_total_entries, int64_t *h_overflow_rows);
+                       const void *d_ypost, int post_bits, const uint32_t *d_ypostcnt, const float *d_xrnorm,
+                       const float *d_yrnorm, int64_t row0, int64_t row1, int64_t cap_ent, uint64_t *d_start,
+                       uint32_t *d_len, uint64_t *d_ent, int64_t *h_total_entries, int64_t *h_overflow_rows);
 
 /* k best cosine neighbours per row from the lists of skm_gram_neighbors: score = dot * xrnorm[row0+r]
  * * yrnorm[j], descending, ties towards the lower j; exclude_self drops j == row0 + r.
@@ -325,7 +332,9 @@ int skm_count_dense(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, const 
 
 /* out[i*ld + j] = (sum_c X[i,c]*Y[j,c]) * xr[i] * yr[j]; X [n x kdim], Y [m x kdim] int8 row-major
  * with kdim a multiple of 64 and rows padded with zeros; i8 MFMA with int32 accumulation.
- * Y may equal X.  mode as in skm_cosine_csr. */
+ * Y may equal X.  mode as in skm_cosine_csr.  int32 is safe by construction up to kdim = 133 143 (127^2 * kdim < 2^31);
+ * for wider operands the call first checks on the device that the norms bound every dot product below 2^31
+ * (1 / (xrnorm * yrnorm), one host wait) and returns SKM_E_OVERFLOW otherwise. */
 int skm_cosine_dense_i8(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim, const int8_t *d_x,
                         const int8_t *d_y, const float *d_xrnorm, const float *d_yrnorm, int mode,
                         float *d_out, int64_t ld);

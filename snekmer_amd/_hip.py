@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNEKMER_HIP_LIB") or os.path.join(_HERE, "libsnekmer_hip.so")
 
 SKM_OK = 0
+ABI_VERSION = 3  # SKM_ABI_VERSION of include/snekmer_hip.h
 ERRORS = {-1: "BADARG", -2: "NOMEM", -3: "HIP", -4: "OVERFLOW", -5: "UNSUPPORTED", -6: "COMM"}
 COMM_ID_BYTES = 128
 
@@ -99,7 +100,7 @@ _SIGNATURES = {
     "skm_pairwise_f64": (C.c_int, [_p, C.c_int, C.c_double, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64]),
     "skm_row_top2": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p]),
     "skm_csr_group_sum": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _p, _p, C.POINTER(_i64)]),
-    "skm_gram_neighbors": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _p, _p, C.c_int, _p, _i64, _i64, _i64, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)]),
+    "skm_gram_neighbors": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _p, _p, C.c_int, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)]),
     "skm_neighbors_topk": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p, _p]),
     "skm_jaccard_distance_from_gram": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64]),
     "skm_pair_work": (C.c_int, [_p, _i64, _p, C.POINTER(C.c_uint64)]),
@@ -150,6 +151,9 @@ def load_library():
             lib = C.CDLL(LIB_PATH)
         except OSError as exc:  # e.g. libamdhip64 not found
             raise HipUnavailable(f"cannot load {LIB_PATH}: {exc}") from exc
+        lib.skm_abi_version.restype = C.c_int
+        if lib.skm_abi_version() != ABI_VERSION:  # e.g. a stale build named by SNEKMER_HIP_LIB
+            raise HipUnavailable(f"{LIB_PATH} has ABI version {lib.skm_abi_version()}, this binding needs {ABI_VERSION}: rebuild it")
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res

@@ -239,6 +239,8 @@ int skm_ws(skm_ctx *ctx, int slot, size_t bytes, void **out)
             return SKM_E_NOMEM;
         }
         ctx->ws_bytes[slot] = want;
+        if (slot == WS_COS)  // holds a ticket counter that every user leaves at zero (k_cosine_prologue)
+            SKM_HIP(hipMemsetAsync(ctx->ws[slot], 0, want, ctx->stream));
     }
     *out = ctx->ws[slot];
     return SKM_OK;

@@ -412,17 +412,22 @@ __global__ __launch_bounds__(BLK) void k_row_norms(int64_t n, const int64_t *__r
     for (int64_t i = wave; i < n; i += nwaves) {
         const int64_t b = rowptr[i], e = rowptr[i + 1];
         unsigned long long s = 0;
+        double sd = 0.0;  // the same sum in float64: tells when the exact one has left 64 bits (counts near 2^32)
         for (int64_t t = b + lane; t < e; t += 64) {
             unsigned long long v = counts[t];
             s += v * v;
+            sd += (double)v * (double)v;
         }
-        for (int o = 32; o > 0; o >>= 1)
+        for (int o = 32; o > 0; o >>= 1) {
             s += __shfl_down(s, o);
+            sd += __shfl_down(sd, o);
+        }
         if (lane == 0) {
+            const bool wrapped = sd >= 0x1p63;
             if (normsq)
-                normsq[i] = s;
+                normsq[i] = wrapped ? ~0ull : s;  // saturates
             if (rnorm)
-                rnorm[i] = s ? (float)(1.0 / sqrt((double)s)) : 1.0f;
+                rnorm[i] = wrapped ? (float)(1.0 / sqrt(sd)) : (s ? (float)(1.0 / sqrt((double)s)) : 1.0f);
         }
     }
 }

@@ -23,6 +23,7 @@
 // after a warm-up call, the timed path performs no hipMalloc/hipFree.
 enum skm_ws_slot {
     WS_A = 0, WS_B, WS_C, WS_D, WS_E, WS_F, WS_G, WS_H, WS_I, WS_J, WS_K, WS_L, WS_ROCPRIM, WS_SMALL, WS_LUT,
+    WS_COS,  // counters and partial minima of the cosine stage; zero-filled when (re)allocated (skm_ws)
     WS_COUNT
 };
 

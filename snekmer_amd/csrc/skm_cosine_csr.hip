@@ -58,11 +58,95 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SKM_FIRST_GH 2048
 #endif
 constexpr uint32_t G_DONE_ROW = 0xFFFFFFFEu;  // g_len of a row k_cosine_heavy has already written
+constexpr uint32_t G_WIDE_ROW = 0xFFFFFFFDu;  // g_len of a row whose dot products may exceed int32 (skm_row_is_wide)
 
 // ------------------------------------------------------------------------------- sparse Gram
 #include "skm_gram_kernel.h"
 
-template <int MODE, bool VEC, int ABL, typename PW>
+// Small state of one skm_cosine_csr / skm_gram_neighbors call (scratch slot WS_COS, zero-filled when allocated).
+struct cos_state {
+    unsigned long long g_counter;  // next free neighbour-list entry            (skm_cosine_csr_stats reads the first
+    uint32_t fb_count;             // strips left to the 32-bit cursor kernel     three fields)
+    uint32_t over_count[16];       // rows handed to the second pass, per row block of the overlapped schedule
+    uint32_t wide_count;           // strips with a wide row (float64 accumulators)
+    float min_yrnorm;              // min_j yrnorm[j]: the Y side of the int32 guard (skm_row_is_wide)
+    uint32_t blocks_done;          // ticket counter of k_cosine_prologue; always 0 between launches
+    unsigned long long first_entry;  // g_counter's starting value (the fixed list slots in front of it)
+    uint32_t pad[6];
+    float partial[1024];           // per-workgroup minima of k_cosine_prologue
+};
+constexpr int PRO_MAXB = 1024;
+
+// One launch in front of every cosine call: clears the strip flags and the call's counters and reduces
+// min_j yrnorm[j] (workgroup minima, then the last workgroup to finish combines them: one kernel, no pre-initialised
+// accumulator).  Replaces two hipMemsetAsync and a one-thread kernel.
+__global__ __launch_bounds__(256) void k_cosine_prologue(uint32_t *__restrict__ flags, int64_t nflags, cos_state *st,
+                                                         unsigned long long first_entry,
+                                                         const float *__restrict__ yrnorm, int64_t m)
+{
+    __shared__ float s_w[4];
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + tid, stride = (int64_t)gridDim.x * 256;
+    for (int64_t z = gid; z < nflags; z += stride)
+        flags[z] = 0u;
+    float mn = INFINITY;
+    for (int64_t j = gid; j < m; j += stride)
+        mn = fminf(mn, yrnorm[j]);
+    auto block_min = [&](float v) -> float {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            v = fminf(v, __shfl_xor(v, o));
+        __syncthreads();
+        if ((tid & 63) == 0)
+            s_w[tid >> 6] = v;
+        __syncthreads();
+        return fminf(fminf(s_w[0], s_w[1]), fminf(s_w[2], s_w[3]));
+    };
+    mn = block_min(mn);
+    if (tid == 0) {
+        __hip_atomic_store(&st->partial[blockIdx.x], mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        s_last = atomicAdd(&st->blocks_done, 1u) == gridDim.x - 1u;
+    }
+    __syncthreads();
+    if (!s_last)
+        return;
+    __threadfence();
+    float all = INFINITY;
+    for (uint32_t b = (uint32_t)tid; b < gridDim.x; b += 256)
+        all = fminf(all, __hip_atomic_load(&st->partial[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    all = block_min(all);
+    if (tid == 0) {
+        st->min_yrnorm = all;
+        st->g_counter = first_entry;
+        st->first_entry = first_entry;
+        st->fb_count = 0u;
+        st->wide_count = 0u;
+        st->blocks_done = 0u;
+    }
+    if (tid < 16)
+        st->over_count[tid] = 0u;
+}
+
+static inline int cosine_prologue(skm_ctx *ctx, uint32_t *flags, int64_t nflags, cos_state *state,
+                                  unsigned long long first_entry, const float *d_yrnorm, int64_t m, hipStream_t st)
+{
+    const int64_t work = (nflags > m ? nflags : m);
+    int64_t grid = skm_ceil_div(work, 256 * 8);
+    grid = grid < 1 ? 1 : (grid > PRO_MAXB ? PRO_MAXB : grid);
+    SKM_PROF(ctx, "k_cosine_prologue");
+    k_cosine_prologue<<<(unsigned)grid, 256, 0, st>>>(flags, nflags, state, first_entry, d_yrnorm, m);
+    return skm_check_launch("k_cosine_prologue");
+}
+
+// WIDE = false: exact int32 accumulators (dot products below 2^31: rows that pass skm_row_is_wide's test).
+// WIDE = true: float64 accumulators, the reference's own arithmetic (sklearn works in float64): exact while a dot
+// product stays below 2^53, rounded like any float64 sum beyond, no upper limit; counts use all 32 bits.
+// strip_list == nullptr: one strip per workgroup, strip = blockIdx.x (the grid covers all strips).  A 32-bit launch
+// that is given `wide_list` appends the strips holding a wide row to it and leaves them unwritten.
+// strip_list != nullptr: workgroups stride over the first *strip_count entries of the list (any grid).
+template <int MODE, bool VEC, int ABL, typename PW, bool WIDE>
 __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__ xrowptr,
                                                      const uint32_t *__restrict__ xcolidx,
                                                      const uint32_t *__restrict__ xcounts,
@@ -73,38 +157,59 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
                                                      const float *__restrict__ yrnorm, int64_t row0, int64_t row1,
                                                      float *__restrict__ out, int64_t ld,
                                                      const uint32_t *__restrict__ strip_list,
-                                                     const uint32_t *__restrict__ strip_count)
+                                                     const uint32_t *__restrict__ strip_count,
+                                                     const float *__restrict__ min_yrnorm,
+                                                     uint32_t *__restrict__ wide_list, uint32_t *__restrict__ wide_count)
 {
-    __shared__ __attribute__((aligned(16))) int s_acc[R][CH];
+    using acc_t = typename std::conditional<WIDE, double, int>::type;
+    __shared__ __attribute__((aligned(16))) acc_t s_acc[R][CH];
     __shared__ int64_t s_rp[R + 1];
     __shared__ float s_rni[R];
+    __shared__ int s_skip;
     const int tid = threadIdx.x;
-    // With a strip list the grid is sized for the worst case and surplus workgroups leave at once.
-    if (strip_list && blockIdx.x >= *strip_count)
-        return;
-    const int64_t strip = strip_list ? strip_list[blockIdx.x] : blockIdx.x;
+    const uint32_t nlist = strip_list ? *strip_count : 0u;
+    for (int z = tid; z < (int)(R * CH * sizeof(acc_t) / 16); z += TB)
+        reinterpret_cast<int4 *>(&s_acc[0][0])[z] = make_int4(0, 0, 0, 0);
+    for (uint32_t it = blockIdx.x;; it += gridDim.x) {
+    if (strip_list ? it >= nlist : it != blockIdx.x)  // uniform for the workgroup
+        break;
+    const int64_t strip = strip_list ? strip_list[it] : blockIdx.x;
     const int64_t i0 = row0 + strip * R;
     const int rows = (int)min((int64_t)R, row1 - i0);
 
+    __syncthreads();  // the previous strip's row pointers and accumulators are no longer in use
     if (tid <= R) {
         int64_t r = tid <= rows ? tid : rows;
         s_rp[tid] = xrowptr[i0 + r];
     }
     if (tid < R)
         s_rni[tid] = tid < rows ? xrnorm[i0 + tid] : 0.0f;
-    for (int z = tid; z < R * CH / 4; z += TB)
-        reinterpret_cast<int4 *>(&s_acc[0][0])[z] = make_int4(0, 0, 0, 0);
+    if (tid == 0)
+        s_skip = 0;
     __syncthreads();
+    if (!WIDE && wide_list && !strip_list) {
+        if (tid < rows && skm_row_is_wide(s_rni[tid], *min_yrnorm))
+            s_skip = 1;
+        __syncthreads();
+        if (s_skip) {  // uniform: a row of this strip may exceed int32; the float64 launch behind this one takes it
+            if (tid == 0)
+                wide_list[atomicAdd(wide_count, 1u)] = (uint32_t)strip;
+            continue;
+        }
+    }
 
     const int64_t e0 = s_rp[0];
     const int64_t ntasks = s_rp[R] - e0;
 
     uint32_t cur[Q], rem[Q], nj[Q], nv[Q], liv[Q];
+    uint32_t xv[WIDE ? Q : 1];  // WIDE: the full 32-bit count (liv keeps 28 bits beside the row index)
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int64_t t = (int64_t)tid + (int64_t)q * TB;
         nj[q] = NONE;
         cur[q] = rem[q] = nv[q] = liv[q] = 0;
+        if (WIDE)
+            xv[q] = 0;
         if (ABL != 1 && t < ntasks) {
             const int64_t e = e0 + t;
             int li = 0;
@@ -114,6 +219,8 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
             const uint32_t c = xcolidx[e];
             const uint32_t v = xcounts[e];
             liv[q] = ((uint32_t)li << 28) | (v & 0x0FFFFFFFu);
+            if (WIDE)
+                xv[q] = v;
             if (c == 0xFFFFFFFFu) {  // singleton k-mer (ELIDE_SINGLETONS): pairs with its own row only
                 rem[q] = 1;
                 nj[q] = (uint32_t)(i0 + li);
@@ -130,6 +237,12 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
             }
         }
     }
+    auto product = [](uint32_t a, uint32_t b) -> acc_t {
+        if constexpr (WIDE)
+            return (double)a * (double)b;
+        else
+            return (int)a * (int)b;
+    };
 
     for (int64_t j0 = 0; j0 < m; j0 += CH) {
         const int64_t j1 = min(j0 + (int64_t)CH, m);
@@ -146,8 +259,8 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
                 tv[q] = nv[q];
                 if (nj[q] < j1u) {
                     const int li = (int)(liv[q] >> 28);
-                    const int v = (int)(liv[q] & 0x0FFFFFFFu);
-                    atomicAdd(&s_acc[li][nj[q] - j0u], v * (int)nv[q]);
+                    const uint32_t v = WIDE ? xv[WIDE ? q : 0] : (liv[q] & 0x0FFFFFFFu);
+                    atomicAdd(&s_acc[li][nj[q] - j0u], product(v, nv[q]));
                     ++cur[q];
                     --rem[q];
                     tj[q] = NONE;
@@ -174,11 +287,11 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
             for (int r = 1; r < R; ++r)
                 li += (e >= s_rp[r]) ? 1 : 0;
             const uint32_t c = xcolidx[e];
-            const int v = (int)xcounts[e];
+            const uint32_t v = xcounts[e];
             if (c == 0xFFFFFFFFu) {
                 const uint32_t j = (uint32_t)(i0 + li);
                 if (j >= j0u && j < j1u)
-                    atomicAdd(&s_acc[li][j - j0u], v * v);
+                    atomicAdd(&s_acc[li][j - j0u], product(v, v));
                 continue;
             }
             uint32_t lo = ycolptr[c], hi = ycolptr[c + 1];
@@ -195,7 +308,7 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
                 const uint32_t j = posting<PW>::row(pw);
                 if (j >= j1u)
                     break;
-                atomicAdd(&s_acc[li][j - j0u], v * (int)posting<PW>::count(pw, ypostcnt, lo));
+                atomicAdd(&s_acc[li][j - j0u], product(v, posting<PW>::count(pw, ypostcnt, lo)));
             }
         }
         __syncthreads();
@@ -213,12 +326,22 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
         }
 #pragma unroll
         for (int li = 0; li < R; ++li) {
-            int4 a = *reinterpret_cast<int4 *>(&s_acc[li][4 * tid]);
-            *reinterpret_cast<int4 *>(&s_acc[li][4 * tid]) = make_int4(0, 0, 0, 0);
+            acc_t a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = s_acc[li][4 * tid + u];
+                s_acc[li][4 * tid + u] = acc_t(0);
+            }
             if (li < rows) {
                 const float ri = s_rni[li];
-                float o[4] = {(float)a.x * ri * rj[0], (float)a.y * ri * rj[1], (float)a.z * ri * rj[2],
-                              (float)a.w * ri * rj[3]};
+                float o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if constexpr (WIDE)
+                        o[u] = (float)(a[u] * (double)ri * (double)rj[u]);
+                    else
+                        o[u] = (float)a[u] * ri * rj[u];
+                }
                 const int64_t i = i0 + li;
                 if (MODE == 1) {
 #pragma unroll
@@ -247,6 +370,7 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
         }
         __syncthreads();
     }
+    }
 }
 
 
@@ -263,7 +387,8 @@ __global__ __launch_bounds__(WTB) void k_cosine_write(const uint64_t *__restrict
                                                      const float *__restrict__ yrnorm, int64_t m, int64_t row0,
                                                      int64_t rbase, float *__restrict__ out, int64_t ld,
                                                      uint32_t *__restrict__ fb_list, uint32_t *__restrict__ fb_count,
-                                                     uint32_t *__restrict__ fb_flag)
+                                                     uint32_t *__restrict__ fb_flag, uint32_t *__restrict__ wide_list,
+                                                     uint32_t *__restrict__ wide_count)
 {
     constexpr int CH = WCH, TB = WTB, NV = WCH / 4 / WTB, WREG = 2;  // NV 16-byte vectors per thread and step
     __shared__ __attribute__((aligned(16))) float s_acc[CH];
@@ -273,15 +398,19 @@ __global__ __launch_bounds__(WTB) void k_cosine_write(const uint64_t *__restrict
     const uint32_t len = g_len[r];
     if (len == G_DONE_ROW)  // written by k_cosine_heavy (Gram and write fused for rows with thousands of neighbours)
         return;
-    if (len == G_OVERFLOW) {
-        // the row exceeded the sparse kernels' capacities: leave its strip to the cursor kernel
-        // (cursor strips are 8 rows; fb_flag makes sure a strip is listed once, since the cursor
-        // kernel's grid is sized by the number of strips)
+    if (len == G_OVERFLOW || len == G_WIDE_ROW) {
+        // the row exceeded the sparse kernels' capacities (or the int32 range: G_WIDE_ROW): leave its strip to the
+        // cursor kernel, 32-bit or float64 form (cursor strips are 8 rows; a bit of fb_flag per list makes sure a strip
+        // is listed once).  A strip on both lists is written by both launches, the float64 one last.
         constexpr int CURSOR_R = 8;
         if (tid == 0) {
-            const uint32_t strip = (uint32_t)(r / CURSOR_R);
-            if (atomicExch(&fb_flag[strip], 1u) == 0u)
-                fb_list[atomicAdd(fb_count, 1u)] = strip;
+            const uint32_t strip = (uint32_t)(r / CURSOR_R), bit = len == G_WIDE_ROW ? 2u : 1u;
+            if ((atomicOr(&fb_flag[strip], bit) & bit) == 0u) {
+                if (len == G_WIDE_ROW)
+                    wide_list[atomicAdd(wide_count, 1u)] = strip;
+                else
+                    fb_list[atomicAdd(fb_count, 1u)] = strip;
+            }
         }
         return;
     }
@@ -861,11 +990,6 @@ __global__ __launch_bounds__(1024) void k_gram_sparse_huge(const int64_t *__rest
     }
 }
 
-__global__ void k_set_u64(unsigned long long *dst, unsigned long long v)
-{
-    *dst = v;
-}
-
 __global__ void k_count_overflow(int64_t nrows, const uint32_t *__restrict__ g_len, unsigned int *out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -881,8 +1005,9 @@ namespace {
 template <typename PW>
 int gram_neighbors_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
                         const uint32_t *d_xcounts, int64_t m, int64_t ncols, const uint32_t *d_ycolptr, const PW *d_ypost,
-                        const uint32_t *d_ypostcnt, int64_t row0, int64_t row1, int64_t cap_ent, uint64_t *d_start,
-                        uint32_t *d_len, uint64_t *d_ent, int64_t *h_total_entries, int64_t *h_overflow_rows)
+                        const uint32_t *d_ypostcnt, const float *d_xrnorm, const float *d_yrnorm, int64_t row0, int64_t row1,
+                        int64_t cap_ent, uint64_t *d_start, uint32_t *d_len, uint64_t *d_ent, int64_t *h_total_entries,
+                        int64_t *h_overflow_rows)
 {
     SKM_REQUIRE(ctx && n >= 0 && m >= 0 && ncols >= 0 && cap_ent >= 0 && h_total_entries && h_overflow_rows, SKM_E_BADARG,
                 "skm_gram_neighbors: bad argument");
@@ -893,7 +1018,7 @@ int gram_neighbors_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const
     const int64_t nrows = row1 - row0;
     if (nrows == 0)
         return SKM_OK;
-    SKM_REQUIRE(d_xrowptr && d_ycolptr && d_start && d_len && (cap_ent == 0 || d_ent), SKM_E_BADARG,
+    SKM_REQUIRE(d_xrowptr && d_ycolptr && d_start && d_len && d_xrnorm && d_yrnorm && (cap_ent == 0 || d_ent), SKM_E_BADARG,
                 "skm_gram_neighbors: null array");
     SKM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -902,16 +1027,18 @@ int gram_neighbors_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const
     uint32_t *list1 = (uint32_t *)p;
     SKM_TRY(skm_ws(ctx, WS_F, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
     uint32_t *list2 = (uint32_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
-    unsigned long long *g_counter = (unsigned long long *)((uint8_t *)p + 2048);
-    uint32_t *cnt1 = (uint32_t *)((uint8_t *)p + 2048 + 8), *cnt2 = cnt1 + 1, *novf = cnt1 + 2;
-    SKM_HIP(hipMemsetAsync(g_counter, 0, 8 + 16, st));
+    SKM_TRY(skm_ws(ctx, WS_COS, sizeof(cos_state), &p));
+    cos_state *state = (cos_state *)p;
+    unsigned long long *g_counter = &state->g_counter;
+    uint32_t *cnt1 = &state->over_count[0], *cnt2 = cnt1 + 1, *novf = cnt1 + 2;
+    SKM_TRY(cosine_prologue(ctx, nullptr, 0, state, 0ull, d_yrnorm, m, st));
     const unsigned long long cap = (unsigned long long)cap_ent;
     {
+        // rows whose dot products may not fit the 32-bit entries (skm_row_is_wide) are marked G_OVERFLOW at once
         SKM_PROF(ctx, "k_gram_sparse");
         k_gram_sparse<0, 1, 2048, 256, 2, 32, 2, PW><<<(unsigned)nrows, 256, 0, st>>>(
             d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0, row1, 0ull, 0, d_ent, cap, g_counter, d_start,
-            d_len, list1, cnt1);
+            d_len, list1, cnt1, d_xrnorm, &state->min_yrnorm, G_OVERFLOW);
     }
     SKM_TRY(skm_check_launch("k_gram_sparse"));
     {
@@ -955,19 +1082,20 @@ int gram_neighbors_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const
 
 extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
                                   const uint32_t *d_xcounts, int64_t m, int64_t ncols, const uint32_t *d_ycolptr,
-                                  const void *d_ypost, int post_bits, const uint32_t *d_ypostcnt, int64_t row0, int64_t row1,
-                                  int64_t cap_ent, uint64_t *d_start, uint32_t *d_len, uint64_t *d_ent,
-                                  int64_t *h_total_entries, int64_t *h_overflow_rows)
+                                  const void *d_ypost, int post_bits, const uint32_t *d_ypostcnt, const float *d_xrnorm,
+                                  const float *d_yrnorm, int64_t row0, int64_t row1, int64_t cap_ent, uint64_t *d_start,
+                                  uint32_t *d_len, uint64_t *d_ent, int64_t *h_total_entries, int64_t *h_overflow_rows)
 {
     SKM_REQUIRE(post_bits == 64 || post_bits == 32, SKM_E_BADARG, "skm_gram_neighbors: post_bits must be 32 or 64");
     if (post_bits == 32) {
         SKM_REQUIRE(m <= ((int64_t)1 << 24), SKM_E_BADARG, "skm_gram_neighbors: 32-bit postings hold rows < 2^24");
         return gram_neighbors_impl<uint32_t>(ctx, n, d_xrowptr, d_xcolidx, d_xcounts, m, ncols, d_ycolptr, (const uint32_t *)d_ypost,
-                                             d_ypostcnt, row0, row1, cap_ent, d_start, d_len, d_ent, h_total_entries,
-                                             h_overflow_rows);
+                                             d_ypostcnt, d_xrnorm, d_yrnorm, row0, row1, cap_ent, d_start, d_len, d_ent,
+                                             h_total_entries, h_overflow_rows);
     }
     return gram_neighbors_impl<uint64_t>(ctx, n, d_xrowptr, d_xcolidx, d_xcounts, m, ncols, d_ycolptr, (const uint64_t *)d_ypost,
-                                         nullptr, row0, row1, cap_ent, d_start, d_len, d_ent, h_total_entries, h_overflow_rows);
+                                         nullptr, d_xrnorm, d_yrnorm, row0, row1, cap_ent, d_start, d_len, d_ent,
+                                         h_total_entries, h_overflow_rows);
 }
 
 extern "C" int skm_neighbors_topk(skm_ctx *ctx, int64_t nrows, int64_t row0, const uint64_t *d_start, const uint32_t *d_len,
@@ -1063,12 +1191,23 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
                 CALL(1, false); \
         }                      \
     } while (0)
+    // 32-bit launch over fb_list (nullptr: every strip, wide ones skipped and listed), then the float64 launch over
+    // the strips with a wide row: a small grid that strides over a list which is empty in all but pathological batches
 #define SKM_CURSOR(MODE, VEC)                                                                                        \
-    k_cosine_strip<MODE, VEC, 0, PW><<<(unsigned)strips, TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, \
-                                                                       d_ypost, d_ypostcnt, d_yrnorm, row0, row1, d_out, ld,   \
-                                                                       fb_list, fb_count)
+    do {                                                                                                             \
+        k_cosine_strip<MODE, VEC, 0, PW, false><<<(unsigned)strips, TB, 0, st>>>(                                    \
+            d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, d_ypost, d_ypostcnt, d_yrnorm, row0, row1, d_out, ld, fb_list, \
+            fb_count, &state->min_yrnorm, wide_list, &state->wide_count);                                            \
+        k_cosine_strip<MODE, VEC, 0, PW, true><<<skm_grid_cap(ctx, strips, 2), TB, 0, st>>>(                         \
+            d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, d_ypost, d_ypostcnt, d_yrnorm, row0, row1, d_out, ld,          \
+            wide_list, &state->wide_count, nullptr, nullptr, nullptr);                                               \
+    } while (0)
 
-    uint32_t *fb_list = nullptr, *fb_count = nullptr;
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_COS, sizeof(cos_state), &p));
+    cos_state *state = (cos_state *)p;
+    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * 2 * (size_t)(strips + 8), &p));  // each strip is listed at most once per list
+    uint32_t *fb_list = nullptr, *fb_count = nullptr, *wide_list = (uint32_t *)p + (strips + 8);
 #ifdef SKM_DIAG
     // Diagnostic builds of the cursor kernel (tools/ablate_cosine.py): results are NOT valid.
     const char *abl_env = getenv("SKM_COSINE_ABLATE");
@@ -1076,9 +1215,9 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     if (abl >= 1 && abl <= 3 && mode == 0 && vec) {
         SKM_PROF(ctx, "k_cosine_strip");
 #define SKM_CURSOR_ABL(ABL)                                                                                          \
-    k_cosine_strip<0, true, ABL, PW><<<(unsigned)strips, TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, \
+    k_cosine_strip<0, true, ABL, PW, false><<<(unsigned)strips, TB, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, \
                                                                        d_ypost, d_ypostcnt, d_yrnorm, row0, row1, d_out, ld,   \
-                                                                       nullptr, nullptr)
+                                                                       nullptr, nullptr, nullptr, nullptr, nullptr)
         if (abl == 1)
             SKM_CURSOR_ABL(1);
         else if (abl == 2)
@@ -1091,6 +1230,7 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
 #endif
     const char *path_env = getenv("SKM_COSINE_PATH");  // "cursor" forces the fallback kernel everywhere
     if (path_env && strcmp(path_env, "cursor") == 0) {
+        SKM_TRY(cosine_prologue(ctx, nullptr, 0, state, 0ull, d_yrnorm, m, st));
         SKM_PROF(ctx, "k_cosine_strip");
         SKM_BY_MODE_VEC(SKM_CURSOR);
         return skm_check_launch("k_cosine_strip");
@@ -1100,6 +1240,7 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     // cursor kernel's dense per-strip accumulators hold every column, no neighbour lists are needed
     // (a list path would pin SLOT entries of scratch per row for a few-MB output).
     if (m <= CH && !(path_env && strcmp(path_env, "lists") == 0)) {  // SKM_COSINE_PATH=lists keeps the list path (tests)
+        SKM_TRY(cosine_prologue(ctx, nullptr, 0, state, 0ull, d_yrnorm, m, st));
         SKM_PROF(ctx, "k_cosine_strip");
         SKM_BY_MODE_VEC(SKM_CURSOR);
         return skm_check_launch("k_cosine_strip");
@@ -1114,27 +1255,23 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     const unsigned long long SLOT = (unsigned long long)(m < FIRST_CAP ? m : FIRST_CAP);
     const unsigned long long fixed_ent = (unsigned long long)nrows * SLOT;
     const unsigned long long cap_ent = fixed_ent + (unsigned long long)max((int64_t)(1 << 20), nrows * 256);
-    void *p;
     SKM_TRY(skm_ws(ctx, WS_A, sizeof(uint64_t) * (size_t)cap_ent, &p));
     uint64_t *g_ent = (uint64_t *)p;
     SKM_TRY(skm_ws(ctx, WS_B, sizeof(uint64_t) * (size_t)(nrows + 8), &p));
     uint64_t *g_start = (uint64_t *)p;
     SKM_TRY(skm_ws(ctx, WS_C, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
     uint32_t *g_len = (uint32_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)(strips + 8), &p));  // each strip is listed at most once
-    fb_list = (uint32_t *)p;
+    fb_list = wide_list - (strips + 8);
     SKM_TRY(skm_ws(ctx, WS_E, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
     uint32_t *over_list = (uint32_t *)p;
     SKM_TRY(skm_ws(ctx, WS_F, sizeof(uint32_t) * (size_t)(strips + 8), &p));
     uint32_t *fb_flag = (uint32_t *)p;
-    SKM_HIP(hipMemsetAsync(fb_flag, 0, sizeof(uint32_t) * (size_t)(strips + 8), st));
-    SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
-    unsigned long long *g_counter = (unsigned long long *)((uint8_t *)p + 2048);
-    fb_count = (uint32_t *)((uint8_t *)p + 2048 + 8);
-    uint32_t *over_count = fb_count + 1;
+    unsigned long long *g_counter = &state->g_counter;
+    fb_count = &state->fb_count;
+    uint32_t *over_count = state->over_count;
     constexpr int MAXB = 16;  // row blocks of the overlapped schedule (one overflow counter each)
-    SKM_HIP(hipMemsetAsync(g_counter, 0, 16 + 4 * MAXB, st));
-    k_set_u64<<<1, 1, 0, st>>>(g_counter, fixed_ent);
+    // strip flags and counters cleared, list allocation behind the fixed slots, min_j yrnorm[j]: one launch
+    SKM_TRY(cosine_prologue(ctx, fb_flag, strips + 8, state, fixed_ent, d_yrnorm, m, st));
 #ifdef SKM_DIAG
     const char *gabl_env = getenv("SKM_GRAM_ABLATE");  // diagnostic builds of k_gram_sparse (1, 2, 4: results NOT valid)
     const int gabl = gabl_env ? atoi(gabl_env) : 0;
@@ -1179,13 +1316,13 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
 #define SKM_GRAM(GABL)                                                                                               \
     k_gram_sparse<GABL, 1, FIRST_GH, 256, 2, 32, 2, PW><<<(unsigned)bn, 256, 0, gs>>>(                               \
         d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0 + b0, row0 + b1, SLOT, b0, g_ent, cap_ent, \
-        g_counter, g_start + b0, g_len + b0, b_over_list, b_over_count)
+        g_counter, g_start + b0, g_len + b0, b_over_list, b_over_count, d_xrnorm, &state->min_yrnorm, G_WIDE_ROW)
 #ifdef SKM_DIAG
             // diagnostic: other lane-group shapes for the lists of 17+ postings (exact results)
 #define SKM_GRAM_SHAPE(GG, UU)                                                                                       \
     k_gram_sparse<0, 1, FIRST_GH, 256, 2, GG, UU, PW><<<(unsigned)bn, 256, 0, gs>>>(                                 \
         d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0 + b0, row0 + b1, SLOT, b0, g_ent, cap_ent, \
-        g_counter, g_start + b0, g_len + b0, b_over_list, b_over_count)
+        g_counter, g_start + b0, g_len + b0, b_over_list, b_over_count, d_xrnorm, &state->min_yrnorm, G_WIDE_ROW)
             const char *shape_env = getenv("SKM_GRAM_SHAPE");
             const int shape = shape_env ? atoi(shape_env) : 0;
             if (gabl == 0 && shape == 1)
@@ -1246,10 +1383,12 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     do {                                                                                                             \
         if (m >= 65536) /* wide rows: 128 KiB per step (fewer barriers, longer bursts: 6.9 vs 7.2 ms at m = 100k) */ \
             k_cosine_write<MODE, VEC, 32768, 1024><<<(unsigned)bn, 1024, 0, s_w>>>(                                  \
-                g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, b0, d_out, ld, fb_list, fb_count, fb_flag);      \
+                g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, b0, d_out, ld, fb_list, fb_count, fb_flag,       \
+                wide_list, &state->wide_count);                                                                      \
         else                                                                                                         \
             k_cosine_write<MODE, VEC, 4096, 1024><<<(unsigned)bn, 1024, 0, s_w>>>(                                   \
-                g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, b0, d_out, ld, fb_list, fb_count, fb_flag);      \
+                g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, b0, d_out, ld, fb_list, fb_count, fb_flag,       \
+                wide_list, &state->wide_count);                                                                      \
     } while (0)
             SKM_BY_MODE_VEC(SKM_WRITE);
 #undef SKM_WRITE
@@ -1277,25 +1416,21 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
 // workload): h_out[0] = rows whose neighbours did not fit the first pass's table (sent to the large-table pass),
 // h_out[1] = 8-row strips left to the cursor kernel (a row overflowed the large table too), h_out[2] = neighbour-list
 // entries written.  Synchronises the stream.
-extern "C" int skm_cosine_csr_stats(skm_ctx *ctx, int64_t *h_out3)
+extern "C" int skm_cosine_csr_stats(skm_ctx *ctx, int64_t *h_out4)
 {
-    SKM_REQUIRE(ctx && h_out3, SKM_E_BADARG, "skm_cosine_csr_stats: bad argument");
-    h_out3[0] = h_out3[1] = h_out3[2] = 0;
-    if (!ctx->ws[WS_SMALL] || ctx->ws_bytes[WS_SMALL] < 4096)
+    SKM_REQUIRE(ctx && h_out4, SKM_E_BADARG, "skm_cosine_csr_stats: bad argument");
+    h_out4[0] = h_out4[1] = h_out4[2] = h_out4[3] = 0;
+    if (!ctx->ws[WS_COS] || ctx->ws_bytes[WS_COS] < sizeof(cos_state))
         return SKM_OK;
     SKM_HIP(hipSetDevice(ctx->device));
-    uint8_t host[16 + 4 * 16];
-    SKM_HIP(hipMemcpyAsync(host, (uint8_t *)ctx->ws[WS_SMALL] + 2048, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    cos_state host;
+    SKM_HIP(hipMemcpyAsync(&host, ctx->ws[WS_COS], offsetof(cos_state, pad), hipMemcpyDeviceToHost, ctx->stream));
     SKM_HIP(hipStreamSynchronize(ctx->stream));
-    unsigned long long ent;
-    uint32_t fb, over[16];
-    memcpy(&ent, host, 8);
-    memcpy(&fb, host + 8, 4);
-    memcpy(over, host + 12, sizeof(over));
     for (int b = 0; b < 16; ++b)
-        h_out3[0] += over[b];
-    h_out3[1] = fb;
-    h_out3[2] = (int64_t)ent;
+        h_out4[0] += host.over_count[b];
+    h_out4[1] = host.fb_count;
+    h_out4[2] = (int64_t)(host.g_counter - host.first_entry);
+    h_out4[3] = host.wide_count;
     return SKM_OK;
 }
 

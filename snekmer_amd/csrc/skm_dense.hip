@@ -742,6 +742,25 @@ __global__ void k_rowptr_from_segments(int64_t n, const int64_t *__restrict__ se
 }
 
 // 1/||row|| of an int8 matrix (and optionally the exact squared norms): wave per row, 16 bytes per lane.
+// out[which] = min of v[0..n) (one workgroup; the rare int32-range check of skm_cosine_dense_i8)
+__global__ __launch_bounds__(1024) void k_min_f32(int64_t n, const float *__restrict__ v, float *__restrict__ out, int which)
+{
+    __shared__ float s_w[16];
+    float mn = INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += 1024)
+        mn = fminf(mn, v[i]);
+    for (int o = 32; o > 0; o >>= 1)
+        mn = fminf(mn, __shfl_xor(mn, o));
+    if ((threadIdx.x & 63) == 0)
+        s_w[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            mn = fminf(mn, s_w[w]);
+        out[which] = mn;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_row_norms_i8(int64_t n, int64_t kdim, const int8_t *__restrict__ in,
                                                       float *__restrict__ rnorm, uint64_t *__restrict__ normsq)
 {
@@ -852,6 +871,22 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
     SKM_REQUIRE(d_x && d_y && d_xrnorm && d_yrnorm && d_out, SKM_E_BADARG, "skm_cosine_dense_i8: null array");
     SKM_REQUIRE((((uintptr_t)d_x | (uintptr_t)d_y) & 15) == 0, SKM_E_BADARG, "skm_cosine_dense_i8: operands must be 16-byte aligned");
     SKM_HIP(hipSetDevice(ctx->device));
+    if (kdim * 127 * 127 >= ((int64_t)1 << 31)) {
+        // Wider than 133 143 columns, 127^2 * kdim no longer bounds the int32 accumulators: the norms must
+        // (<x, y> <= 1 / (xrnorm * yrnorm), the test of skm_cosine_csr).  Rare shape, so this one waits for the device.
+        void *p;
+        SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
+        float *mins = (float *)((uint8_t *)p + 3584);
+        k_min_f32<<<1, 1024, 0, ctx->stream>>>(n, d_xrnorm, mins, 0);
+        k_min_f32<<<1, 1024, 0, ctx->stream>>>(m, d_yrnorm, mins, 1);
+        SKM_TRY(skm_check_launch("k_min_f32"));
+        SKM_HIP(hipMemcpyAsync(ctx->h_pinned, mins, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        SKM_HIP(hipStreamSynchronize(ctx->stream));
+        const float *h = (const float *)ctx->h_pinned;
+        SKM_REQUIRE((double)h[0] * (double)h[1] > 0x1p-31 * (1.0 + 1e-6), SKM_E_OVERFLOW,
+                    "skm_cosine_dense_i8: a dot product may reach 2^31 (row norms %.3g x %.3g); use skm_cosine_csr, which has a wide path",
+                    1.0 / h[0], 1.0 / h[1]);
+    }
     dim3 grid((unsigned)skm_ceil_div(m, BN), (unsigned)skm_ceil_div(n, BM));
     // SKM_DENSE_VARIANT (all variants exact; for A/B timing): 1 register-staged kernel, 2 128x128 LDS-DMA kernel,
     // 3 the 256x256 lock-step kernel, 4 the staggered kernel (default where it applies), 5 staggered without symmetry

@@ -49,6 +49,18 @@ struct posting<uint32_t> {
 constexpr uint32_t G_OVERFLOW = 0xFFFFFFFFu;
 constexpr uint32_t G_SINGLETON = 0xFFFFFFFFu;  // colidx of a k-mer that occurs in one row only
 
+// The int32 guard.  The sparse kernels sum exact integer products in 32-bit cells, so a dot product must stay
+// below 2^31.  By Cauchy-Schwarz <x, y> <= |x||y| = 1 / (rnorm_x * rnorm_y), hence a row of X is safe against EVERY
+// row of Y when rnorm_x * min_j rnorm_y > 2^-31 (the margin covers the float32 rounding of the two reciprocal
+// norms; an all-zero row has rnorm 1 and dot 0).  Rows that fail the test ("wide" rows: a count in the tens of
+// thousands, a homopolymer of 46 342 windows or more, aggregated count matrices) never enter the 32-bit kernels:
+// skm_cosine_csr hands their strips to the float64-accumulator form of k_cosine_strip, skm_gram_neighbors (whose
+// output format IS a 32-bit dot) reports them as rows it cannot hold.
+__device__ __forceinline__ bool skm_row_is_wide(float rnorm_x, float min_rnorm_y)
+{
+    return (double)rnorm_x * (double)min_rnorm_y <= 0x1p-31 * (1.0 + 1e-6);
+}
+
 // GABL  diagnostic ablation (0 = real kernel)
 // GR    rows per workgroup           GH  hash slots per row (at most 3/4 GH distinct neighbours)
 // GT    threads per workgroup        GQ  non-zeros per thread (GQ*GT non-zeros per strip)
@@ -474,8 +486,17 @@ __global__ __launch_bounds__(GT) void k_gram_sparse(const int64_t *__restrict__ 
                                                     uint64_t *__restrict__ g_ent, unsigned long long cap_ent,
                                                     unsigned long long *__restrict__ g_counter,
                                                     uint64_t *__restrict__ g_start, uint32_t *__restrict__ g_len,
-                                                    uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_count)
+                                                    uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_count,
+                                                    const float *__restrict__ xrnorm,
+                                                    const float *__restrict__ min_yrnorm, uint32_t wide_mark)
 {
+    static_assert(GR == 1, "the wide-row test below is per workgroup");
+    // a row whose dot products may reach 2^31 (skm_row_is_wide) is marked and left to the caller's wide path
+    if (skm_row_is_wide(xrnorm[row0 + blockIdx.x], *min_yrnorm)) {
+        if (threadIdx.x == 0)
+            g_len[blockIdx.x] = wide_mark;
+        return;
+    }
     gram_strip<GABL, GR, GH, GT, GQ, G, U, PW>(row0 + (int64_t)blockIdx.x * GR, xrowptr, xcolidx, xcounts, ycolptr, ypost,
                                              ypostcnt, row0, row1, fixed_stride, slot0, g_ent, cap_ent, g_counter, g_start,
                                              g_len, over_list, over_count);

@@ -389,8 +389,8 @@ class ShardedPipeline:
         b = self.basis
         if cap_entries is None:
             cap_entries = 16 * max(self.nnz_total // max(self.world, 1), 1) + (1 << 20)
-        nb = e.gram_neighbors(ctx, self.x, self.n_total, getattr(b, "ncols_shared", b.ncols), b.colptr, b.post,
-                              row0=lo, row1=hi, cap_entries=cap_entries)
+        nb = e.gram_neighbors(ctx, self.x, self.rnorm, self.n_total, getattr(b, "ncols_shared", b.ncols), b.colptr, b.post,
+                              self.rnorm, row0=lo, row1=hi, cap_entries=cap_entries)
         # overflow is a COLLECTIVE decision: a rank that raised alone would leave its peers waiting in the next
         # collective, so every rank learns every rank's count and all of them raise together
         over = self.ex.allgather_i64([nb.overflow_rows])[:, 0]

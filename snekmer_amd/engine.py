@@ -496,10 +496,13 @@ class NeighborLists:
                 (ent & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32))
 
 
-def gram_neighbors(ctx, x: CountsCSR, m: int, ncols: int, colptr, post, row0: int = 0, row1: Optional[int] = None,
-                   cap_entries: Optional[int] = None, post_bits: int = 64, postcnt=None) -> NeighborLists:
+def gram_neighbors(ctx, x: CountsCSR, x_rnorm, m: int, ncols: int, colptr, post, y_rnorm, row0: int = 0,
+                   row1: Optional[int] = None, cap_entries: Optional[int] = None, post_bits: int = 64,
+                   postcnt=None) -> NeighborLists:
     """Neighbour lists (exact sparse Gram rows) for rows [row0,row1) of `x` against the postings of an
-    m-row matrix: the reduced output when the dense matrix cannot be stored (skm_gram_neighbors)."""
+    m-row matrix: the reduced output when the dense matrix cannot be stored (skm_gram_neighbors).  `x_rnorm` /
+    `y_rnorm` (row_norms of the two matrices) let the device refuse rows whose dot products may not fit the 32-bit
+    entries: they come back in `overflow_rows`."""
     row1 = x.n if row1 is None else row1
     nrows = row1 - row0
     cap = int(cap_entries if cap_entries is not None else 16 * max(x.nnz, 1) + (1 << 20))
@@ -508,8 +511,8 @@ def gram_neighbors(ctx, x: CountsCSR, m: int, ncols: int, colptr, post, row0: in
     ent = ctx.empty(max(cap, 1), np.uint64)
     total, ovf = _i64(0), _i64(0)
     ctx.call("skm_gram_neighbors", _i64(x.n), _ptr(x.rowptr), _ptr(x.colidx), _ptr(x.counts), _i64(m), _i64(ncols),
-             _ptr(colptr), _ptr(post), post_bits, _ptr(postcnt), _i64(row0), _i64(row1), _i64(cap), _ptr(start), _ptr(length),
-             _ptr(ent), C.byref(total), C.byref(ovf))
+             _ptr(colptr), _ptr(post), post_bits, _ptr(postcnt), _ptr(x_rnorm), _ptr(y_rnorm), _i64(row0), _i64(row1), _i64(cap),
+             _ptr(start), _ptr(length), _ptr(ent), C.byref(total), C.byref(ovf))
     return NeighborLists(ctx, row0, row1, start, length, ent, int(total.value), int(ovf.value))
 
 

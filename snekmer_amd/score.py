@@ -7,7 +7,9 @@ DataFrames or scipy sparse matrices in, float64 ndarray out, as sklearn).
 
 Three device paths, all exact in the sense the reference needs (|error| <= 1e-5, in practice far less):
 count matrices (non-negative integers, what the rule call sites pass) take the exact-integer sparse
-Gram or, for small dense bases, the i8 MFMA GEMM, both with float32 scaling; any other real-valued
+Gram (int32 cells where the rows' norms prove that every dot product fits, float64 accumulators for the
+rows where they do not: include/snekmer_hip.h, skm_cosine_csr) or, for small dense bases, the i8 MFMA GEMM,
+both with float32 scaling; any other real-valued
 matrix (e.g. the length-normalised rows of snekmer/utils.py:183-203) takes a float64 GEMM on the
 f64 matrix cores with sklearn's own order of operations.  There is no CPU path.
 """
@@ -40,8 +42,8 @@ def _as_count_csr(ctx, X):
     data = np.asarray(data)
     if data.size and (np.any(data < 0) or np.any(data != np.floor(data))):
         raise ValueError("internal: real-valued features must take the float64 path")
-    if data.size and data.max() >= 2**28:
-        raise OverflowError("counts >= 2^28 are unsupported")
+    if data.size and data.max() >= 2**32:  # cosine_similarity sends such matrices to the float64 path
+        raise OverflowError("counts >= 2^32 do not fit the CSR's uint32 cells")
     csr = engine.CountsCSR(
         ctx, int(shape[0]), int(data.size), 32, ctx.to_device(np.asarray(indptr, dtype=np.int64)),
         ctx.to_device(np.zeros(max(int(data.size), 1), dtype=np.uint32)), ctx.to_device(data.astype(np.uint32) if data.size else np.zeros(1, np.uint32)), None,
@@ -126,6 +128,12 @@ def _is_count_matrix(M) -> bool:
     return bool(np.all(np.isfinite(v)) and v.min() >= 0 and np.all(v == np.floor(v)))
 
 
+def _fits_u32(M) -> bool:
+    """Counts are uint32 on the device; a count matrix with a larger cell is just a real-valued matrix (float64 path)."""
+    v = np.asarray(_values(M))
+    return bool(v.dtype == bool or v.size == 0 or v.max() < 2**32)
+
+
 F64_MAX_ELEMS = 1 << 31  # dense float64 operands above 16 GiB are refused rather than silently densified
 
 
@@ -183,7 +191,7 @@ def cosine_similarity(X, Y=None, mode: int = 0, ctx=None, path: str = "auto", dt
         Y = None
     X = _plain(X)
     Y = None if Y is None else _plain(Y)
-    counts = _is_count_matrix(X) and (Y is None or _is_count_matrix(Y))
+    counts = _is_count_matrix(X) and (Y is None or _is_count_matrix(Y)) and _fits_u32(X) and (Y is None or _fits_u32(Y))
     if path == "f64" or (path == "auto" and not counts):
         return _cosine_f64(ctx, X, Y, mode).astype(dtype, copy=False)
     if not counts:

@@ -3,7 +3,8 @@
 tests/test_gpu_parity.py::test_fuzz_short on a GPU box):  python tests/fuzz_parity.py [seconds] [first_seed]
 
 Every round draws an alphabet, a k, and a batch (family sequences with substitutions, junk characters, trailing
-stars, lowercase, empties, repeats, a few long records) and compares, bit for bit unless stated:
+stars, lowercase, empties, repeats, a few long records, now and then a homopolymer long enough for dot products
+beyond int32) and compares, bit for bit unless stated:
   * skm_count_csr and skm_vectorize_csr (CSR, basis codes, column starts, column ids, row norms) with the C oracle;
   * the N x N cosine by the neighbour-list path, by the cursor kernel and by the overlapped schedule with each other,
     and with the oracle's float64 rows to 1e-5;
@@ -55,6 +56,17 @@ def draw_batch(rng, big=False):
             if rng.random() < 0.1:
                 t += "*" * int(rng.integers(1, 3))
             seqs.append(t)
+    if rng.random() < 0.08:
+        # records of 46 342 windows or more in one or two letters: a k-mer count whose square leaves int32, so the row's
+        # dot products take the float64-accumulator kernel (and its strip neighbours with it)
+        for _ in range(int(rng.integers(1, 3))):
+            L = int(rng.integers(46400, 70000))
+            unit = AA[rng.integers(0, 20, size=int(rng.integers(1, 3)))]
+            s = np.resize(unit, L).copy()
+            if rng.random() < 0.5:
+                m = rng.random(L) < 0.0005
+                s[m] = AA[rng.integers(0, 20, size=int(m.sum()))]
+            seqs.append(s.tobytes().decode() + ("*" if rng.random() < 0.3 else ""))
     order = rng.permutation(len(seqs))
     return [seqs[i] for i in order]
 
@@ -131,7 +143,7 @@ def one_round(ctx, seed, verbose=False):
         lo = int(rng.integers(0, n))
         hi = int(rng.integers(lo + 1, n + 1))
         b = p.basis
-        nb = engine.gram_neighbors(ctx, p.csr, n, b.ncols, b.colptr, b.post, row0=lo, row1=hi, post_bits=b.post_bits, postcnt=b.postcnt)
+        nb = engine.gram_neighbors(ctx, p.csr, p.rnorm, n, b.ncols, b.colptr, b.post, p.rnorm, row0=lo, row1=hi, post_bits=b.post_bits, postcnt=b.postcnt)
         start, length, jj, dot = nb.host()
         nsq = np.add.reduceat(np.concatenate([o_counts.astype(np.float64) ** 2, [0.0]]), np.minimum(o_rowptr[:-1], nnz))
         nsq[np.diff(o_rowptr) == 0] = 0.0

@@ -300,6 +300,135 @@ def test_cosine_medium_vs_oracle_all_modes(ctx):
     assert np.abs(D - refD).max() <= COS_TOL and (np.diag(D) == 0).all()
 
 
+# ------------------------------------------------------------------ dot products beyond int32 (the wide path)
+def _cosine_f64(X, Y=None):
+    """sklearn's arithmetic in numpy float64: rows normalised (zero norm -> 1), then the dot products."""
+    X = np.asarray(X, dtype=np.float64)
+    Y = X if Y is None else np.asarray(Y, dtype=np.float64)
+    xn = np.sqrt((X * X).sum(1))
+    yn = np.sqrt((Y * Y).sum(1))
+    xn[xn == 0] = 1.0
+    yn[yn == 0] = 1.0
+    return (X / xn[:, None]) @ (Y / yn[:, None]).T
+
+
+@pytest.mark.cosine_paths
+def test_counts_whose_dot_products_exceed_int32_api(ctx):
+    """sklearn's cosine_similarity is float64 and has no range limit (rules/apply.smk:282-284, snekmer/score.py:169-171);
+    the int32 cells of the sparse kernels do.  Rows whose norms allow a dot product of 2^31 or more take float64 accumulators."""
+    from snekmer_amd import score
+
+    assert score.cosine_similarity(np.array([[70000]]))[0, 0] == pytest.approx(1.0, abs=1e-6)  # dot 4.9e9
+    X = np.array([[70000, 1, 0], [3, 70000, 0], [1, 1, 1], [0, 0, 0], [46341, 0, 0], [46340, 0, 0]])
+    for path in ("auto", "sparse"):
+        S = score.cosine_similarity(X, path=path)
+        assert np.abs(S - _cosine_f64(X)).max() <= COS_TOL
+        assert (S[3] == 0).all() and (S[:, 3] == 0).all()
+    # counts that use all 32 bits, and counts that do not fit them (float64 path)
+    for big in (np.array([[2**30, 5], [7, 2**31], [2**32 - 1, 2**32 - 1]]), np.array([[2**33, 1], [1, 2**33], [2**40, 2**40]])):
+        assert np.abs(score.cosine_similarity(big) - _cosine_f64(big)).max() <= COS_TOL
+    # rectangular, Y other than X: the X rows are wide because of ONE row of Y
+    rng = np.random.default_rng(11)
+    A = rng.integers(0, 40, size=(37, 50))
+    B = rng.integers(0, 40, size=(1100, 50))
+    B[700] *= 3_000_000
+    S = score.cosine_similarity(A, B, path="sparse")
+    assert np.abs(S - _cosine_f64(A, B)).max() <= COS_TOL
+    D = score.cosine_similarity(A, B, mode=1, path="sparse")
+    assert np.abs(D - np.clip(1.0 - _cosine_f64(A, B), 0, 2)).max() <= COS_TOL
+    # an aggregated count matrix through the reference's entry point (cosine distance, exact-zero diagonal),
+    # more than 1024 rows so that the neighbour-list kernels are the default route
+    C = rng.integers(0, 30, size=(1300, 40)) * (rng.random((1300, 40)) < 0.3) * 1000
+    C[5] = 0
+    got = score.connection_matrix_from_features(C, metric="cosine")
+    ref = np.clip(1.0 - _cosine_f64(C), 0, 2)
+    np.fill_diagonal(ref, 0.0)
+    assert np.abs(got - ref).max() <= COS_TOL and (np.diag(got) == 0).all()
+    try:
+        from sklearn.metrics import pairwise_distances
+
+        assert np.abs(got - pairwise_distances(C, metric="cosine")).max() <= COS_TOL
+    except ImportError:  # pragma: no cover
+        pass
+
+
+@pytest.mark.cosine_paths
+@pytest.mark.parametrize("mode", [0, 1])
+def test_homopolymers_beyond_int32_beside_normal_rows_vs_oracle(ctx, mode):
+    """A 50 000-residue homopolymer at hydro k=3 has ONE k-mer with count 49 998: its diagonal dot is 2.5e9 > 2^31.  Beside
+    normal rows, square and as a rank's row block; a 40 000-residue run is wide only because of its neighbours
+    (39 998^2 < 2^31 < 39 998 * 59 998); everything else stays on the 32-bit kernels."""
+    import ctypes as C
+
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+    from snekmer_amd.utils import pack_sequences
+
+    orc = _oracle()
+    lut = A.build_lut("hydro")
+    k = 3
+    res, off, _ = synth_families(1400, 300, family=20, seed=77)
+    raw = res.tobytes()
+    seqs = [raw[off[i] : off[i + 1]].decode() for i in range(1400)]
+    seqs.insert(3, "A" * 50000)
+    seqs.insert(640, "AG" * 30000)
+    seqs.insert(641, "MKV")  # empty row inside a wide strip
+    seqs.insert(1203, "L" * 40000 + "SSSS")
+    seqs.append("AILMV" * 9300 + "*")
+    res, off = pack_sequences(seqs)
+    n = len(seqs)
+    batch = engine.SeqBatch(ctx, res, off)
+    pipe = engine.Pipeline(ctx, lut, k)
+    pipe.vectorize(batch)
+    b = pipe.basis
+    ld = (n + 3) // 4 * 4
+    S = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, b.ncols_hint(), b.colptr, b.post, pipe.rnorm, mode=mode, ld=ld)
+    S = S.download().reshape(-1, ld)[:n, :n]
+    st = (C.c_int64 * 4)()
+    ctx.call("skm_cosine_csr_stats", st)
+    assert st[3] == 4  # strips with a wide row: those of rows 3, 640 (with the empty row 641), 1203 and the last one
+    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
+    assert int(o_counts.max()) == 59998
+    ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), np.arange(n))
+    assert ref[3, 640] > 0.99 and ref[3, 3] == pytest.approx(1.0)
+    if mode == 1:
+        ref = np.clip(1.0 - ref, 0, 2)
+        np.fill_diagonal(ref, 0.0)
+    assert np.abs(S - ref).max() <= COS_TOL
+    # one rank's row block
+    blk = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, b.ncols_hint(), b.colptr, b.post, pipe.rnorm, row0=600, row1=1250,
+                               mode=mode, ld=ld).download().reshape(-1, ld)[:650, :n]
+    assert (blk == S[600:1250]).all()
+    # the neighbour lists hold 32-bit dots: the wide rows are reported as rows the lists cannot hold, the others are exact
+    if mode == 0:
+        nb = engine.gram_neighbors(ctx, pipe.csr, pipe.rnorm, n, b.ncols, b.colptr, b.post, pipe.rnorm, cap_entries=n * (n + 8))
+        length = nb.length.download(n)
+        wide = {3, 640, 1203, n - 1}
+        assert set(np.nonzero(length == 0xFFFFFFFF)[0].tolist()) == wide and nb.overflow_rows == len(wide)
+
+
+def test_dense_i8_refuses_operands_whose_dot_products_may_leave_int32(ctx):
+    """127^2 * kdim bounds the MFMA kernel's int32 accumulators up to 133 143 columns; beyond, the norms must."""
+    from snekmer_amd import _hip, engine
+
+    kdim = 133248
+    X = np.zeros((4, kdim), dtype=np.int8)
+    X[0, :5000] = 127
+    X[1, ::7] = 3
+    dx = ctx.to_device(X)
+    xr = engine.row_norms_i8(ctx, 4, kdim, dx)
+    S = engine.cosine_dense_i8(ctx, 4, 4, kdim, dx, dx, xr, xr).download().reshape(4, 4)
+    assert np.abs(S - _cosine_f64(X)).max() <= COS_TOL
+    X[2] = 127
+    X[3] = 127  # <x2, x3> = 127^2 * 133248 = 2 149 156 992 > 2^31
+    dx = ctx.to_device(X)
+    xr = engine.row_norms_i8(ctx, 4, kdim, dx)
+    with pytest.raises(_hip.HipError, match="OVERFLOW"):
+        engine.cosine_dense_i8(ctx, 4, 4, kdim, dx, dx, xr, xr)
+
+
 @pytest.mark.cosine_paths
 def test_connection_matrix_and_feature_matrix_goldens(ctx):
     import snekmer_amd as skm
@@ -979,7 +1108,7 @@ def test_heavy_rows_every_list_shape_vs_oracle(ctx, mode):
     if os.environ.get("SKM_COSINE_PATH") != "cursor":
         import ctypes as C
 
-        st = (C.c_int64 * 3)()
+        st = (C.c_int64 * 4)()
         ctx.call("skm_cosine_csr_stats", st)
         assert st[0] >= 1700 + 70 + 5 + 3 + 1  # rows handed to the heavy kernel ...
         assert 1 <= st[1] <= 3                 # ... of which the three 3000-residue copies end in cursor strips
@@ -1244,7 +1373,7 @@ def test_gram_neighbors_and_topk_vs_oracle(ctx):
     n = batch.n
     b = pipe.basis
     lo, hi = 100, 1100
-    nb = engine.gram_neighbors(ctx, pipe.csr, n, b.ncols, b.colptr, b.post, row0=lo, row1=hi, post_bits=b.post_bits, postcnt=b.postcnt)
+    nb = engine.gram_neighbors(ctx, pipe.csr, pipe.rnorm, n, b.ncols, b.colptr, b.post, pipe.rnorm, row0=lo, row1=hi, post_bits=b.post_bits, postcnt=b.postcnt)
     start, length, jj, dot = nb.host()
     o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
     ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
@@ -1403,7 +1532,7 @@ def test_posting_formats_agree_incl_saturated_counts(ctx):
         out = pipe.step(batch)
         assert pipe.basis.post_bits == (32 if p32 else 64)
         outs.append(out.download().reshape(out.shape)[:n, :n].copy())
-        nb = engine.gram_neighbors(ctx, pipe.csr, n, pipe.basis.ncols, pipe.basis.colptr, pipe.basis.post,
+        nb = engine.gram_neighbors(ctx, pipe.csr, pipe.rnorm, n, pipe.basis.ncols, pipe.basis.colptr, pipe.basis.post, pipe.rnorm,
                                    post_bits=pipe.basis.post_bits, postcnt=pipe.basis.postcnt)
         outs.append(nb.host())
     assert (outs[0] == outs[2]).all()
@@ -1650,7 +1779,7 @@ def test_config4_one_rank_share_125k_rows_vs_1m(ctx):
     pipe = engine.Pipeline(ctx, lut, k)
     pipe.vectorize(batch)
     b = pipe.basis
-    nb = engine.gram_neighbors(ctx, pipe.csr, n, b.ncols, b.colptr, b.post, row0=0, row1=block, cap_entries=block * 6000,
+    nb = engine.gram_neighbors(ctx, pipe.csr, pipe.rnorm, n, b.ncols, b.colptr, b.post, pipe.rnorm, row0=0, row1=block, cap_entries=block * 6000,
                                post_bits=b.post_bits, postcnt=b.postcnt)
     assert nb.overflow_rows == 0
     idx, val = engine.neighbors_topk(ctx, nb, pipe.rnorm, pipe.rnorm, topk, exclude_self=True)

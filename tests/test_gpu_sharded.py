@@ -107,7 +107,7 @@ def test_sharded_threads_small_dense_block_and_topk(ctx, world, n, name, by_resi
         assert (r["block"] == S[lo:hi]).all()
         if hi == lo:
             continue
-        nb = engine.gram_neighbors(ctx, ref.csr, n, b.ncols, b.colptr, b.post, row0=lo, row1=hi, post_bits=b.post_bits, postcnt=b.postcnt)
+        nb = engine.gram_neighbors(ctx, ref.csr, ref.rnorm, n, b.ncols, b.colptr, b.post, ref.rnorm, row0=lo, row1=hi, post_bits=b.post_bits, postcnt=b.postcnt)
         want, got = _canonical_lists(*nb.host()), _canonical_lists(*r["lists"])
         for w, g in zip(want, got):
             assert (w == g).all()
@@ -176,7 +176,7 @@ def _config4_body(ctx, lut, k, n, world, topk, check):
         if rank not in check:
             continue
         assert (r["rnorm"] == rn).all()
-        nb = engine.gram_neighbors(ctx, ref.csr, n, b.ncols, b.colptr, b.post, row0=lo, row1=hi, cap_entries=(hi - lo) * 4000,
+        nb = engine.gram_neighbors(ctx, ref.csr, ref.rnorm, n, b.ncols, b.colptr, b.post, ref.rnorm, row0=lo, row1=hi, cap_entries=(hi - lo) * 4000,
                                    post_bits=b.post_bits, postcnt=b.postcnt)
         assert nb.overflow_rows == 0 and nb.total == r["entries"]
         want, got = _canonical_lists(*nb.host()), _canonical_lists(*r["lists"])

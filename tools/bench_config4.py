@@ -78,7 +78,7 @@ for rnd in range(2):
     t_vec = time.perf_counter() - t0
     b = pipe.basis
     t0 = time.perf_counter()
-    nb = engine.gram_neighbors(ctx, pipe.csr, n, b.ncols, b.colptr, b.post, row0=0, row1=block,
+    nb = engine.gram_neighbors(ctx, pipe.csr, pipe.rnorm, n, b.ncols, b.colptr, b.post, pipe.rnorm, row0=0, row1=block,
                                cap_entries=block * 6000, post_bits=b.post_bits, postcnt=b.postcnt)
     ctx.sync()
     t_nb = time.perf_counter() - t0

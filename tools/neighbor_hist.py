@@ -18,7 +18,7 @@ res, off, _ = synth_families(n, 300, family=100, seed=BASE_SEED + 2)
 pipe = engine.Pipeline(ctx, lut, 12)
 csr = pipe.vectorize(engine.SeqBatch(ctx, res, off))
 b = pipe.basis
-nb = engine.gram_neighbors(ctx, csr, n, b.ncols, b.colptr, b.post, post_bits=b.post_bits, postcnt=b.postcnt)
+nb = engine.gram_neighbors(ctx, csr, pipe.rnorm, n, b.ncols, b.colptr, b.post, pipe.rnorm, post_bits=b.post_bits, postcnt=b.postcnt)
 ln = nb.length.download(n).astype(np.int64)
 ln = ln[ln != 0xFFFFFFFF]
 nnz_row = np.diff(csr.rowptr.download(n + 1))
