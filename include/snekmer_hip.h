@@ -480,6 +480,17 @@ int skm_fasta_index(const uint8_t *h_buf, int64_t len, int nthreads, int64_t *ou
 int skm_fasta_parse(const uint8_t *h_buf, int64_t len, int nthreads, int64_t nrecords, int64_t nresidues,
                     uint8_t *h_out_residues, int64_t *h_out_offsets, int64_t *h_out_id_begin, int32_t *h_out_id_len);
 
+/* HOST function, no GPU and no context: the `.npz` writer of the rule (np.savez_compressed at
+ * snekmer/rules/kmerize.smk:132-139; read back by snekmer/io.py:46-96 through np.load).  Writes a zip archive with one
+ * member "<names[m]>.npy" per array = h_headers[m] (the .npy header bytes, numpy.lib.format) followed by h_data[m]
+ * (the C-contiguous array bytes).  level: -1 = zlib's default (6, what numpy uses), 1-9, or 0 = stored (np.savez).
+ * Every member is deflated in 2 MiB chunks by nthreads threads (< 1: all hardware threads), each chunk a run of raw
+ * deflate blocks closed by a sync flush, the chunks' CRC-32s combined: one ordinary deflate stream per member that any
+ * unzip reads.  *out_file_bytes (optional) = size of the file written. */
+int skm_npz_write(const char *path, int nmembers, const char *const *names, const void *const *h_headers,
+                  const int64_t *header_bytes, const void *const *h_data, const int64_t *data_bytes, int level,
+                  int nthreads, int64_t *out_file_bytes);
+
 /* Ragged byte rows -> fixed-width UCS-4 rows, zero padded: d_out[i * width + j] = d_bytes[d_off[i] + j] for
  * j < d_len[i].  Viewed as numpy '<U{width}' this is the `seqs` array of reduced strings the rule stores
  * (snekmer/rules/kmerize.smk:121-127,136) without a per-record Python string (bytes are latin-1 code points). */

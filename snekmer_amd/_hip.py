@@ -113,6 +113,7 @@ _SIGNATURES = {
     "skm_apply_top2": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p]),
     "skm_fasta_index": (C.c_int, [_p, _i64, C.c_int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_int)]),
     "skm_fasta_parse": (C.c_int, [_p, _i64, C.c_int, _i64, _i64, _p, _p, _p, _p]),
+    "skm_npz_write": (C.c_int, [C.c_char_p, C.c_int, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.POINTER(_i64)]),
     "skm_rows_to_utf32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p]),
     "skm_decode_kmers_utf32": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p, _p, _p, _i64, _p]),
     "skm_csr_remap_columns": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _p, _p, _p, C.POINTER(_i64)]),

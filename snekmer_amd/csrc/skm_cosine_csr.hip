@@ -508,6 +508,12 @@ __global__ __launch_bounds__(WTB) void k_cosine_write(const uint64_t *__restrict
 // shared non-zeros (HEAVY_EMAX; rows beyond that stay flagged for the cursor kernel).  The step's tile is then scaled
 // and stored like the writer's.  A row done here gets g_len = G_DONE_ROW: the writer's workgroup for it exits.
 constexpr int HEAVY_CH = 32768, HEAVY_TB = 1024, HEAVY_EMAX = 2048, HEAVY_U = 4, HEAVY_NG = 4;
+// 128 KiB tile + 24 KiB of list state: this kernel (like the writer's 128 KiB tile) needs gfx950's 160 KiB of LDS per
+// workgroup; the library is built for gfx950 only (csrc/Makefile).
+static_assert(HEAVY_CH * 4 + 3 * HEAVY_EMAX * 4 + 64 <= 160 * 1024, "k_cosine_heavy needs 160 KiB of LDS (gfx950)");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libsnekmer_hip is written for gfx950 (MI355X): 160 KiB LDS tiles, gfx950 MFMA shapes"
+#endif
 
 template <int MODE, bool VEC, typename PW>
 __global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__restrict__ xrowptr,

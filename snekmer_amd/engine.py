@@ -542,9 +542,9 @@ class DensePipeline:
         self.csr = self.rnorm = self.dense = self.out = self._d_max = None
 
     def step(self, batch: SeqBatch, mode: int = 0):
-        """count -> int8 operand -> norms -> symmetric MFMA GEMM.  Every buffer is reused between steps and no stage
-        waits for another through the host: the largest count (which decides whether int8 holds the operand) stays on
-        the device and is read once, after the GEMM has been queued."""
+        """count -> int8 operand -> norms -> symmetric MFMA GEMM.  Every buffer is reused between steps.  The largest
+        count (which decides whether int8 holds the operand) stays on the device and is read once, after the GEMM has
+        been queued; one size read-back remains in front of it (count_csr returns the entry count to the host)."""
         ctx = self.ctx
         self.csr = count_csr(ctx, batch, self.lut, self.k, out=self.csr)
         n = self.csr.n
@@ -560,6 +560,7 @@ class DensePipeline:
             self.out = ctx.empty((max(n, 1), max(ld, 1)), np.float32)
         cosine_dense_i8(ctx, n, n, self.kdim, self.dense, self.dense, self.rnorm, self.rnorm, mode=mode, out=self.out, ld=ld)
         if int(self._d_max.download(1)[0]) > 127:
+            self.out = self.dense = None  # they hold a product of saturated operands: nothing a caller may read
             raise OverflowError("a k-mer count exceeds 127: int8 dense path not applicable")
         return self.out
 

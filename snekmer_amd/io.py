@@ -13,9 +13,6 @@ from typing import Dict, List, Tuple
 import numpy as np
 
 
-_SPACE = " \t\n\r\x0b\x0c\x1c\x1d\x1e\x1f"
-
-
 def read_fasta(path: str) -> List[Tuple[str, str]]:
     """(id, sequence) per record, as ``Bio.SeqIO.parse(path, "fasta")`` yields ``record.id`` / ``str(record.seq)``
     (Biopython's SimpleFastaParser: text before the first '>' line is skipped; id = first word of the header; the
@@ -38,11 +35,12 @@ def read_fasta(path: str) -> List[Tuple[str, str]]:
     return records
 
 
-def read_fasta_packed(path: str, threads: int = 0):
+def read_fasta_packed(path: str, threads: int = 0, with_records: bool = False):
     """FASTA file -> (ids '<U' array, residues uint8[total], offsets int64[n+1]): the packed layout the device entry
     points take, produced by the C library's threaded reader (skm_fasta_index / skm_fasta_parse: host code, no GPU)
     instead of a per-record Python loop.  Same records as `read_fasta`; files with non-ASCII bytes (which a text
-    handle decodes as UTF-8) take the text-mode path."""
+    handle decodes as UTF-8) take the text-mode path.  `with_records=True` adds a fourth item: the (id, sequence)
+    strings when the text-mode path was taken (the packed bytes cannot hold characters above latin-1), else None."""
     import ctypes as C
 
     from . import _hip
@@ -57,7 +55,8 @@ def read_fasta_packed(path: str, threads: int = 0):
     if flags.value & 1:
         recs = read_fasta(path)
         res, off = pack_sequences([s for _, s in recs])
-        return (np.asarray([r[0] for r in recs], dtype=str) if recs else np.array([], dtype=str)), res, off
+        ids = np.asarray([r[0] for r in recs], dtype=str) if recs else np.array([], dtype=str)
+        return (ids, res, off, recs) if with_records else (ids, res, off)
     n = nrec.value
     res = np.empty(nres.value, dtype=np.uint8)
     off = np.zeros(n + 1, dtype=np.int64)
@@ -65,14 +64,15 @@ def read_fasta_packed(path: str, threads: int = 0):
     _hip._check(lib, lib.skm_fasta_parse(buf.ctypes.data_as(p), buf.size, threads, n, nres.value, res.ctypes.data_as(p),
                                          off.ctypes.data_as(p), idb.ctypes.data_as(p), idl.ctypes.data_as(p)))
     if n == 0:
-        return np.array([], dtype=str), res, off
+        return (np.array([], dtype=str), res, off, None) if with_records else (np.array([], dtype=str), res, off)
     idb, idl = idb[:n], idl[:n]
     width = max(int(idl.max()), 1)
     # ids as a '<U{width}' array: gather the spans into a zero-padded UCS-4 matrix (ASCII bytes are code points)
     cols = np.arange(width, dtype=np.int64)
     take = np.minimum(idb[:, None] + cols[None, :], max(buf.size - 1, 0))
     ids = np.where(cols[None, :] < idl[:, None], buf[take] if buf.size else 0, 0).astype(np.uint32)
-    return np.ascontiguousarray(ids).view(f"<U{width}").ravel(), res, off
+    ids = np.ascontiguousarray(ids).view(f"<U{width}").ravel()
+    return (ids, res, off, None) if with_records else (ids, res, off)
 
 
 def read_kmers(filename: str) -> List[str]:
@@ -106,12 +106,58 @@ def load_npz(
 SPARSE_KEYS = ("kmerlist", "ids", "seqs", "lengths", "counts_rowptr", "counts_col", "counts_val")
 
 
+def save_npz(filename: str, arrays: Dict[str, np.ndarray], compressed: bool = True, level: int = -1, threads: int = 0,
+             _lib=None) -> int:
+    """``np.savez_compressed(filename, **arrays)`` (compressed=True: what rules/kmerize.smk:132-139 calls) or
+    ``np.savez`` (compressed=False) through the C library's threaded writer (skm_npz_write: host code, no GPU): the same
+    zip-of-.npy container, every member deflated in 2 MiB chunks on all cores instead of on one thread.  np.load and
+    the reference's io.load_npz (snekmer/io.py:46-96) read the file unchanged.  Like numpy, ".npz" is appended to a
+    name without it.  Object arrays (which numpy would pickle) are not supported.  Returns the file's size in bytes."""
+    import ctypes as C
+    import io as _io
+    import os
+
+    from . import _hip
+
+    lib = _lib or _hip.load_library()  # (_lib: the sanitizer build of the host code, tests/asan_driver.py)
+    filename = os.fspath(filename)
+    if not filename.endswith(".npz"):
+        filename += ".npz"
+    names, headers, datas = [], [], []
+    for name, arr in arrays.items():
+        a = np.asanyarray(arr)
+        if a.dtype.hasobject:
+            raise TypeError(f"save_npz: member {name!r} is an object array")
+        if not a.flags.c_contiguous and not a.flags.f_contiguous:
+            a = np.ascontiguousarray(a)
+        hdr = _io.BytesIO()
+        # numpy's own header writer: picks format version 1.0 / 2.0 / 3.0 as np.save does
+        np.lib.format._write_array_header(hdr, np.lib.format.header_data_from_array_1_0(a), None)
+        names.append(str(name).encode())
+        headers.append(hdr.getvalue())
+        datas.append(a)
+    n = len(names)
+    c_names = (C.c_char_p * max(n, 1))(*names)
+    hbufs = [C.create_string_buffer(h, len(h)) for h in headers]
+    c_headers = (C.c_void_p * max(n, 1))(*[C.addressof(b) for b in hbufs])
+    c_hbytes = (C.c_int64 * max(n, 1))(*[len(h) for h in headers])
+    c_data = (C.c_void_p * max(n, 1))(*[a.ctypes.data if a.nbytes else None for a in datas])
+    c_dbytes = (C.c_int64 * max(n, 1))(*[a.nbytes for a in datas])
+    size = C.c_int64(0)
+    lib.skm_npz_write.restype = C.c_int
+    lib.skm_npz_write.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                  C.POINTER(C.c_int64)]
+    lib.skm_last_error.restype = C.c_char_p
+    _hip._check(lib, lib.skm_npz_write(filename.encode(), n, c_names, c_headers, c_hbytes, c_data, c_dbytes,
+                                       (level if compressed else 0), threads, C.byref(size)))
+    return int(size.value)
+
+
 def save_npz_sparse(filename: str, out: Dict[str, np.ndarray], compressed: bool = True) -> None:
     """The rule's ``.npz`` with the count matrix as CSR (`counts_rowptr/col/val` over the columns
     of ``kmerlist``) in place of the dense presence matrix ``vecs``.  `out` is what
-    kmerize.vectorize_records returns.  `compressed=False` stores the members as they are (np.savez): zlib is what
-    a 100 k-sequence call spends 15 of its 15.1 seconds in; np.load reads both."""
-    (np.savez_compressed if compressed else np.savez)(filename, **{k: out[k] for k in SPARSE_KEYS})
+    kmerize.vectorize_records returns.  `compressed=False` stores the members as they are; np.load reads both."""
+    save_npz(filename, {k: out[k] for k in SPARSE_KEYS}, compressed=compressed)
 
 
 def load_counts_npz(filename: str):

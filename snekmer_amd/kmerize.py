@@ -20,7 +20,7 @@ import numpy as np
 
 from . import engine
 from .alphabet import FULL_ALPHABETS, build_lut
-from .io import read_fasta, read_fasta_packed, save_npz_sparse
+from .io import read_fasta, read_fasta_packed, save_npz, save_npz_sparse
 from .utils import pack_sequences
 from .vectorize import KmerVec, _restore_wide_chars
 
@@ -104,11 +104,14 @@ def vectorize_packed(
         pos_c = np.clip(pos, 0, max(B - 1, 0))
         hit = ok & (pos < B) & (bcodes[pos_c] == want if B else False)
         colmap = np.full(max(B, 1), 0xFFFFFFFF, dtype=np.uint32)
-        # a k-mer listed twice in the basis keeps only its last column non-zero upstream as well
-        colmap[pos_c[hit]] = np.nonzero(hit)[0].astype(np.uint32)
+        # A k-mer listed more than once: upstream every one of its columns is set (np.isin over the basis,
+        # kmerize.smk:119; the count loop of learn.smk:376-383 looks each column up by name).  The device fills the
+        # FIRST of them; the others are copies made below.
+        _, first_of = np.unique(kmerlist, return_index=True) if len(kmerlist) else (None, np.zeros(0, np.int64))
+        lead = np.zeros(len(kmerlist), dtype=bool)
+        lead[first_of] = True
+        colmap[pos_c[hit & lead]] = np.nonzero(hit & lead)[0].astype(np.uint32)
         ncols_out = int(len(kmerlist))
-        if len(set(kmerlist.tolist())) != len(kmerlist):
-            raise NotImplementedError("explicit basis with repeated k-mers is unsupported")
         d_colmap = ctx.to_device(colmap)
     # additive: integer counts in the kmerlist column order, CSR
     c_rowptr, c_col, c_val = engine.csr_remap_columns(ctx, csr, d_colmap, B)
@@ -117,6 +120,8 @@ def vectorize_packed(
         vecs = engine.csr_to_dense(ctx, n, csr.rowptr, csr.colidx, csr.counts, ncols_out, colmap=d_colmap,
                                    presence=True, dtype=np.float64).download()
         vecs = vecs.reshape(max(n, 1), max(ncols_out, 1))[:n, :ncols_out]
+    if basis is not None and not lead.all():
+        c_rowptr, c_col, c_val, vecs = _copy_repeated_columns(kmerlist, c_rowptr, c_col, c_val, vecs)
     t1 = time.perf_counter()
 
     # string forms: reduced sequences (kmerize.smk:121-127) and the basis k-mers (kmerize.smk:102-106)
@@ -140,6 +145,27 @@ def vectorize_packed(
     return out
 
 
+def _copy_repeated_columns(kmerlist, rowptr, col, val, vecs):
+    """Columns of an explicit basis that repeat an earlier k-mer become copies of that k-mer's first column: in the
+    presence matrix and in the CSR counts (each entry of a first column is followed by its copies, columns ascending)."""
+    _, inverse = np.unique(kmerlist, return_inverse=True)
+    order = np.argsort(inverse, kind="stable")          # columns grouped by k-mer, ascending within a group
+    group_start = np.zeros(int(inverse.max()) + 2, dtype=np.int64)
+    np.cumsum(np.bincount(inverse), out=group_start[1:])
+    first = order[group_start[inverse]]                 # first column of every column's k-mer
+    if vecs is not None:
+        vecs = vecs[:, first]
+    group = inverse[col]                                # entries sit in first columns only
+    rep = (group_start[group + 1] - group_start[group]).astype(np.int64)
+    idx = np.repeat(np.arange(len(col), dtype=np.int64), rep)
+    within = np.arange(len(idx), dtype=np.int64) - np.repeat(np.cumsum(rep) - rep, rep)
+    new_col = order[group_start[group[idx]] + within].astype(col.dtype)
+    grown = np.zeros(len(rowptr), dtype=np.int64)
+    np.cumsum(np.add.reduceat(np.concatenate([rep, [0]]), np.minimum(rowptr[:-1], len(rep)))
+              * (np.diff(rowptr) > 0), out=grown[1:])
+    return grown, new_col, val[idx], vecs
+
+
 def vectorize_fasta(
     path: str,
     alphabet: Union[str, int, None],
@@ -160,19 +186,21 @@ def vectorize_fasta(
     writes the ``.npz`` members uncompressed (np.load reads both; the reference compresses, rules/kmerize.smk:132).  `timings` (optional
     dict) receives parse_s / gpu_s / decode_s / write_s."""
     t0 = time.perf_counter()
-    ids, res, off = read_fasta_packed(path)
+    ids, res, off, text_records = read_fasta_packed(path, with_records=True)
     if timings is not None:
         timings["parse_s"] = timings.get("parse_s", 0.0) + time.perf_counter() - t0
-    out = vectorize_packed(ids, res, off, alphabet, k, min_filter=min_filter, basis=basis,
-                           dense=(bool(npz_out) or not sparse_npz_out) if dense is None else (dense or bool(npz_out)),
-                           timings=timings)
+    want_dense = (bool(npz_out) or not sparse_npz_out) if dense is None else (dense or bool(npz_out))
+    if text_records is not None and any(not s.isascii() and any(ord(c) > 255 for c in s) for _, s in text_records):
+        # characters above latin-1 do not fit the packed bytes: vectorize_records carries them through by position
+        out = vectorize_records(text_records, alphabet, k, min_filter=min_filter, basis=basis, dense=want_dense, timings=timings)
+    else:
+        out = vectorize_packed(ids, res, off, alphabet, k, min_filter=min_filter, basis=basis, dense=want_dense, timings=timings)
     t0 = time.perf_counter()
     if sparse_npz_out:
         save_npz_sparse(sparse_npz_out, out, compressed=compressed)
     if npz_out:
-        (np.savez_compressed if compressed else np.savez)(
-            npz_out, kmerlist=out["kmerlist"], ids=out["ids"], seqs=out["seqs"], vecs=out["vecs"], lengths=out["lengths"]
-        )
+        save_npz(npz_out, dict(kmerlist=out["kmerlist"], ids=out["ids"], seqs=out["seqs"], vecs=out["vecs"], lengths=out["lengths"]),
+                 compressed=compressed)
     if kmers_out:
         kmer = KmerVec(alphabet=alphabet, k=k)
         kmer.set_kmer_set(out["kmerlist"])

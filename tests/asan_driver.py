@@ -106,6 +106,30 @@ def check_fasta(lib):
                 assert (off == want_off).all() and (res == want_res).all()
 
 
+def check_npz(lib):
+    """The threaded .npz writer: members of every size class around the 2 MiB chunk (exactly sized inputs: an overrun is
+    a heap-buffer-overflow report), compressed and stored, read back by numpy."""
+    from snekmer_amd import io
+
+    rng = np.random.default_rng(3)
+    arrays = {"kmerlist": np.array(["ACDEFGHIKLMN", "AAAAAAAAAAAD"] * 3, dtype=str), "ids": np.array([], dtype=str),
+              "vecs": np.asfortranarray(rng.integers(0, 2, (33, 17)).astype(np.float64)), "scalar": np.float32(2.5),
+              "edge": rng.integers(0, 9, size=(1 << 21) - 128, dtype=np.uint8), "edge1": rng.integers(0, 9, size=(1 << 21) - 127, dtype=np.uint8),
+              "big": rng.integers(0, 300, size=1_300_001, dtype=np.uint32), "empty2d": np.zeros((0, 5))}
+    with tempfile.TemporaryDirectory() as tmp:
+        for compressed in (True, False):
+            for th in (1, 4):
+                path = os.path.join(tmp, f"a_{int(compressed)}_{th}.npz")
+                size = io.save_npz(path, arrays, compressed=compressed, threads=th, _lib=lib)
+                assert size == os.path.getsize(path)
+                got = np.load(path)
+                assert sorted(got.files) == sorted(arrays)
+                for key, want in arrays.items():
+                    want = np.asanyarray(want)
+                    assert got[key].dtype == want.dtype and got[key].shape == want.shape and (got[key] == want).all(), key
+        assert lib.skm_npz_write(os.path.join(tmp, "no", "such", "dir.npz").encode(), 0, None, None, None, None, None, 6, 1, None) == -1
+
+
 def main():
     import pytest
 
@@ -115,6 +139,7 @@ def main():
     lib = C.CDLL(os.environ["SKM_HOST_ASAN_LIB"])
     check_plans(lib)
     check_fasta(lib)
+    check_npz(lib)
     print("ASAN_DRIVER_OK")
     return 0
 

@@ -262,6 +262,21 @@ def main(ref_root):
         counts_col=ci,
         counts_val=cv,
     )
+    # the same branch with k-mers listed more than once (kmerize.smk:72-78 takes the lines verbatim; np.isin at :119 sets
+    # every column that carries a present k-mer, and the count loop of learn.smk:376-383 looks every column up by name)
+    dup = explicit[:40] + [explicit[0], explicit[5], "SSSSSSSSSSSSSS", explicit[0]] + explicit[40:60] + [explicit[59]]
+    out = run_rule(V, A, records, "hydro", 14, basis=dup)
+    counts = run_counts(out["seqs"], out["kmerlist"])
+    rp, ci, cv = to_csr(counts)
+    np.savez_compressed(
+        os.path.join(HERE, "g3_demo_hydro_k14_basisdup.npz"),
+        kmerlist=out["kmerlist"],
+        vecs_bits=np.packbits(out["vecs"].astype(bool), axis=1),
+        vecs_shape=np.asarray(out["vecs"].shape),
+        counts_rowptr=rp,
+        counts_col=ci,
+        counts_val=cv,
+    )
     json.dump(summary, open(os.path.join(HERE, "g3_summary.json"), "w"), indent=1, sort_keys=True)
 
     # ---- G6: KmerBasis.transform ----------------------------------------------------

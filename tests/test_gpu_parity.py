@@ -184,6 +184,14 @@ def test_vectorize_records_basis_file_branch(ctx):
     vecs = np.unpackbits(g["vecs_bits"], axis=1)[:, : g["vecs_shape"][1]]
     assert (out["vecs"] == vecs).all()
     assert list(out["kmerlist"]) == list(g["kmerlist"])
+    # a basis file that lists k-mers more than once: every one of their columns is filled (kmerize.smk:72-78,119)
+    g = gnpz("g3_demo_hydro_k14_basisdup.npz")
+    assert len(set(g["kmerlist"].tolist())) < len(g["kmerlist"])
+    out = vectorize_records(demo_records(), "hydro", 14, basis=list(g["kmerlist"]), ctx=ctx)
+    vecs = np.unpackbits(g["vecs_bits"], axis=1)[:, : g["vecs_shape"][1]]
+    assert (out["vecs"] == vecs).all() and list(out["kmerlist"]) == list(g["kmerlist"])
+    mine = csr_to_dense(out["counts_rowptr"], out["counts_col"], out["counts_val"], len(g["kmerlist"]))
+    assert (mine == csr_to_dense(g["counts_rowptr"], g["counts_col"], g["counts_val"], len(g["kmerlist"]))).all()
 
 
 def test_vectorize_fasta_writes_reference_formats(ctx, tmp_path):
@@ -212,6 +220,26 @@ def test_vectorize_fasta_writes_reference_formats(ctx, tmp_path):
     gcol = {kk: i for i, kk in enumerate(g["kmerlist"].tolist())}
     gdense = csr_to_dense(g["counts_rowptr"], g["counts_col"], g["counts_val"], len(g["kmerlist"]))
     assert (C.toarray() == gdense[:n][:, [gcol[kk] for kk in kmerlist.tolist()]]).all()
+
+
+def test_vectorize_fasta_carries_characters_above_latin1(ctx, tmp_path):
+    """reduce() passes unmapped characters through unchanged (snekmer/vectorize.py:195), whatever their code point: a
+    FASTA file with a residue above U+00FF gives the same `seqs` through vectorize_fasta as through the per-record
+    path, and the same as the oracle's restatement."""
+    from oracle import ref_path
+    from snekmer_amd.kmerize import vectorize_fasta, vectorize_records
+
+    recs = [("a", "MKVLAAGIWSTC\u03b1MKVLAAGIWSTCDE"), ("b", "MKVLAAGIW\u00c4STCMKVLAAGIWST*"), ("c", "MKVLAAGIWSTCMKVLAAGIWSTC")]
+    path = tmp_path / "wide.faa"
+    path.write_text("".join(f">{i} x\n{s}\n" for i, s in recs), encoding="utf-8")
+    a = vectorize_fasta(str(path), "hydro", 4)
+    b = vectorize_records(recs, "hydro", 4, ctx=ctx)
+    for key in ("kmerlist", "ids", "seqs", "vecs", "lengths"):
+        assert a[key].shape == b[key].shape and (a[key] == b[key]).all(), key
+    from snekmer_amd.alphabet import FULL_ALPHABETS
+
+    assert list(a["seqs"]) == [ref_path.reduce(s, FULL_ALPHABETS["hydro"]) for _, s in recs]
+    assert "\u03b1" in a["seqs"][0] and "\u00c4" in a["seqs"][1]
 
 
 # ------------------------------------------------------------------ a13 / a14 cosine

@@ -180,3 +180,45 @@ def test_reference_written_kmers_pickle_loads_through_the_module_alias():
     mine._lut()  # populate the cache: it must not reach the pickle
     state = pickle.loads(pickle.dumps(mine)).__dict__
     assert sorted(state.keys()) == g["attrs"]
+
+
+def test_threaded_npz_writer_matches_numpy_savez(tmp_path):
+    """skm_npz_write (host code) against np.savez_compressed / np.savez on the rule's members (rules/kmerize.smk:132-139):
+    the same member names, dtypes, shapes and values through np.load and through the reference-shaped io.load_npz, a valid
+    zip (CRCs checked by zipfile), and a size close to numpy's own."""
+    import zipfile
+
+    from snekmer_amd import io as sio
+
+    rng = np.random.default_rng(5)
+    n, b = 300, 4000
+    arrays = dict(
+        kmerlist=np.array(["".join(rng.choice(list("ADFKNP"), 12)) for _ in range(b)], dtype=str),
+        ids=np.array([f"seq{i}" for i in range(n)], dtype=str),
+        seqs=np.array(["".join(rng.choice(list("ADFKNPX"), int(rng.integers(0, 400)))) for _ in range(n)], dtype=str),
+        vecs=(rng.random((n, b)) < 0.03).astype(np.float64),
+        lengths=rng.integers(0, 400, size=n),
+    )
+    ref = tmp_path / "ref.npz"
+    np.savez_compressed(ref, **arrays)
+    for compressed, threads in ((True, 0), (True, 1), (True, 5), (False, 0)):
+        path = tmp_path / f"mine_{int(compressed)}_{threads}"
+        size = sio.save_npz(str(path), arrays, compressed=compressed, threads=threads)  # ".npz" is appended, as numpy does
+        path = str(path) + ".npz"
+        assert size == os.path.getsize(path)
+        with zipfile.ZipFile(path) as z:
+            assert z.testzip() is None
+            assert [i.filename for i in z.infolist()] == [k + ".npy" for k in arrays]
+            assert all(i.compress_type == (zipfile.ZIP_DEFLATED if compressed else zipfile.ZIP_STORED) for i in z.infolist())
+        got, want = np.load(path), np.load(ref)
+        for key in arrays:
+            assert got[key].dtype == want[key].dtype and got[key].shape == want[key].shape and (got[key] == want[key]).all()
+        if compressed:
+            assert size <= 1.02 * os.path.getsize(ref)
+        (kmerlist,), df = sio.load_npz(path)
+        assert list(kmerlist) == list(arrays["kmerlist"]) and list(df["sequence_id"]) == list(arrays["ids"])
+        assert (np.asarray(list(df["sequence_vector"])) == arrays["vecs"]).all()
+    with pytest.raises(TypeError):
+        sio.save_npz(str(tmp_path / "obj"), {"o": np.array([{}], dtype=object)})
+    with pytest.raises(_hip.HipError):
+        sio.save_npz(str(tmp_path / "no" / "dir" / "x.npz"), arrays)

@@ -1,6 +1,6 @@
 """CPU sanitizers: `make -C oracle asan` builds the C oracle and the product's host-only
 translation unit with -fsanitize=address,undefined; tests/asan_driver.py then runs the golden-vector tests, the
-exchange-plan checks and the FASTA reader checks on those builds in a child process with libasan preloaded.  Device
+exchange-plan checks, the FASTA reader checks and the .npz writer checks on those builds in a child process with libasan preloaded.  Device
 code cannot be sanitized on this pool; it is covered by bit-exact parity against the oracle instead."""
 import os
 import subprocess
