@@ -112,10 +112,14 @@ int skm_kmer_codes(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int cod
  * per sequence, its distinct valid codes in ascending order with multiplicities.
  * Outputs: d_rowptr[n+1]; d_codes / d_counts (/ d_firstpos, optional: index of the first window
  * carrying that code, needed for the reference's first-seen basis order) with capacity
- * cap_entries >= total residues.  *h_nnz receives the number of entries (host-synchronous). */
+ * cap_entries >= total residues.  *h_nnz receives the number of entries (host-synchronous).
+ * max_seq_len: an upper bound on the longest sequence of the batch (max of d_off[i+1] - d_off[i]; the offsets are host
+ * data wherever a batch is packed), or 0 when the caller has none.  With the bound every count kernel is launched
+ * with a worst-case grid and reads its work list on the device; without it the call also fetches the size classes
+ * of the sequences to learn whether any has more than 8192 windows (one more host wait). */
 int skm_count_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits,
                   const uint8_t *d_seq, const int64_t *d_off, int64_t n, int64_t total_residues,
-                  int64_t cap_entries, int64_t *d_rowptr, void *d_codes, uint32_t *d_counts,
+                  int64_t max_seq_len, int64_t cap_entries, int64_t *d_rowptr, void *d_codes, uint32_t *d_counts,
                   uint32_t *d_firstpos, int64_t *h_nnz);
 
 /* ---- a11: observed basis ------------------------------------------------------------------ */
@@ -157,14 +161,14 @@ int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int flags, int64_
  * sized by total_residues.  Outputs as documented for the three calls it replaces, capacity cap_entries >
  * total_residues each (d_colptr: cap_entries + 1); d_codes past the entry count is filled with the all-ones sentinel;
  * d_rnorm / d_normsq are optional.  No result is read back (read d_rowptr[n] / *d_ncols with skm_memcpy_d2h when the
- * host needs them).  ONE host wait remains per call: the 28-byte size-class histogram of the sequences (which count
- * kernels to launch for sequences of more than 512 windows) is awaited on an event recorded right behind the
- * classification kernel, after the common-case count kernel has been queued; the event is stream-ordered, so a
- * caller that queued other work on this context before the call waits for that work too.  n >= 1 and
- * total_residues >= 1. */
+ * host needs them).  With max_seq_len > 0 (see skm_count_csr) the call never waits for the device: the host may queue
+ * any number of steps ahead.  With max_seq_len == 0 one wait remains: the size-class histogram of the sequences is
+ * awaited on an event recorded behind the classification kernel, after the common-case count kernels have been
+ * queued.  n >= 1 and total_residues >= 1.  With d_basis, d_colidx, d_colptr, d_post and d_ncols ALL null the call stops after the count
+ * stage (CSR + norms, d_codes not padded): what the dense route of engine.Pipeline needs. */
 int skm_vectorize_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits, const uint8_t *d_seq,
-                      const int64_t *d_off, int64_t n, int64_t total_residues, int64_t cap_entries, int64_t *d_rowptr,
-                      void *d_codes, uint32_t *d_counts, void *d_basis, uint32_t *d_colidx, uint32_t *d_colptr,
+                      const int64_t *d_off, int64_t n, int64_t total_residues, int64_t max_seq_len, int64_t cap_entries,
+                      int64_t *d_rowptr, void *d_codes, uint32_t *d_counts, void *d_basis, uint32_t *d_colidx, uint32_t *d_colptr,
                       uint64_t *d_post, float *d_rnorm, uint64_t *d_normsq, int64_t *d_ncols);
 
 /* Column-major copy (postings) of any CSR with column ids < ncols; rows ascending per column. */
@@ -338,6 +342,19 @@ int skm_count_dense(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, const 
 int skm_cosine_dense_i8(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim, const int8_t *d_x,
                         const int8_t *d_y, const float *d_xrnorm, const float *d_yrnorm, int mode,
                         float *d_out, int64_t ld);
+
+/* The dense route for small full bases (engine.Pipeline picks it when |S|^k <= 2^17 and the rows are dense enough;
+ * the reference's CI runs solvacc k=8 = 6561 columns): the int8 operand of skm_cosine_dense_i8 straight from a CSR
+ * whose column ids are the k-mer codes (32-bit codes; d_out [n x kdim] is zero-filled first).  Counts above 127
+ * saturate and their rows are appended to d_irr_list[n] (*d_irr_count of them, any order): skm_cosine_fixup_rows then
+ * recomputes the cells of those rows AND columns of a block [row0,row1) x [0,n) of the result from the CSR itself with
+ * float64 accumulators (exact below 2^53, no upper limit), overwriting what the GEMM left there.  Neither call waits
+ * for the device; an empty list costs one launch that exits at once. */
+int skm_csr_to_dense_i8(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const uint32_t *d_codes, const uint32_t *d_counts,
+                        int64_t kdim, int8_t *d_out, uint32_t *d_irr_list, uint32_t *d_irr_count);
+int skm_cosine_fixup_rows(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const uint32_t *d_codes, const uint32_t *d_counts,
+                          const float *d_rnorm, int64_t row0, int64_t row1, const uint32_t *d_irr_list,
+                          const uint32_t *d_irr_count, int mode, float *d_out, int64_t ld);
 
 /* Sparse view of a dense count matrix, the inverse of skm_count_dense / skm_csr_to_dense: per row the
  * non-zero columns in ascending order with their values, i.e. the (code, count) rows skm_count_csr

@@ -70,7 +70,7 @@ _SIGNATURES = {
     "skm_kmer_codes": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _i64, _p, _p]),
     "skm_count_csr": (
         C.c_int,
-        [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, C.POINTER(_i64)],
+        [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, C.POINTER(_i64)],
     ),
     "skm_basis_build": (
         C.c_int,
@@ -78,7 +78,7 @@ _SIGNATURES = {
     ),
     "skm_vectorize_csr": (
         C.c_int,
-        [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+        [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     ),
     "skm_csr_transpose": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p]),
     "skm_csr_concat_rowptr": (C.c_int, [_p, C.c_int, _p, _p, _p, _p]),
@@ -113,6 +113,8 @@ _SIGNATURES = {
     "skm_apply_top2": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p]),
     "skm_fasta_index": (C.c_int, [_p, _i64, C.c_int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_int)]),
     "skm_fasta_parse": (C.c_int, [_p, _i64, C.c_int, _i64, _i64, _p, _p, _p, _p]),
+    "skm_csr_to_dense_i8": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _p]),
+    "skm_cosine_fixup_rows": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, C.c_int, _p, _i64]),
     "skm_npz_write": (C.c_int, [C.c_char_p, C.c_int, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.POINTER(_i64)]),
     "skm_rows_to_utf32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _p]),
     "skm_decode_kmers_utf32": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p, _p, _p, _i64, _p]),

@@ -350,12 +350,13 @@ extern "C" int skm_profile_dump(skm_ctx *ctx, char *h_buf, int cap, int *h_neede
 
 // ---------------------------------------------------------------------------- fused vectorize
 extern "C" int skm_vectorize_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits, const uint8_t *d_seq,
-                                 const int64_t *d_off, int64_t n, int64_t total_residues, int64_t cap_entries,
+                                 const int64_t *d_off, int64_t n, int64_t total_residues, int64_t max_seq_len, int64_t cap_entries,
                                  int64_t *d_rowptr, void *d_codes, uint32_t *d_counts, void *d_basis, uint32_t *d_colidx,
                                  uint32_t *d_colptr, uint64_t *d_post, float *d_rnorm, uint64_t *d_normsq, int64_t *d_ncols)
 {
-    SKM_REQUIRE(ctx && h_rank && d_seq && d_off && d_rowptr && d_codes && d_counts && d_basis && d_colidx && d_colptr && d_post &&
-                    d_ncols && n >= 1 && total_residues >= 1,
+    const bool counts_only = !d_basis && !d_colidx && !d_colptr && !d_post && !d_ncols;  // no basis stage
+    SKM_REQUIRE(ctx && h_rank && d_seq && d_off && d_rowptr && d_codes && d_counts &&
+                    (counts_only || (d_basis && d_colidx && d_colptr && d_post && d_ncols)) && n >= 1 && total_residues >= 1,
                 SKM_E_BADARG, "skm_vectorize_csr: bad argument (empty batches take skm_count_csr + skm_basis_build)");
     SKM_REQUIRE(code_bits == 32 || code_bits == 64, SKM_E_BADARG, "skm_vectorize_csr: code_bits must be 32 or 64");
     SKM_REQUIRE(cap_entries >= total_residues + 1, SKM_E_BADARG,
@@ -364,10 +365,13 @@ extern "C" int skm_vectorize_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, 
     SKM_REQUIRE(total_residues < ((int64_t)1 << 32) - 1 && n < ((int64_t)1 << 32) - 1, SKM_E_OVERFLOW,
                 "skm_vectorize_csr: more than 2^32 residues or sequences in one batch; split the batch");
     SKM_HIP(hipSetDevice(ctx->device));
+    if (counts_only)
+        return skm_count_stage_async(ctx, h_rank, nsym, k, code_bits, d_seq, d_off, n, total_residues, max_seq_len, d_rowptr, d_codes, d_counts,
+                                     nullptr, d_rnorm, d_normsq);
     void *p;
     SKM_TRY(skm_ws(ctx, WS_K, sizeof(uint64_t) * (size_t)(total_residues + 1), &p));
     uint64_t *rowcount = (uint64_t *)p;
-    SKM_TRY(skm_count_stage_async(ctx, h_rank, nsym, k, code_bits, d_seq, d_off, n, total_residues, d_rowptr, d_codes, d_counts,
+    SKM_TRY(skm_count_stage_async(ctx, h_rank, nsym, k, code_bits, d_seq, d_off, n, total_residues, max_seq_len, d_rowptr, d_codes, d_counts,
                                   rowcount, d_rnorm, d_normsq));
     int key_bits = 0;
     {

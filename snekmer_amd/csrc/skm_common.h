@@ -102,7 +102,7 @@ static inline int skm_grid_cap(const skm_ctx *ctx, int64_t want, int per_cu = 8)
 // Stage functions shared by the fused entry point skm_vectorize_csr (skm_api.hip would be the natural home; they
 // live with their kernels in skm_kmer.hip / skm_basis.hip).  Neither waits for the device.
 int skm_count_stage_async(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits, const uint8_t *d_seq,
-                          const int64_t *d_off, int64_t n, int64_t total_residues, int64_t *d_rowptr, void *d_codes,
+                          const int64_t *d_off, int64_t n, int64_t total_residues, int64_t max_seq_len, int64_t *d_rowptr, void *d_codes,
                           uint32_t *d_counts, uint64_t *d_rowcount, float *d_rnorm, uint64_t *d_normsq);
 int skm_basis_stage_async(skm_ctx *ctx, int code_bits, int key_bits, int64_t cap, const int64_t *d_nnz, const void *d_codes,
                           const uint64_t *d_rowcount, void *d_basis, uint32_t *d_colidx, uint32_t *d_colptr, uint64_t *d_post,

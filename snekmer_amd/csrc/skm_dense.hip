@@ -1070,3 +1070,148 @@ extern "C" int skm_row_norms_i8(skm_ctx *ctx, int64_t n, int64_t kdim, const int
     k_row_norms_i8<<<skm_grid_cap(ctx, skm_ceil_div(n, 4), 16), 256, 0, ctx->stream>>>(n, kdim, d_in, d_rnorm, d_normsq);
     return skm_check_launch("k_row_norms_i8");
 }
+
+// ------------------------------------------------------------------------------- dense route of engine.Pipeline
+// Small full bases (|S|^k <= 2^17: the reference's own CI configuration, solvacc k=8 = 6561 columns) are dense enough
+// for the cosine to be a true GEMM.  The count stage's CSR (column id == k-mer code) becomes the int8 operand of the MFMA
+// kernel; a count above 127 saturates there, its row is listed as IRREGULAR, and k_cosine_fixup_rows recomputes that
+// row's cells (and, by symmetry, its column) from the CSR itself with float64 accumulators - so the route is exact for
+// any input and nothing is decided on the host.  Regular rows need no range test: 127^2 * kdim < 2^31 for kdim <= 133 143.
+namespace {
+
+__global__ __launch_bounds__(256) void k_csr_to_dense_i8_flag(int64_t n, const int64_t *__restrict__ rowptr,
+                                                              const uint32_t *__restrict__ codes,
+                                                              const uint32_t *__restrict__ counts, int64_t kdim,
+                                                              int8_t *__restrict__ out, uint32_t *__restrict__ irr_list,
+                                                              uint32_t *__restrict__ irr_count)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const int64_t b = rowptr[i], e = rowptr[i + 1];
+        bool big = false;
+        for (int64_t t = b + lane; t < e; t += 64) {
+            const uint32_t v = counts[t];
+            big |= v > 127u;
+            out[i * kdim + codes[t]] = (int8_t)(v > 127u ? 127u : v);
+        }
+        if (__any(big) && lane == 0)
+            irr_list[atomicAdd(irr_count, 1u)] = (uint32_t)i;
+    }
+}
+
+// Exact cells of the irregular rows.  Work item = (irregular row i, 256 consecutive rows j); row i's (code, count) list
+// goes through LDS in sorted tiles of FX_TILE entries; thread j walks its own row's entries once (they are sorted too)
+// and looks each one up in the tile with a binary search.  out[i][j] for i in [row0, row1), out[j][i] for j in [row0, row1).
+constexpr int FX_TILE = 2048;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cosine_fixup_rows(int64_t n, const int64_t *__restrict__ rowptr,
+                                                           const uint32_t *__restrict__ codes,
+                                                           const uint32_t *__restrict__ counts,
+                                                           const float *__restrict__ rnorm, int64_t row0, int64_t row1,
+                                                           const uint32_t *__restrict__ irr_list,
+                                                           const uint32_t *__restrict__ irr_count, float *__restrict__ out,
+                                                           int64_t ld)
+{
+    __shared__ uint32_t s_code[FX_TILE], s_val[FX_TILE];
+    const int tid = threadIdx.x;
+    const int64_t nchunks = (n + 255) / 256;
+    const int64_t items = (int64_t)*irr_count * nchunks;
+    for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const int64_t i = irr_list[item / nchunks];
+        const int64_t j = (item % nchunks) * 256 + tid;
+        const int64_t ib = rowptr[i], ie = rowptr[i + 1];
+        int64_t pj = 0, ej = 0;
+        uint32_t cj = 0xFFFFFFFFu;
+        if (j < n) {
+            pj = rowptr[j];
+            ej = rowptr[j + 1];
+            if (pj < ej)
+                cj = codes[pj];
+        }
+        double acc = 0.0;
+        for (int64_t t0 = ib; t0 < ie; t0 += FX_TILE) {
+            const int cnt = (int)min((int64_t)FX_TILE, ie - t0);
+            __syncthreads();
+            for (int z = tid; z < cnt; z += 256) {
+                s_code[z] = codes[t0 + z];
+                s_val[z] = counts[t0 + z];
+            }
+            __syncthreads();
+            const uint32_t tile_max = s_code[cnt - 1];
+            while (pj < ej && cj <= tile_max) {
+                int lo = 0, hi = cnt - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_code[mid] < cj)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                if (s_code[lo] == cj)
+                    acc += (double)s_val[lo] * (double)counts[pj];
+                ++pj;
+                cj = pj < ej ? codes[pj] : 0xFFFFFFFFu;
+            }
+        }
+        if (j < n) {
+            float o = (float)(acc * (double)rnorm[i] * (double)rnorm[j]);
+            if (MODE == 1) {
+                o = fminf(fmaxf(1.0f - o, 0.0f), 2.0f);
+                if (i == j)
+                    o = 0.0f;
+            }
+            if (i >= row0 && i < row1)
+                out[(i - row0) * ld + j] = o;
+            if (j >= row0 && j < row1)
+                out[(j - row0) * ld + i] = o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int skm_csr_to_dense_i8(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const uint32_t *d_codes,
+                                   const uint32_t *d_counts, int64_t kdim, int8_t *d_out, uint32_t *d_irr_list,
+                                   uint32_t *d_irr_count)
+{
+    SKM_REQUIRE(ctx && n >= 0 && kdim >= 0 && kdim % 64 == 0, SKM_E_BADARG, "skm_csr_to_dense_i8: bad argument (kdim must be a multiple of 64)");
+    SKM_REQUIRE(d_irr_count, SKM_E_BADARG, "skm_csr_to_dense_i8: null counter");
+    SKM_HIP(hipSetDevice(ctx->device));
+    SKM_HIP(hipMemsetAsync(d_irr_count, 0, sizeof(uint32_t), ctx->stream));
+    if (n == 0 || kdim == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_rowptr && d_codes && d_counts && d_out && d_irr_list, SKM_E_BADARG, "skm_csr_to_dense_i8: null array");
+    {
+        SKM_PROF(ctx, "memset_dense_i8");
+        SKM_HIP(hipMemsetAsync(d_out, 0, (size_t)n * (size_t)kdim, ctx->stream));
+    }
+    SKM_PROF(ctx, "k_csr_to_dense_i8");
+    k_csr_to_dense_i8_flag<<<skm_grid_cap(ctx, skm_ceil_div(n, 4), 16), 256, 0, ctx->stream>>>(n, d_rowptr, d_codes, d_counts, kdim,
+                                                                                             d_out, d_irr_list, d_irr_count);
+    return skm_check_launch("k_csr_to_dense_i8");
+}
+
+extern "C" int skm_cosine_fixup_rows(skm_ctx *ctx, int64_t n, const int64_t *d_rowptr, const uint32_t *d_codes,
+                                     const uint32_t *d_counts, const float *d_rnorm, int64_t row0, int64_t row1,
+                                     const uint32_t *d_irr_list, const uint32_t *d_irr_count, int mode, float *d_out, int64_t ld)
+{
+    SKM_REQUIRE(ctx && n >= 0 && row0 >= 0 && row0 <= row1 && row1 <= n && ld >= n && (mode == 0 || mode == 1), SKM_E_BADARG,
+                "skm_cosine_fixup_rows: bad argument");
+    if (n == 0 || row0 == row1)
+        return SKM_OK;
+    SKM_REQUIRE(d_rowptr && d_codes && d_counts && d_rnorm && d_irr_list && d_irr_count && d_out, SKM_E_BADARG,
+                "skm_cosine_fixup_rows: null array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    SKM_PROF(ctx, "k_cosine_fixup_rows");
+    const int grid = skm_grid_cap(ctx, n, 4);  // strides over (irregular rows) x (chunks of 256 rows); empty list: exits at once
+    if (mode == 0)
+        k_cosine_fixup_rows<0><<<grid, 256, 0, ctx->stream>>>(n, d_rowptr, d_codes, d_counts, d_rnorm, row0, row1, d_irr_list,
+                                                               d_irr_count, d_out, ld);
+    else
+        k_cosine_fixup_rows<1><<<grid, 256, 0, ctx->stream>>>(n, d_rowptr, d_codes, d_counts, d_rnorm, row0, row1, d_irr_list,
+                                                               d_irr_count, d_out, ld);
+    return skm_check_launch("k_cosine_fixup_rows");
+}

@@ -21,9 +21,9 @@
 
 namespace {
 
-constexpr int SHORT_MAX = 512;    // windows handled by the register sort (8 per lane)
-constexpr int BLOCK_LDS_MAX = 8192;  // windows handled with keys in LDS
-constexpr int NBUCKET = 7;        // 0: no windows, 1: short, 2..5: LDS cap 1024..8192, 6: global
+constexpr int SHORT_MAX = 512;    // windows handled by one wave's register sort (8 per lane)
+constexpr int LONGSEQ_MAX = 8192;    // windows handled by one workgroup: 16 waves' register sorts merged through LDS
+constexpr int NBUCKET = 7;        // 0: no windows, 1: short, 2: long (513..8192), 6: keys in global scratch; 3-5 unused
 constexpr int BLK = 256;
 
 template <typename K>
@@ -85,16 +85,12 @@ __global__ void k_classify(const uint8_t *__restrict__ seq, const int64_t *__res
             row_nnz[i] = 0;
         } else if (w <= SHORT_MAX)
             bucket = 1;
-        else if (w <= 1024)
+        else if (w <= LONGSEQ_MAX)
             bucket = 2;
-        else if (w <= 2048)
-            bucket = 3;
-        else if (w <= 4096)
-            bucket = 4;
-        else if (w <= BLOCK_LDS_MAX)
-            bucket = 5;
         else
             bucket = 6;
+        if (i == 0)
+            row_nnz[n] = 0;  // the closing element of the scan over row_nnz
         // one atomic per (wave, bucket) instead of one per sequence
         const int lane = threadIdx.x & 63;
         uint32_t slot = 0;
@@ -294,6 +290,201 @@ __global__ __launch_bounds__(64) void k_count_short(skm_lut256 lut, int nsym, in
     }
 }
 
+// ------------------------------------------------------------------------------- long sequences (513..8192 windows)
+// One workgroup of 16 waves per sequence.  The keys stay in registers in the GLOBAL blocked layout (element e =
+// wave*512 + lane*8 + r): every wave sorts its 512 with the register network of the short kernel, then the sorted runs
+// are merged pairwise (bitonic merges in flip form); only the stages whose partner sits in another wave go through LDS
+// (10 exchanges for 8192 keys), the rest are the same DPP / shuffle stages.  A real proteome has 15-25 % of its
+// sequences here; the kernel this replaces kept the keys in LDS and ran all 55-91 stages of a bitonic sort there with
+// 256 threads: 20 / 40 / 80 us for ONE sequence of 1024 / 2048 / 4096 windows, a launch per size class (the host had
+// to learn the class sizes first), 0.16 ms for the reference's CI proteome.  This one reads its list length on the device.
+template <typename K>
+__device__ __forceinline__ void lds_exchange(K (&v)[8], K *s_x, int e0, int partner_base, bool flip, bool lower)
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        s_x[e0 + r] = v[r];
+    __syncthreads();
+    K o[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        o[r] = s_x[partner_base + (flip ? 7 - r : r)];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const K mn = v[r] < o[r] ? v[r] : o[r], mx = v[r] < o[r] ? o[r] : v[r];
+        v[r] = lower ? mn : mx;
+    }
+}
+
+constexpr int LONG_TB = 1024;
+template <typename K, bool WITH_POS>
+constexpr size_t count_long_lds()
+{
+    return (size_t)LONGSEQ_MAX * sizeof(K) + sizeof(uint32_t) * (LONGSEQ_MAX + 1) + (WITH_POS ? sizeof(uint32_t) * LONGSEQ_MAX : 0) +
+           (size_t)LONGSEQ_MAX + 64 + 16;
+}
+
+template <typename K, bool WITH_POS>
+__global__ __launch_bounds__(LONG_TB) void k_count_long(skm_lut256 lut, int nsym, int k, const uint8_t *__restrict__ seq,
+                                                        const int64_t *__restrict__ off, const int32_t *__restrict__ slen,
+                                                        const uint32_t *__restrict__ list,
+                                                        const uint32_t *__restrict__ nlist_ptr, K *__restrict__ tmp_codes,
+                                                        uint32_t *__restrict__ tmp_counts, uint32_t *__restrict__ tmp_first,
+                                                        int32_t *__restrict__ row_nnz)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    __shared__ uint8_t s_lut[256];
+    __shared__ K s_last[LONG_TB / 64];
+    __shared__ uint32_t s_wtot[LONG_TB / 64];
+    K *s_x = reinterpret_cast<K *>(s_dyn);  // exchange buffer of the merges, then the distinct keys
+    uint32_t *s_start = reinterpret_cast<uint32_t *>(s_x + LONGSEQ_MAX);
+    uint32_t *s_pos = s_start + LONGSEQ_MAX + 1;
+    uint8_t *s_rank = reinterpret_cast<uint8_t *>(s_pos + (WITH_POS ? LONGSEQ_MAX : 0));
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const K SENT = sentinel<K>();
+    const uint32_t nlist = *nlist_ptr;
+    if (tid < 64)
+        reinterpret_cast<uint32_t *>(s_lut)[tid] = reinterpret_cast<const uint32_t *>(lut.b)[tid];
+    K msd = 1;
+    for (int j = 1; j < k; ++j)
+        msd *= (K)nsym;
+    const int e0 = tid * 8;  // first of this thread's 8 consecutive elements (= windows, before the sort)
+
+    for (uint32_t it = blockIdx.x; it < nlist; it += gridDim.x) {
+        const uint32_t i = list[it];
+        const int64_t b = off[i];
+        const int len = slen[i];
+        const int w = len - k + 1;
+        __syncthreads();
+        for (int p = tid; p < len; p += LONG_TB)
+            s_rank[p] = s_lut[seq[b + p]];
+        __syncthreads();
+
+        K v[8];
+        K orig[WITH_POS ? 8 : 1];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            v[r] = SENT;
+        if (e0 < w) {
+            K c = 0;
+            int bad = 0;
+            for (int j = 0; j < k; ++j) {
+                const uint32_t x = s_rank[e0 + j];
+                bad += x == 0xFFu;
+                c = c * (K)nsym + (K)(x == 0xFFu ? 0u : x);
+            }
+            v[0] = bad ? SENT : c;
+#pragma unroll
+            for (int r = 1; r < 8; ++r) {
+                if (e0 + r < w) {  // (the short kernel reads stale ranks past the end; here the buffer is exactly sized)
+                    const uint32_t out = s_rank[e0 + r - 1], in = s_rank[e0 + r - 1 + k];
+                    bad += (int)(in == 0xFFu) - (int)(out == 0xFFu);
+                    c = (c - (K)(out == 0xFFu ? 0u : out) * msd) * (K)nsym + (K)(in == 0xFFu ? 0u : in);
+                    if (bad == 0)
+                        v[r] = c;
+                }
+            }
+        }
+        if constexpr (WITH_POS) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                orig[r] = v[r];
+        }
+        wave_bitonic_512_blocked<K>(v, lane);
+        // merges of sorted runs: sizes 1024, 2048, ... up to the power of two that holds the sequence (uniform)
+        for (int S = 2 * SHORT_MAX; (S >> 1) < w; S <<= 1) {
+            lds_exchange<K>(v, s_x, e0, (e0 ^ (S - 1)) & ~7, true, (e0 & (S >> 1)) == 0);
+            for (int stride = S >> 2; stride >= SHORT_MAX; stride >>= 1)
+                lds_exchange<K>(v, s_x, e0, e0 ^ stride, false, (e0 & stride) == 0);
+            wave_stage<32, false>(v, lane);
+            wave_stage<16, false>(v, lane);
+            wave_stage<8, false>(v, lane);
+            wave_stage<4, false>(v, lane);
+            wave_stage<2, false>(v, lane);
+            wave_stage<1, false>(v, lane);
+            reg_tail(v);
+        }
+        // run heads over the whole workgroup
+        if (lane == 63)
+            s_last[wid] = v[7];
+        __syncthreads();
+        K prev = shfl_idx_k<K>(v[7], (lane + 63) & 63);
+        if (lane == 0 && wid > 0)
+            prev = s_last[wid - 1];
+        uint32_t hm = 0, nval = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const bool valid = v[r] != SENT;
+            const bool head = valid && ((r == 0 && tid == 0) || v[r] != prev);
+            hm |= head ? (1u << r) : 0u;
+            nval += valid ? 1u : 0u;
+            prev = v[r];
+        }
+        const uint32_t mine = (uint32_t)__popc(hm) | (nval << 16);  // at most 8192 each: 16 bits hold them
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o)
+                incl += up;
+        }
+        if (lane == 63)
+            s_wtot[wid] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < LONG_TB / 64; ++q) {
+            const uint32_t t = s_wtot[q];
+            before += q < wid ? t : 0u;
+            total += t;
+        }
+        const int nruns = (int)(total & 0xFFFFu), nvalid = (int)(total >> 16);
+        const uint32_t base = (before + incl - mine) & 0xFFFFu;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if ((hm >> r) & 1u) {
+                const uint32_t idx = base + (uint32_t)__popc(hm & ((1u << r) - 1u));
+                s_x[idx] = v[r];
+                s_start[idx] = (uint32_t)(e0 + r);
+            }
+        }
+        if (tid == 0) {
+            s_start[nruns] = (uint32_t)nvalid;
+            row_nnz[i] = nruns;
+        }
+        if constexpr (WITH_POS) {
+            for (int t = tid; t < nruns; t += LONG_TB)
+                s_pos[t] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        for (int t = tid; t < nruns; t += LONG_TB) {
+            tmp_codes[b + t] = s_x[t];
+            tmp_counts[b + t] = s_start[t + 1] - s_start[t];
+        }
+        if constexpr (WITH_POS) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const K c = orig[r];
+                if (c != SENT) {
+                    int lo = 0, hi = nruns - 1;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_x[mid] < c)
+                            lo = mid + 1;
+                        else
+                            hi = mid;
+                    }
+                    atomicMin(&s_pos[lo], (uint32_t)(e0 + r));
+                }
+            }
+            __syncthreads();
+            for (int t = tid; t < nruns; t += LONG_TB)
+                tmp_first[b + t] = s_pos[t];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- block variant
 // Workgroup per sequence; keys / run heads / first positions live in LDS (GLOBAL=false, cap <=
 // 8192) or in a per-workgroup slice of global scratch (GLOBAL=true, any length).
@@ -302,8 +493,9 @@ __global__ __launch_bounds__(BLK) void k_count_block(skm_lut256 lut, int nsym, i
                                                      const uint8_t *__restrict__ seq,
                                                      const int64_t *__restrict__ off,
                                                      const int32_t *__restrict__ slen,
-                                                     const uint32_t *__restrict__ list, uint32_t nlist,
-                                                     uint32_t cap_lds, const int64_t *__restrict__ g_base,
+                                                     const uint32_t *__restrict__ list, uint32_t nlist_host,
+                                                     const uint32_t *__restrict__ nlist_ptr, uint32_t cap_lds,
+                                                     const int64_t *__restrict__ g_base, int64_t slice_bytes,
                                                      uint8_t *__restrict__ g_scratch,
                                                      K *__restrict__ tmp_codes, uint32_t *__restrict__ tmp_counts,
                                                      uint32_t *__restrict__ tmp_first, int32_t *__restrict__ row_nnz)
@@ -317,6 +509,9 @@ __global__ __launch_bounds__(BLK) void k_count_block(skm_lut256 lut, int nsym, i
     const K SENT = sentinel<K>();
     if (tid < 64)
         reinterpret_cast<uint32_t *>(s_lut)[tid] = reinterpret_cast<const uint32_t *>(lut.b)[tid];
+    // nlist_ptr: the list length lives on the device (no host wait); every workgroup then owns ONE scratch slice of
+    // slice_bytes (sized by the caller's bound on the longest sequence) instead of a slice per sequence
+    const uint32_t nlist = nlist_ptr ? *nlist_ptr : nlist_host;
 
     for (uint32_t it = blockIdx.x; it < nlist; it += gridDim.x) {
         const uint32_t i = list[it];
@@ -331,7 +526,7 @@ __global__ __launch_bounds__(BLK) void k_count_block(skm_lut256 lut, int nsym, i
             cap = 1;
             while (cap < w)
                 cap <<= 1;
-            uint8_t *base = g_scratch + g_base[it];
+            uint8_t *base = g_scratch + (slice_bytes ? (int64_t)blockIdx.x * slice_bytes : g_base[it]);
             keys = reinterpret_cast<K *>(base);
             heads = reinterpret_cast<uint32_t *>(base + (size_t)cap * sizeof(K));
             pos = heads + cap + 1;
@@ -539,7 +734,7 @@ int check_code_space(int nsym, int k, int code_bits)
 // entry count from d_rowptr[n] on the device); d_rowcount / d_rnorm / d_normsq: by-products of the compaction pass.
 template <typename K, bool WITH_POS>
 int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const uint8_t *d_seq,
-                   const int64_t *d_off, int64_t n, int64_t total_residues, int64_t *d_rowptr, K *d_codes,
+                   const int64_t *d_off, int64_t n, int64_t total_residues, int64_t max_seq_len, int64_t *d_rowptr, K *d_codes,
                    uint32_t *d_counts, uint32_t *d_firstpos, int64_t *h_nnz, uint64_t *d_rowcount = nullptr,
                    float *d_rnorm = nullptr, uint64_t *d_normsq = nullptr)
 {
@@ -564,21 +759,25 @@ int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const u
     }
 
     SKM_HIP(hipMemsetAsync(fill, 0, sizeof(uint32_t) * NBUCKET, st));
-    SKM_HIP(hipMemsetAsync(row_nnz + n, 0, sizeof(int32_t), st));
     {
         SKM_PROF(ctx, "k_classify");
         k_classify<<<(unsigned)skm_ceil_div(n, 256), 256, 0, st>>>(d_seq, d_off, n, k, slen, nullptr, lists, fill,
                                                                      row_nnz);
     }
     SKM_TRY(skm_check_launch("k_classify"));
-    // The size-class counts travel to the host asynchronously; the short-sequence kernel (nearly all of the work) is
-    // launched at once with a worst-case grid and reads its list length on the device, so the host's wait for the
-    // counts overlaps with it instead of idling the GPU.
+    // Every count kernel reads its list length on the device and is launched with a grid that covers the worst case,
+    // so nothing here waits for the size-class histogram - provided the caller bounds the longest sequence
+    // (max_seq_len > 0: the packed batch's offsets are host data at every call site of the Python layer).  Without the
+    // bound the histogram is fetched (asynchronously, awaited behind the two common-case kernels) to learn whether, and
+    // for which sequences, the global-scratch kernel is needed.
+    const bool bounded = max_seq_len > 0;
     uint32_t *h_fill = (uint32_t *)ctx->h_pinned;
-    SKM_HIP(hipMemcpyAsync(h_fill, fill, sizeof(uint32_t) * NBUCKET, hipMemcpyDeviceToHost, st));
-    if (!ctx->ev_host)
-        SKM_HIP(hipEventCreateWithFlags(&ctx->ev_host, hipEventDisableTiming));
-    SKM_HIP(hipEventRecord(ctx->ev_host, st));
+    if (!bounded) {
+        SKM_HIP(hipMemcpyAsync(h_fill, fill, sizeof(uint32_t) * NBUCKET, hipMemcpyDeviceToHost, st));
+        if (!ctx->ev_host)
+            SKM_HIP(hipEventCreateWithFlags(&ctx->ev_host, hipEventDisableTiming));
+        SKM_HIP(hipEventRecord(ctx->ev_host, st));
+    }
     {
         SKM_PROF(ctx, "k_count_short");
         int grid = skm_grid_cap(ctx, n, 64);
@@ -586,52 +785,64 @@ int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const u
                                                          tmp_codes, tmp_counts, tmp_first, row_nnz);
         SKM_TRY(skm_check_launch("k_count_short"));
     }
-    SKM_HIP(hipEventSynchronize(ctx->ev_host));
-    for (int bk = 2; bk <= 5; ++bk) {
-        if (!h_fill[bk])
-            continue;
-        uint32_t cap = 512u << (bk - 1);
-        size_t lds = (size_t)cap * sizeof(K) + sizeof(uint32_t) * (cap + 1) + (WITH_POS ? sizeof(uint32_t) * cap : 0) +
-                     (size_t)cap + 64 + 16;
-        SKM_PROF(ctx, "k_count_block_lds");
-        auto kern = k_count_block<K, WITH_POS, false>;
+    if (!bounded || max_seq_len - k + 1 > SHORT_MAX) {
+        // 513..8192 windows: one workgroup of 16 waves per sequence, persistent grid (one workgroup per CU: ~100-137 KB of LDS)
+        SKM_PROF(ctx, "k_count_long");
+        auto kern = k_count_long<K, WITH_POS>;
+        constexpr size_t lds = count_long_lds<K, WITH_POS>();
         SKM_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        int grid = skm_grid_cap(ctx, h_fill[bk], 4);
-        kern<<<grid, BLK, lds, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + (int64_t)bk * n, h_fill[bk], cap, nullptr,
-                                     nullptr, tmp_codes, tmp_counts, tmp_first, row_nnz);
-        SKM_TRY(skm_check_launch("k_count_block_lds"));
+        kern<<<skm_grid_cap(ctx, n, 1), LONG_TB, lds, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + (int64_t)2 * n, fill + 2,
+                                                             tmp_codes, tmp_counts, tmp_first, row_nnz);
+        SKM_TRY(skm_check_launch("k_count_long"));
     }
-    if (h_fill[6]) {
-        // Rare path (sequences with > 8192 windows): keys in global scratch, one workgroup each.
-        uint32_t nl = h_fill[6];
-        std::vector<uint32_t> ids(nl);
-        SKM_HIP(hipMemcpyAsync(ids.data(), lists + 6 * n, sizeof(uint32_t) * nl, hipMemcpyDeviceToHost, st));
-        SKM_HIP(hipStreamSynchronize(st));
-        std::vector<int32_t> lens(nl);
-        for (uint32_t q = 0; q < nl; ++q)
-            SKM_HIP(hipMemcpyAsync(&lens[q], slen + ids[q], sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        SKM_HIP(hipStreamSynchronize(st));
-        std::vector<int64_t> base(nl);
-        size_t tot = 0;
-        for (uint32_t q = 0; q < nl; ++q) {
-            uint64_t w = (uint64_t)(lens[q] - k + 1), cap = 1;
-            while (cap < w)
-                cap <<= 1;
-            base[q] = (int64_t)tot;
-            tot += cap * sizeof(K) + sizeof(uint32_t) * (2 * cap + 2);
-            tot = (tot + 255) & ~(size_t)255;
-        }
-        SKM_TRY(skm_ws(ctx, WS_G, tot, &p));
-        uint8_t *scratch = (uint8_t *)p;
-        SKM_TRY(skm_ws(ctx, WS_H, sizeof(int64_t) * nl, &p));
-        int64_t *d_base = (int64_t *)p;
-        SKM_HIP(hipMemcpyAsync(d_base, base.data(), sizeof(int64_t) * nl, hipMemcpyHostToDevice, st));
-        SKM_HIP(hipStreamSynchronize(st));
+    if (bounded && max_seq_len - k + 1 > LONGSEQ_MAX) {
+        // more than 8192 windows (rare): keys in global scratch, one slice per workgroup sized by the caller's bound
+        uint64_t w = (uint64_t)(max_seq_len - k + 1), cap = 1;
+        while (cap < w)
+            cap <<= 1;
+        size_t slice = cap * sizeof(K) + sizeof(uint32_t) * (2 * cap + 2);
+        slice = (slice + 255) & ~(size_t)255;
+        const int grid = skm_grid_cap(ctx, n, 1);
+        SKM_TRY(skm_ws(ctx, WS_G, slice * (size_t)grid, &p));
         SKM_PROF(ctx, "k_count_block_global");
-        k_count_block<K, WITH_POS, true><<<nl, BLK, 16, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + 6 * n, nl, 0,
-                                                               d_base, scratch, tmp_codes, tmp_counts, tmp_first,
-                                                               row_nnz);
+        k_count_block<K, WITH_POS, true><<<grid, BLK, 16, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + 6 * n, 0, fill + 6, 0,
+                                                                 nullptr, (int64_t)slice, (uint8_t *)p, tmp_codes, tmp_counts,
+                                                                 tmp_first, row_nnz);
         SKM_TRY(skm_check_launch("k_count_block_global"));
+    }
+    if (!bounded) {
+        SKM_HIP(hipEventSynchronize(ctx->ev_host));
+        if (h_fill[6]) {
+            // Sequences with > 8192 windows and no bound from the caller: size a scratch slice per sequence on the host.
+            uint32_t nl = h_fill[6];
+            std::vector<uint32_t> ids(nl);
+            SKM_HIP(hipMemcpyAsync(ids.data(), lists + 6 * n, sizeof(uint32_t) * nl, hipMemcpyDeviceToHost, st));
+            SKM_HIP(hipStreamSynchronize(st));
+            std::vector<int32_t> lens(nl);
+            for (uint32_t q = 0; q < nl; ++q)
+                SKM_HIP(hipMemcpyAsync(&lens[q], slen + ids[q], sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            SKM_HIP(hipStreamSynchronize(st));
+            std::vector<int64_t> base(nl);
+            size_t tot = 0;
+            for (uint32_t q = 0; q < nl; ++q) {
+                uint64_t w = (uint64_t)(lens[q] - k + 1), cap = 1;
+                while (cap < w)
+                    cap <<= 1;
+                base[q] = (int64_t)tot;
+                tot += cap * sizeof(K) + sizeof(uint32_t) * (2 * cap + 2);
+                tot = (tot + 255) & ~(size_t)255;
+            }
+            SKM_TRY(skm_ws(ctx, WS_G, tot, &p));
+            uint8_t *scratch = (uint8_t *)p;
+            SKM_TRY(skm_ws(ctx, WS_H, sizeof(int64_t) * nl, &p));
+            int64_t *d_base = (int64_t *)p;
+            SKM_HIP(hipMemcpyAsync(d_base, base.data(), sizeof(int64_t) * nl, hipMemcpyHostToDevice, st));
+            SKM_HIP(hipStreamSynchronize(st));
+            SKM_PROF(ctx, "k_count_block_global");
+            k_count_block<K, WITH_POS, true><<<nl, BLK, 16, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + 6 * n, nl, nullptr, 0,
+                                                                   d_base, 0, scratch, tmp_codes, tmp_counts, tmp_first, row_nnz);
+            SKM_TRY(skm_check_launch("k_count_block_global"));
+        }
     }
 
     // rowptr = exclusive scan of row_nnz (n+1 entries, the last one zero)
@@ -725,7 +936,7 @@ extern "C" int skm_kmer_codes(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int
 
 extern "C" int skm_count_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits,
                              const uint8_t *d_seq, const int64_t *d_off, int64_t n, int64_t total_residues,
-                             int64_t cap_entries, int64_t *d_rowptr, void *d_codes, uint32_t *d_counts,
+                             int64_t max_seq_len, int64_t cap_entries, int64_t *d_rowptr, void *d_codes, uint32_t *d_counts,
                              uint32_t *d_firstpos, int64_t *h_nnz)
 {
     SKM_REQUIRE(ctx && d_off && d_rowptr && d_codes && d_counts && h_nnz && n >= 0, SKM_E_BADARG,
@@ -746,15 +957,15 @@ extern "C" int skm_count_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int 
     }
     if (code_bits == 32) {
         if (d_firstpos)
-            return count_csr_impl<uint32_t, true>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, d_rowptr,
+            return count_csr_impl<uint32_t, true>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, max_seq_len, d_rowptr,
                                                   (uint32_t *)d_codes, d_counts, d_firstpos, h_nnz);
-        return count_csr_impl<uint32_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, d_rowptr,
+        return count_csr_impl<uint32_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, max_seq_len, d_rowptr,
                                                (uint32_t *)d_codes, d_counts, nullptr, h_nnz);
     }
     if (d_firstpos)
-        return count_csr_impl<uint64_t, true>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, d_rowptr,
+        return count_csr_impl<uint64_t, true>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, max_seq_len, d_rowptr,
                                               (uint64_t *)d_codes, d_counts, d_firstpos, h_nnz);
-    return count_csr_impl<uint64_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, d_rowptr,
+    return count_csr_impl<uint64_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, max_seq_len, d_rowptr,
                                            (uint64_t *)d_codes, d_counts, nullptr, h_nnz);
 }
 
@@ -762,16 +973,17 @@ extern "C" int skm_count_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int 
 // pre-filled with the sentinel so that everything past the (device-side) entry count sorts last, and the
 // compaction pass also emits the posting words and the row norms.
 int skm_count_stage_async(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits, const uint8_t *d_seq,
-                          const int64_t *d_off, int64_t n, int64_t total_residues, int64_t *d_rowptr, void *d_codes,
+                          const int64_t *d_off, int64_t n, int64_t total_residues, int64_t max_seq_len, int64_t *d_rowptr, void *d_codes,
                           uint32_t *d_counts, uint64_t *d_rowcount, float *d_rnorm, uint64_t *d_normsq)
 {
     skm_lut256 lut;
     SKM_TRY(make_lut(h_rank, &lut));
     SKM_TRY(check_code_space(nsym, k, code_bits));
-    SKM_HIP(hipMemsetAsync(d_codes, 0xFF, (size_t)(code_bits / 8) * (size_t)(total_residues + 1), ctx->stream));
+    if (d_rowcount)  // the sentinel tail is for the basis stage's sort; a counts-only call has none
+        SKM_HIP(hipMemsetAsync(d_codes, 0xFF, (size_t)(code_bits / 8) * (size_t)(total_residues + 1), ctx->stream));
     if (code_bits == 32)
-        return count_csr_impl<uint32_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, d_rowptr, (uint32_t *)d_codes,
+        return count_csr_impl<uint32_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, max_seq_len, d_rowptr, (uint32_t *)d_codes,
                                                d_counts, nullptr, nullptr, d_rowcount, d_rnorm, d_normsq);
-    return count_csr_impl<uint64_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, d_rowptr, (uint64_t *)d_codes,
+    return count_csr_impl<uint64_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, max_seq_len, d_rowptr, (uint64_t *)d_codes,
                                            d_counts, nullptr, nullptr, d_rowcount, d_rnorm, d_normsq);
 }

@@ -50,6 +50,8 @@ class SeqBatch:
         self.n = int(offsets.size - 1)
         self.total = int(residues.size)
         self.h_offsets = offsets
+        # bound on the longest sequence: lets the count stage size every launch without asking the device (skm_count_csr)
+        self.max_len = int(np.diff(offsets).max()) if self.n else 0
         # 64 spare bytes keep 16-byte vector loads of the tail in bounds
         self.d_seq = ctx.zeros(self.total + 64, np.uint8)
         if self.total:
@@ -239,7 +241,7 @@ def count_csr(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int, with_firstpos: boo
     nnz = _i64(0)
     ctx.call(
         "skm_count_csr", _ptr(lut.rank), lut.nsym, k, bits, _ptr(batch.d_seq), _ptr(batch.d_off), _i64(batch.n),
-        _i64(batch.total), _i64(cap), _ptr(out.rowptr), _ptr(out.codes), _ptr(out.counts),
+        _i64(batch.total), _i64(batch.max_len), _i64(cap), _ptr(out.rowptr), _ptr(out.codes), _ptr(out.counts),
         _ptr(out.firstpos if with_firstpos else None), C.byref(nnz),
     )
     out.n, out.nnz = batch.n, int(nnz.value)
@@ -324,12 +326,33 @@ def vectorize_fused(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int, csr: Optiona
     rn = rnorm if rnorm is not None and rnorm.size >= batch.n else ctx.empty(batch.n + 4, np.float32)
     ctx.call(
         "skm_vectorize_csr", _ptr(lut.rank), lut.nsym, k, bits, _ptr(batch.d_seq), _ptr(batch.d_off), _i64(batch.n),
-        _i64(batch.total), _i64(cap), _ptr(csr.rowptr), _ptr(csr.codes), _ptr(csr.counts), _ptr(b.codes), _ptr(csr.colidx),
+        _i64(batch.total), _i64(batch.max_len), _i64(cap), _ptr(csr.rowptr), _ptr(csr.codes), _ptr(csr.counts), _ptr(b.codes), _ptr(csr.colidx),
         _ptr(b.colptr), _ptr(b.post), _ptr(rn), _ptr(None), _ptr(b.d_ncols),
     )
     csr.n, csr.nnz, csr.elided = batch.n, None, True
     b.ncols = None
     return csr, b, rn
+
+
+def vectorize_counts(ctx, batch: SeqBatch, lut: AlphabetLUT, k: int, csr: Optional[CountsCSR] = None, rnorm=None):
+    """The count stage of vectorize_fused alone (skm_vectorize_csr without basis outputs): CSR counts + row norms, no
+    result read back.  Returns (csr, rnorm); `csr.colidx` is left as it was (no basis has been built)."""
+    if batch.n < 1 or batch.total < 1:
+        raise ValueError("vectorize_counts needs a non-empty batch")
+    bits = lut.code_bits(k)
+    dt = np.uint32 if bits == 32 else np.uint64
+    cap = batch.total + 1
+    if csr is None or csr.codes.size < cap or csr.code_bits != bits or csr.rowptr.size < batch.n + 1:
+        csr = CountsCSR(ctx, batch.n, None, bits, ctx.empty(batch.n + 1, np.int64), ctx.empty(cap, dt),
+                        ctx.empty(cap, np.uint32), None)
+    rn = rnorm if rnorm is not None and rnorm.size >= batch.n else ctx.empty(batch.n + 4, np.float32)
+    ctx.call(
+        "skm_vectorize_csr", _ptr(lut.rank), lut.nsym, k, bits, _ptr(batch.d_seq), _ptr(batch.d_off), _i64(batch.n),
+        _i64(batch.total), _i64(batch.max_len), _i64(cap), _ptr(csr.rowptr), _ptr(csr.codes), _ptr(csr.counts), _ptr(None), _ptr(None),
+        _ptr(None), _ptr(None), _ptr(rn), _ptr(None), _ptr(None),
+    )
+    csr.n, csr.nnz, csr.elided = batch.n, None, False
+    return csr, rn
 
 
 def row_norms(ctx, n: int, rowptr, counts, out=None) -> _hip.DeviceArray:
@@ -565,52 +588,139 @@ class DensePipeline:
         return self.out
 
 
+DENSE_ROUTE_MAX_COLS = 1 << 17   # |S|^k up to which the full basis may be held dense (int8, n x |S|^k bytes)
+DENSE_ROUTE_MIN_FILL = 0.005     # windows per sequence / |S|^k: below this the sparse kernels do less work
+
+
 class Pipeline:
     """vectorize + all-pairs cosine for one batch, reusing every device buffer between steps.
 
     This is the unit `bench.py` times: inputs resident in HBM, outputs (CSR counts, basis,
     N x N float32 cosine) resident in HBM.
+
+    `step` picks between two exact routes from what the host knows before anything runs.  Large or sparsely filled
+    bases (BASELINE's red6 k=12: 2e9 possible columns, ~126 observed per sequence) take the sparse route: observed
+    basis by a global sort, postings, sparse Gram, streaming writer.  Small full bases (|S|^k <= 2^17 with at least
+    0.5 % of a row filled: the reference's CI configuration solvacc k=8 = 6561 columns, hydro k <= 17) take the DENSE
+    route: the count stage's CSR becomes an int8 operand whose column ids are the codes themselves (no sort, no
+    postings) and the cosine is one symmetric GEMM on the matrix cores (skm_cosine_dense_i8); rows with a count above
+    127 are recomputed exactly by skm_cosine_fixup_rows, so the route needs no data-dependent decision on the host.
+    `dense_route=False` (or SKM_COSINE_PATH=lists / cursor, the test knobs that name a sparse kernel) keeps the sparse
+    route.  `basis` is built on first use after a dense-route step.
     """
 
-    def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int, post32: bool = False, fused: bool = True):
+    def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int, post32: bool = False, fused: bool = True,
+                 dense_route="auto"):
         self.ctx, self.lut, self.k = ctx, lut, k
         self.fused = fused  # skm_vectorize_csr (one call, no result read back) instead of the three-call form
         # 4-byte posting words (batches under 2^24 sequences): half the posting bytes, but measured SLOWER
         # end to end on MI355X (k_gram_sparse is bound by instruction issue and the decode costs
         # instructions: 1.90 vs 1.75 ms at BASELINE configs[2]), so it is opt-in
         self.post32 = post32
+        self.dense_route = dense_route
+        self.route = "sparse"      # route of the last step
         self.csr: Optional[CountsCSR] = None
-        self.basis: Optional[Basis] = None
+        self._basis: Optional[Basis] = None
+        self._basis_stale = False  # a dense-route step builds no basis; `basis` does, on first use
         self.rnorm = None
         self.out = None
+        self._dense = self._irr_list = self._irr_count = None
+        self._dense_valid = False
+
+    @property
+    def basis(self) -> Optional[Basis]:
+        if self._basis_stale:
+            self._basis = build_basis(self.ctx, self.csr, self.lut.nsym, self.k, elide_singletons=True, post32=self.post32)
+            self._basis_stale = False
+        return self._basis
+
+    @basis.setter
+    def basis(self, value):
+        self._basis, self._basis_stale = value, False
+
+    def _sparse_forced(self) -> bool:
+        import os
+
+        return self.dense_route in (False, "never") or os.environ.get("SKM_COSINE_PATH") in ("lists", "cursor")
+
+    def wants_dense(self, batch: SeqBatch) -> bool:
+        """The host-side routing rule: a function of (alphabet, k, batch shape) only."""
+        if self._sparse_forced() or batch.n < 1 or batch.total < 1 or self.lut.code_bits(self.k) != 32:
+            return False
+        space = self.lut.nsym**self.k
+        if self.dense_route == "always":
+            return space <= (1 << 26)
+        fill = max(batch.total / batch.n - self.k + 1, 0.0) / space
+        return space <= DENSE_ROUTE_MAX_COLS and fill >= DENSE_ROUTE_MIN_FILL
 
     def vectorize(self, batch: SeqBatch) -> CountsCSR:
+        self.route, self._dense_valid = "sparse", False
         if self.fused and not self.post32 and batch.n >= 1 and batch.total >= 1:
             # one call, no size read back: within a step the host runs ahead of the GPU (one wait per call remains,
             # for the size-class histogram: see vectorize_fused)
             self.csr, self.basis, self.rnorm = vectorize_fused(self.ctx, batch, self.lut, self.k, csr=self.csr,
-                                                               basis=self.basis, rnorm=self.rnorm)
+                                                               basis=self._basis, rnorm=self.rnorm)
             return self.csr
         self.csr = count_csr(self.ctx, batch, self.lut, self.k, out=self.csr)
-        self.basis = build_basis(self.ctx, self.csr, self.lut.nsym, self.k, out=self.basis, elide_singletons=True,
+        self.basis = build_basis(self.ctx, self.csr, self.lut.nsym, self.k, out=self._basis, elide_singletons=True,
                                  post32=self.post32)
         self.rnorm = row_norms(self.ctx, self.csr.n, self.csr.rowptr, self.csr.counts, out=self.rnorm)
         return self.csr
 
-    def cosine(self, row0: int = 0, row1: Optional[int] = None):
-        n = self.csr.n
-        row1 = n if row1 is None else row1
-        rows = row1 - row0
-        ld = (n + 3) // 4 * 4
+    def _out_block(self, rows: int, ld: int):
         if self.out is None or self.out.shape[0] < rows or self.out.shape[1] != ld:
             self.out = None
             self.out = self.ctx.empty((max(rows, 1), max(ld, 1)), np.float32)
-        b = self.basis
-        cosine_matrix(self.ctx, self.csr, self.rnorm, n, b.ncols_hint(), b.colptr, b.post, self.rnorm,
-                      row0=row0, row1=row1, out=self.out, ld=ld, post_bits=b.post_bits, postcnt=b.postcnt)
         return self.out
 
+    def cosine(self, row0: int = 0, row1: Optional[int] = None):
+        n = self.csr.n
+        row1 = n if row1 is None else row1
+        if not 0 <= row0 <= row1 <= n:
+            raise ValueError(f"bad row range [{row0},{row1}) of {n}")
+        ld = (n + 3) // 4 * 4
+        if self.route == "dense" and not self._sparse_forced():
+            return self._cosine_dense(row0, row1, ld)
+        out = self._out_block(row1 - row0, ld)
+        b = self.basis
+        cosine_matrix(self.ctx, self.csr, self.rnorm, n, b.ncols_hint(), b.colptr, b.post, self.rnorm,
+                      row0=row0, row1=row1, out=out, ld=ld, post_bits=b.post_bits, postcnt=b.postcnt)
+        return out
+
+    def _cosine_dense(self, row0: int, row1: int, ld: int):
+        ctx, n = self.ctx, self.csr.n
+        kdim = (self.lut.nsym**self.k + 127) // 128 * 128
+        if not self._dense_valid:
+            if self._dense is None or self._dense.shape != (n, kdim):
+                self._dense = None
+                self._dense = ctx.empty((n, kdim), np.int8)
+            if self._irr_list is None or self._irr_list.size < n:
+                self._irr_list = ctx.empty(n, np.uint32)
+            if self._irr_count is None:
+                self._irr_count = ctx.zeros(1, np.uint32)
+            ctx.call("skm_csr_to_dense_i8", _i64(n), _ptr(self.csr.rowptr), _ptr(self.csr.codes), _ptr(self.csr.counts), _i64(kdim),
+                     _ptr(self._dense), _ptr(self._irr_list), _ptr(self._irr_count))
+            self._dense_valid = True
+        rows = row1 - row0
+        out = self._out_block(rows, ld)
+        if rows > 0:
+            whole = row0 == 0 and row1 == n  # X is Y: the symmetric launch
+            cosine_dense_i8(ctx, rows, n, kdim, self._dense if whole else self._dense.at(row0 * kdim), self._dense,
+                            self.rnorm if whole else self.rnorm.at(row0), self.rnorm, out=out, ld=ld)
+            ctx.call("skm_cosine_fixup_rows", _i64(n), _ptr(self.csr.rowptr), _ptr(self.csr.codes), _ptr(self.csr.counts),
+                     _ptr(self.rnorm), _i64(row0), _i64(row1), _ptr(self._irr_list), _ptr(self._irr_count), 0, _ptr(out), _i64(ld))
+        return out
+
+    def irregular_rows(self) -> int:
+        """Rows the last dense-route step recomputed exactly (a count above 127); reads one word back."""
+        return int(self._irr_count.download(1)[0]) if self._dense_valid else 0
+
     def step(self, batch: SeqBatch):
+        if self.wants_dense(batch):
+            self.csr, self.rnorm = vectorize_counts(self.ctx, batch, self.lut, self.k, csr=self.csr, rnorm=self.rnorm)
+            self.csr.colidx = None
+            self.route, self._basis_stale, self._dense_valid = "dense", True, False
+            return self.cosine()
         self.vectorize(batch)
         return self.cosine()
 

@@ -7,8 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# skm_cosine_csr routes outputs of at most 1024 columns to the cursor kernel and larger ones to the neighbour-list
-# kernels; SKM_COSINE_PATH=lists / cursor force one of them (all exact).  Tests marked `cosine_paths` run once per
+# skm_cosine_csr routes tall outputs of at most 1024 columns (rows >= 8 x columns) to the cursor kernel and all others to
+# the neighbour-list kernels; SKM_COSINE_PATH=lists / cursor force one of them (all exact).  Tests marked `cosine_paths` run once per
 # routing: "default" is the product's own dispatch (no variable set), the other two cover the kernel the default
 # would not pick at the test's size.  Unmarked tests run the default dispatch.
 COSINE_PATHS = ("default", "lists", "cursor")

@@ -142,6 +142,16 @@ def test_count_csr_and_basis_vs_oracle(ctx, name, k):
     csr2 = engine.count_csr(ctx, batch, lut, k, with_firstpos=False)
     r2, c2, n2, _ = csr2.host()
     assert (r2 == o_rowptr).all() and (c2.astype(np.uint64) == o_codes).all() and (n2 == o_counts).all()
+    # a caller without a bound on the longest sequence (max_seq_len = 0: the library asks the device for the size
+    # classes and sizes the global-scratch kernel per sequence) gets the same arrays, first positions included
+    assert batch.max_len == max(len(s) for s in seqs) > 8192 + k
+    bound, batch.max_len = batch.max_len, 0
+    try:
+        csr3 = engine.count_csr(ctx, batch, lut, k, with_firstpos=True)
+    finally:
+        batch.max_len = bound
+    r3, c3, n3, f3 = csr3.host()
+    assert (r3 == o_rowptr).all() and (c3.astype(np.uint64) == o_codes).all() and (n3 == o_counts).all() and (f3 == o_first).all()
 
 
 def test_unsupported_code_space_is_loud(ctx):
@@ -455,6 +465,58 @@ def test_dense_i8_refuses_operands_whose_dot_products_may_leave_int32(ctx):
     xr = engine.row_norms_i8(ctx, 4, kdim, dx)
     with pytest.raises(_hip.HipError, match="OVERFLOW"):
         engine.cosine_dense_i8(ctx, 4, 4, kdim, dx, dx, xr, xr)
+
+
+@pytest.mark.parametrize("name,k,n", [("solvacc", 8, 1500), ("hydro", 3, 1400), ("hydro", 14, 1100), ("hydrocharge", 5, 300)])
+def test_pipeline_dense_route_small_full_bases_vs_oracle(ctx, name, k, n):
+    """Pipeline.step routes small full bases (|S|^k <= 2^17, rows at least 0.5 % filled: the reference's CI configuration
+    is solvacc k=8) to the int8 GEMM on the matrix cores; rows with a count above 127 (here also homopolymers whose
+    dot products leave int32) are recomputed exactly from the CSR.  Same values as the sparse route and the oracle,
+    whole matrix and row block; `basis` appears on first use."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+    from snekmer_amd.utils import pack_sequences
+
+    orc = _oracle()
+    lut = A.build_lut(name)
+    res, off, _ = synth_families(n, 300, family=25, seed=31 + k)
+    raw = res.tobytes()
+    seqs = [raw[off[i] : off[i + 1]].decode() for i in range(n)]
+    seqs[7] = "A" * 50000            # count 49 998 at k=3: irregular AND beyond int32
+    seqs[8] = ""
+    seqs[640 % n] = "AG" * 30000
+    seqs[n - 1] = "MKV"
+    seqs.insert(100, "ST" * 200 + "X" + "DE" * 150)  # counts above 127, nothing more
+    res, off = pack_sequences(seqs)
+    n = len(seqs)
+    batch = engine.SeqBatch(ctx, res, off)
+    pipe = engine.Pipeline(ctx, lut, k)
+    assert pipe.wants_dense(batch)
+    out = pipe.step(batch)
+    assert pipe.route == "dense" and pipe.irregular_rows() >= 3
+    S = out.download().reshape(out.shape)[:n, :n].copy()
+    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off)
+    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first)
+    ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), np.arange(n))
+    assert np.abs(S - ref).max() <= COS_TOL
+    assert (S[8] == 0).all() and (S[:, 8] == 0).all()
+    hi = min(777, n - 3)
+    blk = pipe.cosine(row0=5, row1=hi).download().reshape(pipe.out.shape)[: hi - 5, :n]
+    assert np.abs(blk - ref[5:hi]).max() <= COS_TOL
+    with pytest.raises(ValueError):
+        pipe.cosine(row0=5, row1=n + 1)
+    # the sparse route on the same batch: same counts, and the basis the dense route builds on demand is the same one
+    sparse = engine.Pipeline(ctx, lut, k, dense_route=False)
+    S2 = sparse.step(batch)
+    S2 = S2.download().reshape(S2.shape)[:n, :n]
+    assert sparse.route == "sparse" and np.abs(S2 - S).max() <= 1e-6
+    assert pipe.basis.ncols == sparse.basis.ncols == len(ob)
+    assert (pipe.basis.codes.download(len(ob)).astype(np.uint64) == ob).all()
+    assert (pipe.csr.counts.download(pipe.csr.nnz) == o_counts).all()
+    # large or thinly filled bases keep the sparse route
+    assert not engine.Pipeline(ctx, A.build_lut("red6"), 12).wants_dense(batch)
+    assert not engine.Pipeline(ctx, A.build_lut("solvacc"), 11).wants_dense(batch)
 
 
 @pytest.mark.cosine_paths
@@ -1522,7 +1584,7 @@ def test_c_abi_error_codes_and_messages(ctx):
 
     def count(nsym, k, bits, cap):
         return lib.skm_count_csr(ctx.handle, rank, nsym, k, bits, p(batch.d_seq), p(batch.d_off), C.c_int64(1),
-                                 C.c_int64(batch.total), C.c_int64(cap), p(rowptr), p(codes), p(counts), None, C.byref(nnz))
+                                 C.c_int64(batch.total), C.c_int64(0), C.c_int64(cap), p(rowptr), p(codes), p(counts), None, C.byref(nnz))
 
     assert count(2, 4, 32, 16) == 0 and nnz.value > 0
     assert count(2, 4, 16, 16) == -1 and b"code width" in lib.skm_last_error()          # SKM_E_BADARG
@@ -1858,8 +1920,8 @@ def test_fused_vectorize_equals_the_three_call_form(ctx, name, k):
     seqs, (res, off) = _mixed_batch(seed=31, n=700)
     batch = engine.SeqBatch(ctx, res, off)
     n = batch.n
-    a = engine.Pipeline(ctx, lut, k, fused=False)
-    b = engine.Pipeline(ctx, lut, k, fused=True)
+    a = engine.Pipeline(ctx, lut, k, fused=False, dense_route=False)  # (hydro k=3 would take the dense route: this test
+    b = engine.Pipeline(ctx, lut, k, fused=True, dense_route=False)   # is about the two forms of the sparse vectorize)
     Sa = a.step(batch)
     Sa = Sa.download().reshape(Sa.shape)[:n, :n].copy()
     for _ in range(2):  # second step reuses every buffer
