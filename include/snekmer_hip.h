@@ -159,7 +159,8 @@ int skm_basis_build(skm_ctx *ctx, int code_bits, int key_bits, int flags, int64_
  * rules/kmerize.smk:89-104 + rules/learn.smk:359-383 as the cosine stage needs it.  Sizes that depend on the data stay
  * on the device: the entry count is d_rowptr[n], the number of basis columns *d_ncols (device int64); every launch is
  * sized by total_residues.  Outputs as documented for the three calls it replaces, capacity cap_entries >
- * total_residues each (d_colptr: cap_entries + 1); d_codes past the entry count is filled with the all-ones sentinel;
+ * total_residues each (d_colptr: cap_entries + 1); d_codes past the entry count is unspecified (all-ones under
+ * SKM_SORT=rocprim, whose capacity-sized sort runs over that fill);
  * d_rnorm / d_normsq are optional.  No result is read back (read d_rowptr[n] / *d_ncols with skm_memcpy_d2h when the
  * host needs them).  With max_seq_len > 0 (see skm_count_csr) the call never waits for the device: the host may queue
  * any number of steps ahead.  With max_seq_len == 0 one wait remains: the size-class histogram of the sequences is

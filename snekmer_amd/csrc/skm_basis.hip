@@ -15,6 +15,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "skm_common.h"
+#include "skm_onesweep.h"
 #include "skm_sort.h"
 
 namespace {
@@ -1047,12 +1048,29 @@ int skm_basis_stage_async(skm_ctx *ctx, int code_bits, int key_bits, int64_t cap
     if (key_bits <= 0 || key_bits > code_bits)
         key_bits = code_bits;
     SKM_HIP(hipMemsetAsync(d_colidx, 0xFF, sizeof(uint32_t) * (size_t)cap, st));
-    // Entries past the device-side count carry the all-ones sentinel (skm_count_stage_async): they are the last
-    // ones of the input, and the sort is stable, so positions [0, nnz) of the sorted order are exactly the entries.
-    if (code_bits == 32)
-        SKM_TRY(sort_pairs<uint32_t>(ctx, (const uint32_t *)d_codes, (uint32_t *)skeys, sidx, cap, key_bits, "rocprim_radix_sort_codes"));
-    else
-        SKM_TRY(sort_pairs<uint64_t>(ctx, (const uint64_t *)d_codes, (uint64_t *)skeys, sidx, cap, key_bits, "rocprim_radix_sort_codes"));
+    if (skm_use_onesweep(cap)) {
+        // the library's own sort: sized by the device-side entry count, 2 + (key_bits / 8) launches (skm_onesweep.h)
+        const int passes = (key_bits + 7) / 8;
+        SKM_TRY(skm_ws(ctx, WS_H, kb * (size_t)cap, &p));
+        void *ktmp = p;
+        SKM_TRY(skm_ws(ctx, WS_I, sizeof(uint32_t) * (size_t)cap, &p));
+        uint32_t *vtmp = (uint32_t *)p;
+        SKM_TRY(skm_ws(ctx, WS_ROCPRIM, skm_onesweep::state_bytes(cap, 8192, passes) + skm_onesweep::state_bytes(cap, 2048, passes), &p));
+        if (code_bits == 32)
+            SKM_TRY(skm_onesweep::sort_pairs_dev<uint32_t>(ctx, d_nnz, cap, (const uint32_t *)d_codes, (uint32_t *)skeys, sidx,
+                                                            (uint32_t *)ktmp, vtmp, p, key_bits, "onesweep_sort_codes"));
+        else
+            SKM_TRY(skm_onesweep::sort_pairs_dev<uint64_t>(ctx, d_nnz, cap, (const uint64_t *)d_codes, (uint64_t *)skeys, sidx,
+                                                            (uint64_t *)ktmp, vtmp, p, key_bits, "onesweep_sort_codes"));
+    } else {
+        // rocPRIM sorts the capacity: entries past the device-side count carry the all-ones sentinel
+        // (skm_count_stage_async); they are the last ones of the input and the sort is stable, so positions [0, nnz) of
+        // the sorted order are exactly the entries.
+        if (code_bits == 32)
+            SKM_TRY(sort_pairs<uint32_t>(ctx, (const uint32_t *)d_codes, (uint32_t *)skeys, sidx, cap, key_bits, "rocprim_radix_sort_codes"));
+        else
+            SKM_TRY(sort_pairs<uint64_t>(ctx, (const uint64_t *)d_codes, (uint64_t *)skeys, sidx, cap, key_bits, "rocprim_radix_sort_codes"));
+    }
     {
         SKM_PROF(ctx, "k_head_count");
         if (code_bits == 32)

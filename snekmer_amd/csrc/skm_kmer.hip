@@ -979,7 +979,7 @@ int skm_count_stage_async(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, 
     skm_lut256 lut;
     SKM_TRY(make_lut(h_rank, &lut));
     SKM_TRY(check_code_space(nsym, k, code_bits));
-    if (d_rowcount)  // the sentinel tail is for the basis stage's sort; a counts-only call has none
+    if (d_rowcount && !skm_use_onesweep(total_residues))  // the sentinel tail is for rocPRIM's capacity-sized sort
         SKM_HIP(hipMemsetAsync(d_codes, 0xFF, (size_t)(code_bits / 8) * (size_t)(total_residues + 1), ctx->stream));
     if (code_bits == 32)
         return count_csr_impl<uint32_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, max_seq_len, d_rowptr, (uint32_t *)d_codes,

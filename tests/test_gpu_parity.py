@@ -1906,7 +1906,7 @@ def test_config4_one_rank_share_125k_rows_vs_1m(ctx):
 # ------------------------------------------------------------------ fused vectorize (no host synchronisation)
 @pytest.mark.cosine_paths
 @pytest.mark.parametrize("name,k", [("red6", 12), ("standard", 12), ("hydro", 20), ("hydro", 3), ("hydro", 32)])
-def test_fused_vectorize_equals_the_three_call_form(ctx, name, k):
+def test_fused_vectorize_equals_the_three_call_form(ctx, name, k, monkeypatch):
     """skm_vectorize_csr (count + basis/postings + norms in one call, sizes left on the device) against
     skm_count_csr + skm_basis_build + skm_row_norms_csr: every output array identical, and the cosine matrix with it;
     all size classes (long sequences take the LDS-block and global-scratch count kernels), both code widths.
@@ -1948,8 +1948,21 @@ def test_fused_vectorize_equals_the_three_call_form(ctx, name, k):
         shared[cp[c]:cp[c + 1]] = True
     pa, pb = a.basis.post.download(nnz), b.basis.post.download(nnz)
     assert (pa[shared] == pb[shared]).all()
-    # the sentinel fill past the entry count (what lets the sort run without knowing it)
-    tail = b.csr.codes.download(batch.total + 1 - nnz, offset=nnz)
+    # The library's own sort reads the entry count on the device.  The vendor sort (SKM_SORT=rocprim, kept for A/B
+    # timing) sorts the capacity instead, over a sentinel fill past the entry count: both are stable sorts of the same
+    # keys, so every array is the same again.
+    monkeypatch.setenv("SKM_SORT", "onesweep")  # (the default picks by size: this batch is below the switch-over)
+    Sd = engine.Pipeline(ctx, lut, k, fused=True, dense_route=False).step(batch)
+    assert (Sd.download().reshape(Sd.shape)[:n, :n] == Sb).all()
+    monkeypatch.setenv("SKM_SORT", "rocprim")
+    c = engine.Pipeline(ctx, lut, k, fused=True, dense_route=False)
+    Sc = c.step(batch)
+    assert (Sc.download().reshape(Sc.shape)[:n, :n] == Sb).all()
+    for x, y in ((c.csr.colidx.download(nnz), b.csr.colidx.download(nnz)), (c.basis.codes.download(B), b.basis.codes.download(B)),
+                 (c.basis.colptr.download(B + 1), b.basis.colptr.download(B + 1))):
+        assert (x == y).all()
+    assert (c.basis.post.download(nnz)[shared] == pb[shared]).all()
+    tail = c.csr.codes.download(batch.total + 1 - nnz, offset=nnz)
     assert (tail == np.iinfo(tail.dtype).max).all()
 
 
