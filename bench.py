@@ -555,8 +555,8 @@ def sharded_stage_rooflines(engine, args, pipe, prof, world, residues_local, row
         ("rocprim_scan_shared_kmers", "hbm", own * (cb + 8), "sorted keys read, scan written"),
         ("k_bucket_emit", "hbm", own * (cb + 12) + z["owned_postings"] * 16 + z["owned_columns"] * (8 + cb),
          "sorted keys/indices/scan read; posting word gathered + written per shared entry; column start + table slot per column"),
-        ("rccl_allgatherv", "xgmi", z["allgather_bytes_in"] // max(world - 1, 1),
-         "this rank's postings/starts/table/norms to every peer (bytes per link)"),
+        ("rccl_allgatherv", "xgmi", z["owned_postings"] * 8 + z["owned_columns"] * 4 + z["owned_table_slots"] * (cb + 4) + rows_local * 4,
+         "this rank's own postings / column starts / table / norms, sent once over the link to every peer (bytes per link)"),
         ("k_colidx_lookup", "hbm", loc * (cb + 4) + loc * (cb + 4), "codes read, column ids written, one table probe (key + value) per entry"),
         ("k_gram_sparse", "hbm", pairs * 8, "every (row, posting) pair of this rank's rows reads one 8-byte posting"),
         ("k_cosine_write", "hbm", rows_local * ld * 4, "this rank's float32 row block"),
@@ -679,23 +679,77 @@ def real_proteome(ctx, engine, alphabet):
     batch = engine.SeqBatch(ctx, res, off)
     out = {"file": "tests/golden/data/UP000322080_2603819.fasta", "sequences": int(len(ids)), "residues": int(off[-1]),
            "longest": int(np.diff(off).max()), "runs": []}
-    for name, k in (("solvacc", 8), ("standard", 12)):
-        p = engine.Pipeline(ctx, alphabet.build_lut(name), k)
+    # solvacc k=8 twice: the product's own dispatch (small full basis -> int8 GEMM on the matrix cores) and the sparse
+    # kernels forced on the same batch (what every round before this one ran)
+    for name, k, dense_route in (("solvacc", 8, "auto"), ("solvacc", 8, False), ("standard", 12, "auto")):
+        p = engine.Pipeline(ctx, alphabet.build_lut(name), k, dense_route=dense_route)
         for _ in range(3):
             p.step(batch)
         ctx.sync()
-        reps = 20
+        reps = 50
         t1 = time.perf_counter()
         for _ in range(reps):
             p.step(batch)
         ctx.sync()
         dt = (time.perf_counter() - t1) / reps
-        st = (C.c_int64 * 4)()
-        ctx.call("skm_cosine_csr_stats", st)
-        out["runs"].append({"alphabet": name, "k": k, "ms_per_step": dt * 1e3, "sequences_per_s": len(ids) / dt,
-                            "residues_per_s": int(off[-1]) / dt, "nnz": p.csr.nnz, "basis_columns": p.basis.ncols,
-                            "rows_handed_to_k_cosine_heavy": int(st[0]), "strips_left_to_cursor_kernel": int(st[1])})
+        run = {"alphabet": name, "k": k, "route": p.route, "ms_per_step": dt * 1e3, "sequences_per_s": len(ids) / dt,
+               "residues_per_s": int(off[-1]) / dt}
+        if p.route == "dense":
+            kdim = (p.lut.nsym**k + 127) // 128 * 128
+            ctx.profile_enable(True)
+            ctx.profile_reset()
+            for _ in range(10):
+                p.step(batch)
+            gemm_ms = ctx.profile_dump()["k_cosine_dense_i8"][1] / 10
+            ctx.profile_enable(False)
+            ops = len(ids) * (len(ids) + 1) * kdim  # symmetric launch: tiles on or above the diagonal
+            run.update({"irregular_rows_recomputed_exactly": p.irregular_rows(), "gemm_ms": gemm_ms,
+                        "mfma_util": ops / (gemm_ms * 1e-3) / (I8_PEAK_TOPS * 1e12), "kdim": kdim})
+        else:
+            st = (C.c_int64 * 4)()
+            ctx.call("skm_cosine_csr_stats", st)
+            run.update({"rows_handed_to_k_cosine_heavy": int(st[0]), "strips_left_to_cursor_kernel": int(st[1])})
+        run.update({"nnz": p.csr.nnz, "basis_columns": p.basis.ncols})
+        out["runs"].append(run)
         del p
+    return out
+
+
+def small_batches(ctx, engine, alphabet, args):
+    """The launch-bound regime: BASELINE configs[1] (10 k sequences) and the reference's real job sizes (one FASTA file
+    of 50-3 700 records per Snakemake job, snekmer/rules/kmerize.smk:57-65).  Per N: wall time per step (host running
+    ahead, no synchronisation inside the loop), the sum of the per-stage HIP-event times, launches per step (profiled
+    scopes: a library sort counts as one) and `frac` = the step's HBM floor (4 bytes per result cell at the 8 TB/s spec)
+    over the wall time."""
+    from snekmer_amd.synth import BASE_SEED, synth_families
+
+    lut = alphabet.build_lut(args.alphabet)
+    out = []
+    for n in (1000, 3383, 10000):
+        res, off, _ = synth_families(n, args.length, family=100, seed=BASE_SEED + 1)
+        b = engine.SeqBatch(ctx, res, off)
+        p = engine.Pipeline(ctx, lut, args.k)
+        for _ in range(5):
+            p.step(b)
+        ctx.sync()
+        reps = 200
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            p.step(b)
+        ctx.sync()
+        wall = (time.perf_counter() - t1) / reps * 1e3
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        for _ in range(50):
+            p.step(b)
+        prof = ctx.profile_dump()
+        ctx.profile_enable(False)
+        ld = (n + 3) // 4 * 4
+        floor_ms = 4.0 * n * ld / (HBM_PEAK_GBS * 1e9) * 1e3
+        out.append({"n": n, "wall_ms": wall, "kernel_sum_ms": sum(v[1] for v in prof.values()) / 50,
+                    "launches_per_step": sum(v[0] for v in prof.values()) / 50, "hbm_floor_ms": floor_ms, "frac": floor_ms / wall,
+                    "sequences_per_s": n / (wall * 1e-3), "stage_ms": {kk: round(v[1] / 50, 4) for kk, v in prof.items()}})
+        del p, b
     return out
 
 
@@ -829,6 +883,8 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
     note("extras: real_proteome")
     line["api_vectorize_fasta"] = api_vectorize_fasta(args, seed)
     note("extras: api_vectorize_fasta")
+    line["small_batches"] = small_batches(ctx, engine, alphabet, args)
+    note("extras: small_batches")
 
     # BASELINE configs[1]: 10k sequences, same alphabet and k
     res2, off2, _ = synth_families(10000, args.length, family=100, seed=BASE_SEED + 1)
