@@ -450,22 +450,26 @@ int skm_allgatherv_multi(skm_ctx *ctx, int narrays, const void *const *d_send, v
  * (snekmer_amd/csrc/skm_shard.hip has the data flow; snekmer_amd/dist.py drives it). */
 #define SKM_MAX_RANKS 64
 /* Entries of a local CSR shard (n rows, first global row = row_base) grouped by owner, original
- * order kept inside a group: d_out_codes[nnz], d_out_rowcount[nnz] = global row | count << 32;
- * h_counts[nbuckets] = entries per owner.  Host-synchronous. */
-int skm_bucket_partition(skm_ctx *ctx, int code_bits, int nbuckets, int64_t n, int64_t nnz, const int64_t *d_rowptr,
+ * order kept inside a group: d_out_codes / d_out_rowcount (global row | count << 32), capacity cap_entries each.  The
+ * entry count is read on the device (d_rowptr[n] <= cap_entries < 2^30), so the call does not wait for it:
+ * d_out_counts[nbuckets] (device int64) = entries per owner, which the exchange can gather device to device
+ * (one host round trip for the whole [src, dst] matrix).  h_counts (optional): the same on the host; passing it makes
+ * the call host-synchronous. */
+int skm_bucket_partition(skm_ctx *ctx, int code_bits, int nbuckets, int64_t n, int64_t cap_entries, const int64_t *d_rowptr,
                          const void *d_codes, const uint32_t *d_counts, int64_t row_base, void *d_out_codes,
-                         uint64_t *d_out_rowcount, int64_t *h_counts);
+                         uint64_t *d_out_rowcount, int64_t *d_out_counts, int64_t *h_counts);
 /* Owner side: from the nrecv (code, row | count << 32) entries an owner received (ascending rows
  * within equal codes once stably sorted, which holds when sources are concatenated in rank order)
  * build d_post[npost] (postings of k-mers found in >= 2 rows, column after column, rows ascending),
  * d_cols_start[ncols] (index of each such column's first posting in d_post) and an open-addressing
  * hash table code -> column: d_tab_vals[tsize] (0xFFFFFFFF = empty) / d_tab_keys[tsize], tsize a
- * power of two >= 2 * ncols.  h_out4 = {distinct k-mers incl. single-row ones, ncols, npost, tsize}.
- * d_cols_start / d_post need room for nrecv elements, the table for
- * skm_bucket_table_capacity(nrecv) slots.  Host-synchronous. */
+ * power of two >= 2 * ncols.  d_out4 (device int64[4]) = {distinct k-mers incl. single-row ones, ncols, npost, tsize};
+ * the call does not wait for them (gather them device to device with the other owners' sizes).  h_out4 (optional):
+ * the same on the host, which makes the call host-synchronous.  d_cols_start / d_post need room for nrecv elements, the
+ * table for skm_bucket_table_capacity(nrecv) slots (all of its value words are cleared). */
 int64_t skm_bucket_table_capacity(int64_t nrecv);
 int skm_bucket_postings(skm_ctx *ctx, int code_bits, int key_bits, int64_t nrecv, const void *d_codes,
-                        const uint64_t *d_rowcount, int64_t *h_out4, uint32_t *d_cols_start, uint64_t *d_post,
+                        const uint64_t *d_rowcount, int64_t *d_out4, int64_t *h_out4, uint32_t *d_cols_start, uint64_t *d_post,
                         void *d_tab_keys, uint32_t *d_tab_vals);
 /* Global column starts from the gathered per-owner arrays: d_starts holds the owners' d_cols_start
  * arrays back to back (h_ncols[p] entries each); d_colptr[sum(h_ncols) + 1] gets them rebased by

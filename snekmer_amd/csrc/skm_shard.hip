@@ -23,6 +23,7 @@
 // Every rank sorts 1/G of the entries instead of all of them (the replicated skm_basis_build was
 // the Amdahl term of the strong-scaling bench).
 #include "skm_common.h"
+#include "skm_onesweep.h"
 #include "skm_sort.h"
 
 namespace {
@@ -87,13 +88,19 @@ __global__ __launch_bounds__(BLK) void k_bucket_keys(const int64_t *__restrict__
         atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
 }
 
+// (the entry count lives on the device: d_rowptr[n]; the grid covers the capacity)
 template <typename K>
-__global__ __launch_bounds__(BLK) void k_partition_gather(int64_t nnz, const uint32_t *__restrict__ idx,
+__global__ __launch_bounds__(BLK) void k_partition_gather(const int64_t *__restrict__ d_nnz, const uint32_t *__restrict__ idx,
                                                           const K *__restrict__ codes,
                                                           const uint64_t *__restrict__ rowcount,
-                                                          K *__restrict__ out_codes, uint64_t *__restrict__ out_rowcount)
+                                                          K *__restrict__ out_codes, uint64_t *__restrict__ out_rowcount,
+                                                          const unsigned int *__restrict__ hist, int nbuckets,
+                                                          int64_t *__restrict__ out_counts)
 {
+    const int64_t nnz = *d_nnz;
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nbuckets)
+        out_counts[t] = (int64_t)hist[t];  // entries per owner, as the exchange gathers them (int64)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; t < nnz; t += stride) {
         const uint32_t e = idx[t];
@@ -118,15 +125,35 @@ struct ns_flags {
     }
 };
 
+// sizes of an owner's share from the closing element of the scan: (distinct k-mers, shared columns, postings, table slots)
+__device__ __forceinline__ uint32_t table_size_dev(int64_t ncols)
+{
+    uint32_t t = 2;
+    while ((int64_t)t < 2 * ncols)
+        t <<= 1;
+    return t;
+}
+
+__global__ void k_owner_sizes(int64_t n, const uint64_t *__restrict__ incl, int64_t *__restrict__ out4)
+{
+    const uint64_t last = incl[n - 1];
+    const int64_t npost = (int64_t)(uint32_t)last, ncols_ns = (int64_t)(last >> 32);
+    out4[0] = (n - npost) + ncols_ns;
+    out4[1] = ncols_ns;
+    out4[2] = npost;
+    out4[3] = (int64_t)table_size_dev(ncols_ns);
+}
+
 template <typename K>
 __global__ __launch_bounds__(BLK) void k_bucket_emit(int64_t n, const K *__restrict__ skeys,
                                                      const uint32_t *__restrict__ sidx,
                                                      const uint64_t *__restrict__ incl,
                                                      const uint64_t *__restrict__ rowcount,
                                                      uint32_t *__restrict__ cols_start, uint64_t *__restrict__ post,
-                                                     uint32_t tsize, K *__restrict__ tab_keys,
+                                                     const int64_t *__restrict__ out4, K *__restrict__ tab_keys,
                                                      uint32_t *__restrict__ tab_vals)
 {
+    const uint32_t tsize = (uint32_t)out4[3];  // power of two >= 2 x shared columns (k_owner_sizes)
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; t < n; t += stride) {
@@ -204,19 +231,22 @@ __global__ void k_embed_rowptr(int64_t n_total, int64_t lo, int64_t nloc, const 
 }
 
 template <typename K>
-int partition_impl(skm_ctx *ctx, int nbuckets, int64_t n, int64_t nnz, const int64_t *d_rowptr, const K *d_codes,
+int partition_impl(skm_ctx *ctx, int nbuckets, int64_t n, int64_t cap, const int64_t *d_rowptr, const K *d_codes,
                    const uint32_t *d_counts, int64_t row_base, K *d_out_codes, uint64_t *d_out_rowcount,
-                   int64_t *h_counts)
+                   int64_t *d_out_counts, int64_t *h_counts)
 {
+    // Nothing here waits for the device unless the caller asks for the counts on the host: the entry count is
+    // d_rowptr[n], the launches cover the capacity, the stable grouping by owner is one digit of the library's own
+    // one-sweep sort (which reads its size on the device; rocPRIM's takes it as a host argument).
     hipStream_t st = ctx->stream;
     void *p;
-    SKM_TRY(skm_ws(ctx, WS_A, sizeof(uint64_t) * (size_t)nnz, &p));
+    SKM_TRY(skm_ws(ctx, WS_A, sizeof(uint64_t) * (size_t)cap, &p));
     uint64_t *rowcount = (uint64_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_B, (size_t)nnz, &p));
+    SKM_TRY(skm_ws(ctx, WS_B, (size_t)cap, &p));
     uint8_t *key8 = (uint8_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_C, (size_t)nnz, &p));
+    SKM_TRY(skm_ws(ctx, WS_C, (size_t)cap, &p));
     uint8_t *key8s = (uint8_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)nnz, &p));
+    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)cap, &p));
     uint32_t *idx = (uint32_t *)p;
     SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
     unsigned int *hist = (unsigned int *)p;
@@ -230,25 +260,20 @@ int partition_impl(skm_ctx *ctx, int nbuckets, int64_t n, int64_t nnz, const int
     int bits = 1;
     while ((1 << bits) < nbuckets)
         ++bits;
-    {
-        const rocprim::counting_iterator<uint32_t> vin(0);
-        size_t tmp = 0;
-        SKM_HIP(rocprim::radix_sort_pairs(nullptr, tmp, key8, key8s, vin, idx, (size_t)nnz, 0u, (unsigned)bits, st));
-        SKM_TRY(skm_ws(ctx, WS_ROCPRIM, tmp, &p));
-        SKM_PROF(ctx, "rocprim_radix_sort_owner");
-        SKM_HIP(rocprim::radix_sort_pairs(p, tmp, key8, key8s, vin, idx, (size_t)nnz, 0u, (unsigned)bits, st));
-    }
+    SKM_TRY(skm_ws(ctx, WS_ROCPRIM, skm_onesweep::state_bytes(cap, 8192, 1) + skm_onesweep::state_bytes(cap, 2048, 1), &p));
+    SKM_TRY(skm_onesweep::sort_pairs_dev<uint8_t>(ctx, d_rowptr + n, cap, key8, key8s, idx, nullptr, nullptr, p, bits,
+                                                  "onesweep_sort_owner"));
     {
         SKM_PROF(ctx, "k_partition_gather");
-        k_partition_gather<K><<<skm_grid_cap(ctx, skm_ceil_div(nnz, BLK), 16), BLK, 0, st>>>(nnz, idx, d_codes, rowcount,
-                                                                                           d_out_codes, d_out_rowcount);
+        k_partition_gather<K><<<skm_grid_cap(ctx, skm_ceil_div(cap, BLK), 16), BLK, 0, st>>>(
+            d_rowptr + n, idx, d_codes, rowcount, d_out_codes, d_out_rowcount, hist, nbuckets, d_out_counts);
     }
     SKM_TRY(skm_check_launch("k_partition_gather"));
-    unsigned int *h = (unsigned int *)ctx->h_pinned;
-    SKM_HIP(hipMemcpyAsync(h, hist, sizeof(unsigned int) * SKM_MAX_RANKS, hipMemcpyDeviceToHost, st));
-    SKM_HIP(hipStreamSynchronize(st));
-    for (int b = 0; b < nbuckets; ++b)
-        h_counts[b] = (int64_t)h[b];
+    if (h_counts) {
+        SKM_HIP(hipMemcpyAsync(ctx->h_pinned, d_out_counts, sizeof(int64_t) * (size_t)nbuckets, hipMemcpyDeviceToHost, st));
+        SKM_HIP(hipStreamSynchronize(st));
+        memcpy(h_counts, ctx->h_pinned, sizeof(int64_t) * (size_t)nbuckets);
+    }
     return SKM_OK;
 }
 
@@ -261,8 +286,8 @@ static uint32_t table_size_for(int64_t ncols)
 }
 
 template <typename K>
-int postings_impl(skm_ctx *ctx, int key_bits, int64_t n, const K *d_codes, const uint64_t *d_rowcount, int64_t *h_out4,
-                  uint32_t *d_cols_start, uint64_t *d_post, K *d_tab_keys, uint32_t *d_tab_vals)
+int postings_impl(skm_ctx *ctx, int key_bits, int64_t n, const K *d_codes, const uint64_t *d_rowcount, int64_t *d_out4,
+                  int64_t *h_out4, uint32_t *d_cols_start, uint64_t *d_post, K *d_tab_keys, uint32_t *d_tab_vals)
 {
     hipStream_t st = ctx->stream;
     void *p;
@@ -281,50 +306,53 @@ int postings_impl(skm_ctx *ctx, int key_bits, int64_t n, const K *d_codes, const
         SKM_PROF(ctx, "rocprim_scan_shared_kmers");
         SKM_HIP(rocprim::inclusive_scan(p, tmp, in, incl, (size_t)n, rocprim::plus<uint64_t>(), st));
     }
-    uint64_t *h = (uint64_t *)ctx->h_pinned;
-    SKM_HIP(hipMemcpyAsync(h, incl + (n - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    SKM_HIP(hipStreamSynchronize(st));
-    const int64_t npost = (int64_t)(uint32_t)h[0], ncols_ns = (int64_t)(h[0] >> 32);
-    const uint32_t tsize = table_size_for(ncols_ns);
-    SKM_HIP(hipMemsetAsync(d_tab_vals, 0xFF, sizeof(uint32_t) * (size_t)tsize, st));
+    // sizes stay on the device (d_out4); the table's value words are cleared over their whole capacity because the
+    // size actually used (a power of two >= 2 x shared columns) is only known there
+    k_owner_sizes<<<1, 1, 0, st>>>(n, incl, d_out4);
+    SKM_HIP(hipMemsetAsync(d_tab_vals, 0xFF, sizeof(uint32_t) * (size_t)table_size_for(n / 2), st));
     {
         SKM_PROF(ctx, "k_bucket_emit");
         k_bucket_emit<K><<<skm_grid_cap(ctx, skm_ceil_div(n, BLK), 16), BLK, 0, st>>>(n, skeys, sidx, incl, d_rowcount,
-                                                                                   d_cols_start, d_post, tsize, d_tab_keys,
+                                                                                   d_cols_start, d_post, d_out4, d_tab_keys,
                                                                                    d_tab_vals);
     }
     SKM_TRY(skm_check_launch("k_bucket_emit"));
-    h_out4[0] = (n - npost) + ncols_ns;  // distinct k-mers this owner holds, singletons included
-    h_out4[1] = ncols_ns;
-    h_out4[2] = npost;
-    h_out4[3] = (int64_t)tsize;
+    if (h_out4) {
+        SKM_HIP(hipMemcpyAsync(ctx->h_pinned, d_out4, sizeof(int64_t) * 4, hipMemcpyDeviceToHost, st));
+        SKM_HIP(hipStreamSynchronize(st));
+        memcpy(h_out4, ctx->h_pinned, sizeof(int64_t) * 4);
+    }
     return SKM_OK;
 }
 
 }  // namespace
 
-extern "C" int skm_bucket_partition(skm_ctx *ctx, int code_bits, int nbuckets, int64_t n, int64_t nnz,
+extern "C" int skm_bucket_partition(skm_ctx *ctx, int code_bits, int nbuckets, int64_t n, int64_t cap_entries,
                                     const int64_t *d_rowptr, const void *d_codes, const uint32_t *d_counts,
-                                    int64_t row_base, void *d_out_codes, uint64_t *d_out_rowcount, int64_t *h_counts)
+                                    int64_t row_base, void *d_out_codes, uint64_t *d_out_rowcount, int64_t *d_out_counts,
+                                    int64_t *h_counts)
 {
-    SKM_REQUIRE(ctx && h_counts && n >= 0 && nnz >= 0 && row_base >= 0, SKM_E_BADARG, "skm_bucket_partition: bad argument");
+    SKM_REQUIRE(ctx && d_out_counts && n >= 0 && cap_entries >= 0 && row_base >= 0, SKM_E_BADARG, "skm_bucket_partition: bad argument");
     SKM_REQUIRE(code_bits == 32 || code_bits == 64, SKM_E_BADARG, "skm_bucket_partition: code_bits must be 32 or 64");
     SKM_REQUIRE(nbuckets >= 1 && nbuckets <= SKM_MAX_RANKS, SKM_E_BADARG, "skm_bucket_partition: 1 <= nbuckets <= %d",
                 SKM_MAX_RANKS);
-    SKM_REQUIRE(nnz < ((int64_t)1 << 32) - 1 && row_base + n < ((int64_t)1 << 32) - 1, SKM_E_OVERFLOW,
-                "skm_bucket_partition: nnz or row index >= 2^32");
-    for (int b = 0; b < nbuckets; ++b)
-        h_counts[b] = 0;
-    if (nnz == 0)
+    SKM_REQUIRE(cap_entries < ((int64_t)1 << 30) && row_base + n < ((int64_t)1 << 32) - 1, SKM_E_OVERFLOW,
+                "skm_bucket_partition: 2^30 entries or more in one shard, or a row index >= 2^32");
+    SKM_HIP(hipSetDevice(ctx->device));
+    if (h_counts)
+        for (int b = 0; b < nbuckets; ++b)
+            h_counts[b] = 0;
+    if (n == 0 || cap_entries == 0) {
+        SKM_HIP(hipMemsetAsync(d_out_counts, 0, sizeof(int64_t) * (size_t)nbuckets, ctx->stream));
         return SKM_OK;
+    }
     SKM_REQUIRE(d_rowptr && d_codes && d_counts && d_out_codes && d_out_rowcount, SKM_E_BADARG,
                 "skm_bucket_partition: null array");
-    SKM_HIP(hipSetDevice(ctx->device));
     if (code_bits == 32)
-        return partition_impl<uint32_t>(ctx, nbuckets, n, nnz, d_rowptr, (const uint32_t *)d_codes, d_counts, row_base,
-                                        (uint32_t *)d_out_codes, d_out_rowcount, h_counts);
-    return partition_impl<uint64_t>(ctx, nbuckets, n, nnz, d_rowptr, (const uint64_t *)d_codes, d_counts, row_base,
-                                    (uint64_t *)d_out_codes, d_out_rowcount, h_counts);
+        return partition_impl<uint32_t>(ctx, nbuckets, n, cap_entries, d_rowptr, (const uint32_t *)d_codes, d_counts, row_base,
+                                        (uint32_t *)d_out_codes, d_out_rowcount, d_out_counts, h_counts);
+    return partition_impl<uint64_t>(ctx, nbuckets, n, cap_entries, d_rowptr, (const uint64_t *)d_codes, d_counts, row_base,
+                                    (uint64_t *)d_out_codes, d_out_rowcount, d_out_counts, h_counts);
 }
 
 extern "C" int64_t skm_bucket_table_capacity(int64_t nrecv)
@@ -332,28 +360,40 @@ extern "C" int64_t skm_bucket_table_capacity(int64_t nrecv)
     return (int64_t)table_size_for(nrecv / 2);  // a shared column has at least two entries
 }
 
-extern "C" int skm_bucket_postings(skm_ctx *ctx, int code_bits, int key_bits, int64_t nrecv, const void *d_codes,
-                                   const uint64_t *d_rowcount, int64_t *h_out4, uint32_t *d_cols_start, uint64_t *d_post,
-                                   void *d_tab_keys, uint32_t *d_tab_vals)
+namespace {
+__global__ void k_empty_owner(int64_t *out4, uint32_t *tab_vals)
 {
-    SKM_REQUIRE(ctx && h_out4 && nrecv >= 0, SKM_E_BADARG, "skm_bucket_postings: bad argument");
+    out4[0] = out4[1] = out4[2] = 0;
+    out4[3] = 2;  // an empty table of the minimum size, so that every owner contributes one
+    tab_vals[0] = tab_vals[1] = 0xFFFFFFFFu;
+}
+}  // namespace
+
+extern "C" int skm_bucket_postings(skm_ctx *ctx, int code_bits, int key_bits, int64_t nrecv, const void *d_codes,
+                                   const uint64_t *d_rowcount, int64_t *d_out4, int64_t *h_out4, uint32_t *d_cols_start,
+                                   uint64_t *d_post, void *d_tab_keys, uint32_t *d_tab_vals)
+{
+    SKM_REQUIRE(ctx && d_out4 && nrecv >= 0, SKM_E_BADARG, "skm_bucket_postings: bad argument");
     SKM_REQUIRE(code_bits == 32 || code_bits == 64, SKM_E_BADARG, "skm_bucket_postings: code_bits must be 32 or 64");
     SKM_REQUIRE(nrecv < ((int64_t)1 << 31), SKM_E_OVERFLOW, "skm_bucket_postings: more than 2^31 entries for one owner");
-    h_out4[0] = h_out4[1] = h_out4[2] = 0;
-    h_out4[3] = 2;
     SKM_REQUIRE(d_tab_keys && d_tab_vals, SKM_E_BADARG, "skm_bucket_postings: null table");
     SKM_HIP(hipSetDevice(ctx->device));
-    if (nrecv == 0) {  // an empty table of the minimum size, so that every owner contributes one
-        SKM_HIP(hipMemsetAsync(d_tab_vals, 0xFF, sizeof(uint32_t) * 2, ctx->stream));
+    if (nrecv == 0) {
+        k_empty_owner<<<1, 1, 0, ctx->stream>>>(d_out4, d_tab_vals);
+        SKM_TRY(skm_check_launch("k_empty_owner"));
+        if (h_out4) {
+            h_out4[0] = h_out4[1] = h_out4[2] = 0;
+            h_out4[3] = 2;
+        }
         return SKM_OK;
     }
     SKM_REQUIRE(d_codes && d_rowcount && d_cols_start && d_post, SKM_E_BADARG, "skm_bucket_postings: null array");
     if (key_bits <= 0 || key_bits > code_bits)
         key_bits = code_bits;
     if (code_bits == 32)
-        return postings_impl<uint32_t>(ctx, key_bits, nrecv, (const uint32_t *)d_codes, d_rowcount, h_out4, d_cols_start,
+        return postings_impl<uint32_t>(ctx, key_bits, nrecv, (const uint32_t *)d_codes, d_rowcount, d_out4, h_out4, d_cols_start,
                                        d_post, (uint32_t *)d_tab_keys, d_tab_vals);
-    return postings_impl<uint64_t>(ctx, key_bits, nrecv, (const uint64_t *)d_codes, d_rowcount, h_out4, d_cols_start,
+    return postings_impl<uint64_t>(ctx, key_bits, nrecv, (const uint64_t *)d_codes, d_rowcount, d_out4, h_out4, d_cols_start,
                                    d_post, (uint64_t *)d_tab_keys, d_tab_vals);
 }
 

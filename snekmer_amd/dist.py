@@ -172,6 +172,17 @@ class RcclExchange:
         self.ctx.call("skm_allgatherv", _p(mine.ptr), sizes.ctypes.data_as(_p), _p(gathered.ptr))
         return gathered.download(self.world * vals.size).reshape(self.world, vals.size)
 
+    def allgather_i64_dev(self, d_vals, count: int) -> np.ndarray:
+        """The same for `count` int64 values that already sit on the device (sizes a kernel just produced): gathered
+        device to device, then ONE copy to the host -> [world, count].  One host round trip per size exchange."""
+        key = ("dev", count)
+        if key not in self._small:
+            self._small[key] = self.ctx.empty(self.world * count, np.int64)
+        gathered = self._small[key]
+        sizes = np.full(self.world, 8 * count, dtype=np.int64)
+        self.ctx.call("skm_allgatherv", _p(d_vals.ptr), sizes.ctypes.data_as(_p), _p(gathered.ptr))
+        return gathered.download(self.world * count).reshape(self.world, count)
+
     def allgatherv(self, d_send, nbytes_per_rank: Sequence[int], d_recv):
         sizes = np.asarray(nbytes_per_rank, dtype=np.int64)
         self.ctx.call("skm_allgatherv", _p(d_send.ptr), sizes.ctypes.data_as(_p), _p(d_recv.ptr))
@@ -274,22 +285,38 @@ class ShardedPipeline:
             return self._exchange_replicated(shard_batch)
         return self._exchange_distributed(shard_batch)
 
+    def _gather_sizes(self, d_vals, count: int) -> np.ndarray:
+        """[world, count] int64 from `count` device-resident values per rank: one host round trip when the exchange can
+        gather device buffers (RcclExchange), else a download followed by the exchange's host collective (test doubles)."""
+        if hasattr(self.ex, "allgather_i64_dev"):
+            return self.ex.allgather_i64_dev(d_vals, count)
+        return self.ex.allgather_i64(d_vals.download(count))
+
     def _exchange_distributed(self, shard_batch):
+        """TWO host round trips per step (the [src, dst] entry counts and the owners' sizes, each gathered device to
+        device and read back once): count stage, owner grouping and owner-side postings never wait for the device
+        (sizes stay in d_rowptr[n] / device counters, launches cover the shard's capacity)."""
         e, ctx, ex, G, me = self.engine, self.ctx, self.ex, self.world, self.rank
         lo, hi = self.bounds[me]
         nloc = hi - lo
         cb = np.dtype(self.code_dtype).itemsize
-        self.local = loc = e.count_csr(ctx, shard_batch, self.lut, self.k, out=self.local)
-        # 1. entries grouped by owner rank
-        p_codes = self._need("p_codes", loc.nnz, self.code_dtype)
-        p_rc = self._need("p_rc", loc.nnz, np.uint64)
-        counts = np.zeros(G, dtype=np.int64)
-        ctx.call("skm_bucket_partition", self.code_bits, G, _i64(loc.n), _i64(loc.nnz), _p(loc.rowptr.ptr),
-                 _p(loc.codes.ptr), _p(loc.counts.ptr), _i64(lo), _p(p_codes.ptr), _p(p_rc.ptr), counts.ctypes.data_as(_p))
-        # norms of the local rows: independent of the exchange, queued before the first host round trip
         rn = self._need("rn_local", nloc + 4, np.float32)
-        e.row_norms(ctx, nloc, loc.rowptr, loc.counts, out=rn)
-        cmat = ex.allgather_i64(counts)  # collective 1: [src, dst] entry counts
+        d_counts = self._need("d_counts", G, np.int64)
+        if shard_batch.n >= 1 and shard_batch.total >= 1:
+            # counts + norms of the local rows in one call that reads nothing back (skm_vectorize_csr, count stage only)
+            self.local, _ = e.vectorize_counts(ctx, shard_batch, self.lut, self.k, csr=self.local, rnorm=rn)
+            loc, cap = self.local, shard_batch.total + 1
+        else:  # an empty shard (a world larger than the batch)
+            self.local = loc = e.count_csr(ctx, shard_batch, self.lut, self.k, out=self.local)
+            e.row_norms(ctx, nloc, loc.rowptr, loc.counts, out=rn)
+            cap = 1
+        # 1. entries grouped by owner rank (sized by the capacity; the entry count stays on the device)
+        p_codes = self._need("p_codes", cap, self.code_dtype)
+        p_rc = self._need("p_rc", cap, np.uint64)
+        ctx.call("skm_bucket_partition", self.code_bits, G, _i64(loc.n), _i64(cap), _p(loc.rowptr.ptr),
+                 _p(loc.codes.ptr), _p(loc.counts.ptr), _i64(lo), _p(p_codes.ptr), _p(p_rc.ptr), _p(d_counts.ptr), _p(None))
+        cmat = self._gather_sizes(d_counts, G)  # collective 1 + round trip 1: [src, dst] entry counts
+        loc.nnz = int(cmat[me, :].sum())
         self.nnz_total = int(cmat.sum())
         nrecv = int(cmat[:, me].sum())
         # 2. one grouped all-to-all (codes + posting words): every owner receives its k-mers' entries from all
@@ -303,10 +330,11 @@ class ShardedPipeline:
         tcap = int(ctx.lib.skm_bucket_table_capacity(nrecv))
         o_tkeys = self._need("o_tkeys", tcap, self.code_dtype)
         o_tvals = self._need("o_tvals", tcap, np.uint32)
-        out4 = np.zeros(4, dtype=np.int64)
+        d_out4 = self._need("d_out4", 4, np.int64)
         ctx.call("skm_bucket_postings", self.code_bits, e.key_bits(self.lut.nsym, self.k), _i64(nrecv), _p(r_codes.ptr),
-                 _p(r_rc.ptr), out4.ctypes.data_as(_p), _p(o_start.ptr), _p(o_post.ptr), _p(o_tkeys.ptr), _p(o_tvals.ptr))
-        meta = ex.allgather_i64(out4)  # collective 3: [rank, (distinct, shared columns, postings, table slots)]
+                 _p(r_rc.ptr), _p(d_out4.ptr), _p(None), _p(o_start.ptr), _p(o_post.ptr), _p(o_tkeys.ptr), _p(o_tvals.ptr))
+        # collective 3 + round trip 2: [rank, (distinct, shared columns, postings, table slots)]
+        meta = self._gather_sizes(d_out4, 4)
         ncols, npost, tsize = meta[:, 1].copy(), meta[:, 2].copy(), meta[:, 3].copy()
         tot_cols, tot_post, tot_slots = int(ncols.sum()), int(npost.sum()), int(tsize.sum())
         # 4. one grouped all-gather: every rank gets all postings, column starts, tables and row norms

@@ -818,8 +818,12 @@ def test_owner_partition_postings_lookup_match_host_statements(ctx, name):
     p = C.c_void_p
     d_codes, d_rc = ctx.empty(nnz, dt), ctx.empty(nnz, np.uint64)
     h_counts = np.zeros(nb, dtype=np.int64)
-    ctx.call("skm_bucket_partition", csr.code_bits, nb, C.c_int64(csr.n), C.c_int64(nnz), p(csr.rowptr.ptr), p(csr.codes.ptr),
-             p(csr.counts.ptr), C.c_int64(base), p(d_codes.ptr), p(d_rc.ptr), h_counts.ctypes.data_as(p))
+    d_cnt = ctx.empty(nb, np.int64)
+    # capacity larger than the entry count: the count is read on the device (d_rowptr[n])
+    d_codes, d_rc = ctx.empty(nnz + 1000, dt), ctx.empty(nnz + 1000, np.uint64)
+    ctx.call("skm_bucket_partition", csr.code_bits, nb, C.c_int64(csr.n), C.c_int64(nnz + 1000), p(csr.rowptr.ptr), p(csr.codes.ptr),
+             p(csr.counts.ptr), C.c_int64(base), p(d_codes.ptr), p(d_rc.ptr), p(d_cnt.ptr), h_counts.ctypes.data_as(p))
+    assert (d_cnt.download(nb) == h_counts).all()
     own = owner_host(codes, nb)
     order = np.argsort(own, kind="stable")
     rows = np.repeat(np.arange(csr.n, dtype=np.uint64) + np.uint64(base), np.diff(rowptr))
@@ -835,8 +839,10 @@ def test_owner_partition_postings_lookup_match_host_statements(ctx, name):
     o_start, o_post = ctx.empty(nrecv, np.uint32), ctx.empty(nrecv, np.uint64)
     t_keys, t_vals = ctx.empty(cap, dt), ctx.empty(cap, np.uint32)
     out4 = np.zeros(4, dtype=np.int64)
-    ctx.call("skm_bucket_postings", csr.code_bits, 0, C.c_int64(nrecv), p(r_codes.ptr), p(r_rc.ptr), out4.ctypes.data_as(p),
+    d_out4 = ctx.empty(4, np.int64)
+    ctx.call("skm_bucket_postings", csr.code_bits, 0, C.c_int64(nrecv), p(r_codes.ptr), p(r_rc.ptr), p(d_out4.ptr), out4.ctypes.data_as(p),
              p(o_start.ptr), p(o_post.ptr), p(t_keys.ptr), p(t_vals.ptr))
+    assert (d_out4.download(4) == out4).all()
     distinct, h_code, h_start, h_post = postings_host(codes[order][seg], rc[order][seg])
     assert out4[:3].tolist() == [distinct, len(h_code), len(h_post)] and out4[3] >= 2 * len(h_code)
     assert (o_start.download(len(h_code)) == h_start).all() and (o_post.download(len(h_post)) == h_post).all()
@@ -1055,6 +1061,77 @@ def test_sharded_pipeline_two_ranks_on_one_gpu_equals_pipeline(ctx, tmp_path, mo
         rr = np.repeat(np.arange(hi - lo), 5).reshape(-1, 5)
         if ok.any():
             assert np.abs(blk[rr[ok], idx[ok].astype(np.int64)] - val[ok]).max() <= 1e-6
+        covered += hi - lo
+    assert covered == n
+
+
+def _rccl_rank(rank, world, port, n, tmpdir, mode):
+    """One rank of a REAL multi-GPU step: its own GPU (device = rank), RCCL for the data, gloo only to hand the
+    communicator id around."""
+    import torch.distributed as dist
+
+    from snekmer_amd import _hip
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.dist import RcclExchange, ShardedPipeline, shard_bounds_by_residues
+    from snekmer_amd.synth import synth_families
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        A.register_alphabet("red6", A.RED6_GROUPS)
+        ids = [RcclExchange.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx = _hip.Context(rank)
+        ex = RcclExchange(ctx, world, rank, ids[0])
+        lut = A.build_lut("red6")
+        res, off, _ = synth_families(n, 300, family=30, seed=33)
+        bounds = shard_bounds_by_residues(off, world)
+        lo, hi = bounds[rank]
+        shard = engine.SeqBatch(ctx, res[off[lo]:off[hi]], off[lo:hi + 1] - off[lo])
+        sp = ShardedPipeline(ctx, lut, 12, ex, bounds, int(off[-1]), basis=mode)
+        for _ in range(2):
+            out = sp.step(shard)
+        np.save(os.path.join(tmpdir, f"block{rank}.npy"), out.download().reshape(out.shape)[: hi - lo, :n])
+        np.save(os.path.join(tmpdir, f"meta{rank}.npy"), np.asarray([lo, hi, sp.nnz_total, sp.basis.ncols]))
+        idx, val, _ = sp.step_topk(shard, 5)
+        np.save(os.path.join(tmpdir, f"topval{rank}.npy"), val)
+        dist.barrier()
+        ctx.call("skm_comm_destroy")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["distributed", "replicated"])
+def test_sharded_pipeline_two_ranks_over_rccl_on_two_gpus(ctx, tmp_path, mode):
+    """The first thing to run on a multi-GPU node: two fresh processes, one GPU each, ShardedPipeline.step over RCCL
+    (grouped all-to-all + all-gathers on xGMI); the stacked row blocks must equal the single-GPU result bit for bit.
+    SKIPS on the one-GPU boxes the suite normally gets (RCCL refuses two ranks on one device)."""
+    import torch.multiprocessing as mp
+
+    from snekmer_amd import _hip
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+
+    if _hip.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL does not take two ranks on one device)")
+    n, world = 3000, 2
+    port = 29900 + (os.getpid() % 300) + (5 if mode == "replicated" else 0)
+    mp.start_processes(_rccl_rank, args=(world, port, n, str(tmp_path), mode), nprocs=world, join=True, start_method="spawn")
+    lut = A.build_lut("red6")
+    res, off, _ = synth_families(n, 300, family=30, seed=33)
+    ref = engine.Pipeline(ctx, lut, 12)
+    S = ref.step(engine.SeqBatch(ctx, res, off))
+    S = S.download().reshape(S.shape)[:n, :n]
+    covered = 0
+    for r in range(world):
+        lo, hi, nnz, ncols = np.load(tmp_path / f"meta{r}.npy")
+        assert (nnz, ncols) == (ref.csr.nnz, ref.basis.ncols)
+        assert (np.load(tmp_path / f"block{r}.npy") == S[lo:hi]).all()
+        blk = S[lo:hi].copy()
+        blk[np.arange(hi - lo), np.arange(lo, hi)] = -1.0
+        top = np.maximum(-np.sort(-blk, axis=1)[:, :5], 0.0)
+        assert np.abs(np.load(tmp_path / f"topval{r}.npy") - top).max() <= 1e-6
         covered += hi - lo
     assert covered == n
 
