@@ -38,6 +38,7 @@ extern "C" int skm_create(int device_id, skm_ctx **out_ctx)
     ctx->num_cus = prop.multiProcessorCount;
     SKM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     SKM_HIP(hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocDefault));
+    memset(ctx->h_pinned, 0, 4096);  // (offset 2048: the previous cosine call's heavy-row count, skm_cosine_csr.hip)
     *out_ctx = ctx;
     return SKM_OK;
 }

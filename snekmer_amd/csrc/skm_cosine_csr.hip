@@ -44,7 +44,10 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <algorithm>
+
 #include "skm_common.h"
+#include "skm_onesweep.h"
 
 namespace {
 
@@ -511,12 +514,21 @@ constexpr int HEAVY_CH = 32768, HEAVY_TB = 1024, HEAVY_EMAX = 2048, HEAVY_U = 4,
 // 128 KiB tile + 24 KiB of list state: this kernel (like the writer's 128 KiB tile) needs gfx950's 160 KiB of LDS per
 // workgroup; the library is built for gfx950 only (csrc/Makefile).
 static_assert(HEAVY_CH * 4 + 3 * HEAVY_EMAX * 4 + 64 <= 160 * 1024, "k_cosine_heavy needs 160 KiB of LDS (gfx950)");
+constexpr int HEAVYP_CH = 32768, HEAVYP_TB = 1024, HEAVYP_EMAX = 2048;  // the PANEL form (16384 / 512 / 1024, two workgroups per CU, measured slower: 15.3 vs 13.8 ms)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "libsnekmer_hip is written for gfx950 (MI355X): 160 KiB LDS tiles, gfx950 MFMA shapes"
 #endif
 
-template <int MODE, bool VEC, typename PW>
-__global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__restrict__ xrowptr,
+#include "skm_heavy_panel.h"
+
+// PANEL: the heavy rows come in min-hash order (pb.perm), blocks of PB_ROWS of them own int8 panels whose product G
+// already holds the dot products over the block's long-list columns (skm_heavy_panel.h): those columns are skipped
+// here and the row of G is added through the block's row list J.
+// HC columns per step, HT threads, HE list entries: (32768, 1024, 2048) = one workgroup per CU, the general form;
+// (16384, 512, 1024) = the PANEL form: two workgroups per CU (what remains to walk beside a panel is a few short lists:
+// the row is bound by the latency of its steps, which a second row in flight hides)
+template <int MODE, bool VEC, typename PW, bool PANEL, int HC, int HT, int HE>
+__global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__ xrowptr,
                                                            const uint32_t *__restrict__ xcolidx,
                                                            const uint32_t *__restrict__ xcounts,
                                                            const float *__restrict__ xrnorm, int64_t m,
@@ -526,25 +538,37 @@ __global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__rest
                                                            const float *__restrict__ yrnorm, int64_t row0, int64_t rbase,
                                                            const uint32_t *__restrict__ row_list,
                                                            const uint32_t *__restrict__ row_count,
-                                                           uint32_t *__restrict__ g_len, float *__restrict__ out, int64_t ld)
+                                                           uint32_t *__restrict__ g_len, float *__restrict__ out, int64_t ld,
+                                                           panel_bufs pnl)
 {
-    constexpr int CHH = HEAVY_CH, TBH = HEAVY_TB, NW = HEAVY_TB / 64, U = HEAVY_U;
+    constexpr int CHH = HC, TBH = HT, NW = HT / 64, U = HEAVY_U;
+    static_assert(HC * 4 + 3 * HE * 4 + 1024 <= (HT == 1024 ? 160 : 80) * 1024, "LDS budget of k_cosine_heavy");
     __shared__ __attribute__((aligned(16))) int s_acc[CHH];
-    __shared__ uint32_t s_cur[HEAVY_EMAX], s_end[HEAVY_EMAX], s_val[HEAVY_EMAX];
+    __shared__ uint32_t s_cur[HE], s_end[HE], s_val[HE];
     __shared__ uint32_t s_nlong, s_nshort, s_self;
+    __shared__ uint32_t s_jb[PB_STEPS + 2];  // PANEL: first entry of the block's row list J at or after every column step's start
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t cnt = *row_count;
     for (int z = tid; z < CHH / 4; z += TBH)
         reinterpret_cast<int4 *>(s_acc)[z] = make_int4(0, 0, 0, 0);
     for (uint32_t idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
-        const int64_t r = rbase + row_list[idx];  // row counted from row0 (g_len, out)
+        const int64_t r = rbase + row_list[PANEL ? pnl.perm[idx] : idx];  // row counted from row0 (g_len, out)
         const int64_t i = row0 + r;
+        // the row's panel block (sorted position idx), if it has one with columns in it
+        const uint32_t pblk = idx / (uint32_t)PB_ROWS, prow = idx % (uint32_t)PB_ROWS;
+        const uint32_t pK = (PANEL && pblk < (uint32_t)pnl.nb) ? pnl.meta[pblk * 4 + 0] : 0u;
+        const uint32_t pJ = pK ? pnl.meta[pblk * 4 + 1] : 0u;
+        if (PANEL ? pK == 0u : g_len[r] == G_DONE_ROW)  // uniform.  PANEL form: only rows with a panel (the general
+            continue;                                    // form, launched behind it, takes the others); general form: not again
         __syncthreads();  // the previous row's tile and lists are no longer in use
         if (tid == 0) {
             s_nlong = 0;
             s_nshort = 0;
             s_self = 0;
         }
+        static_assert(!PANEL || CHH == PB_STEP_COLS, "k_panel_rows cuts J at multiples of PB_STEP_COLS");
+        if (PANEL && pJ && tid <= PB_STEPS)  // J is sorted: the part of it inside column step t is [s_jb[t], s_jb[t + 1])
+            s_jb[tid] = pnl.jbound[(size_t)pblk * (PB_STEPS + 1) + tid];
         __syncthreads();
         // ---- the row's shared non-zeros -> (cursor, end, count); lists of more than 64 postings are stored from the
         // front of the arrays, the others from the back
@@ -561,6 +585,8 @@ __global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__rest
                 else {
                     pb = ycolptr[c];
                     pe = ycolptr[c + 1];
+                    if (PANEL && pK && pe - pb > PB_DF_LONG && pe - pb <= PB_DF_MAX && panel_lookup(pnl, pblk, c) != PB_NOSLOT)
+                        pb = pe = 0;  // this column's products are in the block's G
                 }
             }
             const bool is_long = pe - pb > 64u, is_short = pe > pb && !is_long;
@@ -579,9 +605,9 @@ __global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__rest
             if (is_long)
                 slot = basel + (uint32_t)__popcll(bl & below);
             else if (is_short)
-                slot = (uint32_t)HEAVY_EMAX - 1u - (bases + (uint32_t)__popcll(bs & below));
+                slot = (uint32_t)HE - 1u - (bases + (uint32_t)__popcll(bs & below));
             // (on overflow the counters keep counting, nothing is stored out of range, and the row is skipped below)
-            if (slot < (uint32_t)HEAVY_EMAX) {
+            if (slot < (uint32_t)HE) {
                 s_cur[slot] = pb;
                 s_end[slot] = pe;
                 s_val[slot] = v;
@@ -594,9 +620,29 @@ __global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__rest
             atomicAdd(&s_self, self);
         __syncthreads();
         const uint32_t nlong = s_nlong, nshort = s_nshort;
-        if (nlong + nshort > (uint32_t)HEAVY_EMAX)  // uniform: the row stays flagged (cursor kernel)
+        if (nlong + nshort > (uint32_t)HE)  // uniform: the row stays flagged (cursor kernel)
             continue;
         const float ri = xrnorm[i];
+        // PANEL: the row of G reaches the tile through registers that are loaded one step ahead, in front of the previous
+        // step's stores: a wait for a load also waits for every store issued before it, so loads issued behind the
+        // stores would expose the stores' latency in every step
+        constexpr int GP = PANEL ? 2048 / TBH : 1;
+        int gv[GP];
+        uint32_t gj[GP];
+        const int *grow = PANEL ? pnl.G + ((size_t)pblk * PB_ROWS + prow) * PB_JMAX : nullptr;
+        const uint32_t *gjl = PANEL ? pnl.jlist + (size_t)pblk * PB_JMAX : nullptr;
+        auto g_prefetch = [&](uint32_t step) {
+            if (!(PANEL && pJ))
+                return;
+#pragma unroll
+            for (int u = 0; u < GP; ++u) {
+                const uint32_t q = s_jb[step] + (uint32_t)(tid + u * TBH);
+                const bool ok = q < s_jb[step + 1];
+                gv[u] = ok ? grow[q] : 0;
+                gj[u] = gjl[ok ? q : 0u];
+            }
+        };
+        g_prefetch(0);
         for (int64_t j0 = 0; j0 < m; j0 += CHH) {
             const uint32_t j0u = (uint32_t)j0;
             const uint32_t j1u = (uint32_t)min(j0 + (int64_t)CHH, m);
@@ -661,7 +707,7 @@ __global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__rest
             for (uint32_t l0 = (uint32_t)wid * 4u; l0 < nshort; l0 += NW * 4u) {
                 const uint32_t l = l0 + (uint32_t)(lane >> 4), gl = (uint32_t)(lane & 15);
                 const bool have = l < nshort;
-                const uint32_t slot = (uint32_t)HEAVY_EMAX - 1u - (have ? l : 0u);
+                const uint32_t slot = (uint32_t)HE - 1u - (have ? l : 0u);
                 uint32_t p = s_cur[slot];
                 const uint32_t pe = have ? s_end[slot] : 0u, v = s_val[slot];
                 bool active = have;
@@ -685,7 +731,21 @@ __global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__rest
             }
             if (tid == 0 && (uint32_t)i >= j0u && (uint32_t)i < j1u && s_self)
                 atomicAdd(&s_acc[(uint32_t)i - j0u], (int)s_self);
+            const uint32_t step = (uint32_t)(j0 / CHH);  // PANEL: m <= 2^20, at most PB_STEPS steps
+            if (PANEL && pJ) {  // the panel's share: row prow of G, scattered through the block's row list (ascending)
+#pragma unroll
+                for (int u = 0; u < GP; ++u)
+                    if (gv[u])
+                        atomicAdd(&s_acc[gj[u] - j0u], gv[u]);
+                for (uint32_t q = s_jb[step] + (uint32_t)(tid + GP * TBH); q < s_jb[step + 1]; q += TBH) {  // more than 2048 rows of J in one step
+                    const int g = grow[q];
+                    if (g)
+                        atomicAdd(&s_acc[gjl[q] - j0u], g);
+                }
+            }
             __syncthreads();
+            if (j0 + CHH < m)
+                g_prefetch(step + 1);  // in front of this step's stores
             // ---- scale, store, clear (the writer's store shape: 16-byte non-temporal stores, 1 KiB per wave instruction)
 #pragma unroll
             for (int q = 0; q < CHH / 4 / TBH; ++q) {
@@ -695,15 +755,20 @@ __global__ __launch_bounds__(HEAVY_TB) void k_cosine_heavy(const int64_t *__rest
                     break;
                 const int4 a = reinterpret_cast<int4 *>(s_acc)[z];
                 reinterpret_cast<int4 *>(s_acc)[z] = make_int4(0, 0, 0, 0);
+                // the neighbours' norms are only fetched for cells that hold a dot product: even a heavy row is mostly
+                // zeros (a family of 5 000 in 100 000 columns), and a load per store also makes every wait for a load
+                // drain the stores in front of it
                 float rj[4] = {0.f, 0.f, 0.f, 0.f};
-                if (VEC && jc + 3 < m) {
-                    const float4 t4 = *reinterpret_cast<const float4 *>(yrnorm + jc);
-                    rj[0] = t4.x, rj[1] = t4.y, rj[2] = t4.z, rj[3] = t4.w;
-                } else {
+                if ((a.x | a.y | a.z | a.w) != 0) {
+                    if (VEC && jc + 3 < m) {
+                        const float4 t4 = *reinterpret_cast<const float4 *>(yrnorm + jc);
+                        rj[0] = t4.x, rj[1] = t4.y, rj[2] = t4.z, rj[3] = t4.w;
+                    } else {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (jc + u < m)
-                            rj[u] = yrnorm[jc + u];
+                        for (int u = 0; u < 4; ++u)
+                            if (jc + u < m)
+                                rj[u] = yrnorm[jc + u];
+                    }
                 }
                 float o[4] = {(float)a.x * ri * rj[0], (float)a.y * ri * rj[1], (float)a.z * ri * rj[2], (float)a.w * ri * rj[3]};
                 if (MODE == 1) {
@@ -1160,6 +1225,113 @@ int overlap_streams(skm_ctx *ctx)
 }  // namespace
 
 namespace {
+// The panel pipeline is a dozen launches: worth it when thousands of rows are heavy, pure overhead on a batch of small
+// families (a few hundred heavy rows).  The number of heavy rows is only known on the device, so the decision uses the
+// count the PREVIOUS list-path call on this context left in pinned memory (copied asynchronously, never waited for):
+// streams of similar batches adapt after one step, and the choice only moves work between two exact kernels.
+// SKM_HEAVY_PANEL=1 / 0 force it on / off (tests, A/B timing).
+bool heavy_panels_wanted(skm_ctx *ctx, int64_t nrows, int64_t m)
+{
+    if (m > ((int64_t)1 << 20) || nrows < PB_ROWS)
+        return false;
+    const char *e = getenv("SKM_HEAVY_PANEL");
+    if (e)
+        return atoi(e) != 0;
+    const uint32_t last = *(volatile uint32_t *)((uint8_t *)ctx->h_pinned + 2048);
+    return last >= 4096u && last != 0xFFFFFFFFu;
+}
+
+template <typename PW>
+int heavy_panels_run(skm_ctx *ctx, const int64_t *d_xrowptr, const uint32_t *d_xcolidx, const uint32_t *d_xcounts,
+                     const uint32_t *d_ycolptr, const PW *d_ypost, const uint32_t *d_ypostcnt, int64_t m, int64_t row0,
+                     int64_t rbase, int64_t nrows, const uint32_t *row_list, const uint32_t *row_count, panel_bufs *out,
+                     hipStream_t st)
+{
+    panel_bufs pb = {};
+    pb.nb = (int)std::min<int64_t>(skm_ceil_div(nrows, PB_ROWS), PB_MAXBLOCKS);
+    pb.mwords = (uint32_t)((m + 31) / 32);
+    const size_t hcap = (size_t)nrows + 8, nb = (size_t)pb.nb;
+    // one scratch slot, carved up (every piece 256-byte aligned)
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    const size_t o_key = take(4 * hcap), o_skey = take(4 * hcap), o_perm = take(4 * hcap), o_ktmp = take(4 * hcap),
+                 o_vtmp = take(4 * hcap), o_cnt = take(8), o_dk = take(4 * nb * PB_DICT), o_ds = take(4 * nb * PB_DICT),
+                 o_cols = take(4 * nb * PB_KMAX), o_bad = take(nb * PB_KMAX), o_meta = take(16 * nb),
+                 o_jl = take(4 * nb * PB_JMAX), o_jb = take(4 * nb * (PB_STEPS + 1)), o_A = take(nb * PB_ROWS * PB_KMAX),
+                 o_G = take(4 * nb * (size_t)PB_ROWS * PB_JMAX),
+                 o_state = take(skm_onesweep::state_bytes((int64_t)hcap, 8192, 4) + skm_onesweep::state_bytes((int64_t)hcap, 2048, 4));
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_G, off, &p));
+    uint8_t *base = (uint8_t *)p;
+    pb.key = (uint32_t *)(base + o_key);
+    pb.skey = (uint32_t *)(base + o_skey);
+    pb.perm = (uint32_t *)(base + o_perm);
+    pb.count64 = (int64_t *)(base + o_cnt);
+    pb.dict_key = (uint32_t *)(base + o_dk);
+    pb.dict_slot = (uint32_t *)(base + o_ds);
+    pb.cols = (uint32_t *)(base + o_cols);
+    pb.bad = base + o_bad;
+    pb.meta = (uint32_t *)(base + o_meta);
+    pb.jlist = (uint32_t *)(base + o_jl);
+    pb.jbound = (uint32_t *)(base + o_jb);
+    pb.A = (int8_t *)(base + o_A);
+    pb.G = (int *)(base + o_G);
+    hipStream_t saved = ctx->stream;
+    ctx->stream = st;  // the sort and the profiling scopes follow the context's stream
+    int rc = SKM_OK;
+    do {
+        {
+            SKM_PROF(ctx, "k_panel_key");
+            k_panel_key<PW><<<skm_grid_cap(ctx, skm_ceil_div(nrows, 4), 4), 256, 0, st>>>(d_xrowptr, d_xcolidx, d_ycolptr, d_ypost, row0, rbase, row_list,
+                                                                                   row_count, pb);
+        }
+        if ((rc = skm_check_launch("k_panel_key")) != SKM_OK)
+            break;
+        if ((rc = skm_onesweep::sort_pairs_dev<uint32_t>(ctx, pb.count64, (int64_t)hcap, pb.key, pb.skey, pb.perm,
+                                                         (uint32_t *)(base + o_ktmp), (uint32_t *)(base + o_vtmp), base + o_state, 32,
+                                                         "onesweep_sort_heavy_rows")) != SKM_OK)
+            break;
+        {
+            SKM_PROF(ctx, "k_panel_dict");
+            k_panel_dict<<<pb.nb, 1024, 0, st>>>(d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, row0, rbase, row_list, row_count, pb);
+        }
+        {
+            SKM_PROF(ctx, "k_panel_rows");
+            auto kern = k_panel_rows<PW>;
+            const size_t lds = sizeof(uint32_t) * (size_t)pb.mwords;
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                skm_set_error("k_panel_rows: %s", hipGetErrorString(e));
+                rc = SKM_E_HIP;
+                break;
+            }
+            kern<<<pb.nb, 1024, lds, st>>>(d_ycolptr, d_ypost, d_ypostcnt, row_count, pb);
+        }
+        {
+            SKM_PROF(ctx, "k_panel_gemm");
+            auto kern = k_panel_gemm<PW>;
+            constexpr size_t lds = (size_t)128 * PG_KP;
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                skm_set_error("k_panel_gemm: %s", hipGetErrorString(e));
+                rc = SKM_E_HIP;
+                break;
+            }
+            kern<<<dim3(PG_CHUNKS, pb.nb), PG_TB, lds, st>>>(d_ycolptr, d_ypost, d_ypostcnt, row_count, pb);
+        }
+        rc = skm_check_launch("k_panel_gemm");
+    } while (0);
+    ctx->stream = saved;
+    *out = pb;
+    return rc;
+}
+}  // namespace
+
+namespace {
 template <typename PW>
 int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx, const uint32_t *d_xcounts,
                     const float *d_xrnorm, int64_t m, int64_t ncols, const uint32_t *d_ycolptr, const PW *d_ypost,
@@ -1374,17 +1546,38 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
             SKM_HIP(hipEventRecord(ctx->sync_events[1 + b], gs));
             SKM_HIP(hipStreamWaitEvent(s_w, ctx->sync_events[1 + b], 0));
         }
+        panel_bufs pnl = {};
+        bool use_panels = false;
+        if constexpr (sizeof(PW) == 8) {
+            if (nblk == 1 && heavy_panels_wanted(ctx, nrows, m)) {
+                SKM_TRY(heavy_panels_run<PW>(ctx, d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, m, row0, b0, bn,
+                                             b_over_list, b_over_count, &pnl, s_w));
+                use_panels = true;
+            }
+        }
         {
             // rows the first pass could not hold: Gram and write fused, one row per workgroup, dense LDS tile
             SKM_PROF_ON(ctx, "k_cosine_heavy", s_w);
 #define SKM_HEAVY(MODE, VEC)                                                                                         \
-    k_cosine_heavy<MODE, VEC, PW><<<skm_grid_cap(ctx, bn, 1), HEAVY_TB, 0, s_w>>>(                                   \
-        d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, d_ypost, d_ypostcnt, d_yrnorm, row0, b0, b_over_list, \
-        b_over_count, g_len, d_out, ld)
+    do {                                                                                                             \
+        if (use_panels) /* rows with a panel: 16384-column steps, two workgroups per CU */                           \
+            k_cosine_heavy<MODE, VEC, PW, true, HEAVYP_CH, HEAVYP_TB, HEAVYP_EMAX><<<skm_grid_cap(ctx, bn, 1), HEAVYP_TB, 0, s_w>>>( \
+                d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, d_ypost, d_ypostcnt, d_yrnorm, row0, b0, b_over_list, \
+                b_over_count, g_len, d_out, ld, pnl);                                                                \
+        /* every row (left): the general form */                                                                     \
+        k_cosine_heavy<MODE, VEC, PW, false, HEAVY_CH, HEAVY_TB, HEAVY_EMAX><<<skm_grid_cap(ctx, bn, 1), HEAVY_TB, 0, s_w>>>( \
+            d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, d_ypost, d_ypostcnt, d_yrnorm, row0, b0, b_over_list, \
+            b_over_count, g_len, d_out, ld, pnl);                                                                    \
+    } while (0)
             SKM_BY_MODE_VEC(SKM_HEAVY);
 #undef SKM_HEAVY
         }
         SKM_TRY(skm_check_launch("k_cosine_heavy"));
+        if (nblk == 1) {
+            // how many rows this call handed on: the next call on this context reads it (without waiting) to decide
+            // whether the panel pipeline is worth its dozen launches (heavy_panels_wanted)
+            SKM_HIP(hipMemcpyAsync((uint8_t *)ctx->h_pinned + 2048, b_over_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s_w));
+        }
         {
             // one output row per workgroup of 1024 threads
             SKM_PROF_ON(ctx, "k_cosine_write", s_w);

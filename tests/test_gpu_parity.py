@@ -1136,6 +1136,80 @@ def test_sharded_pipeline_two_ranks_over_rccl_on_two_gpus(ctx, tmp_path, mode):
     assert covered == n
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_heavy_rows_on_the_matrix_cores_equal_the_walk(ctx, monkeypatch, mode):
+    """SKM_HEAVY_PANEL=1 sends the long-list columns of the heavy rows through int8 panels and an MFMA GEMM
+    (skm_heavy_panel.h); =0 walks every posting list.  Both are exact integer dot products with the same float32
+    scaling, so the matrices must be IDENTICAL, and equal to the oracle's.  The batch has what the panel path must
+    survive: families of thousands (coherent blocks), a family of 3 000-residue sequences (more long columns than a
+    panel holds: the rest is walked), a family whose tandem repeat gives k-mer counts above 127 (bad columns, walked),
+    a low-complexity k-mer in more rows than a panel column may have (df > 8192), small families and loners."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families, synth_skewed
+    from snekmer_amd.utils import pack_sequences
+
+    orc = _oracle()
+    lut = A.build_lut("red6")
+    k = 12
+    rng = np.random.default_rng(91)
+    res, off, _ = synth_skewed(14000, seed=91, max_family=3000)
+    raw = res.tobytes()
+    seqs = [raw[off[i] : off[i + 1]].decode("latin-1") for i in range(14000)]
+    aa = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+
+    def family(root, members, p_sub):
+        out = []
+        for _ in range(members):
+            s = root.copy()
+            msk = rng.random(s.size) < p_sub
+            s[msk] = aa[rng.integers(0, 20, size=int(msk.sum()))]
+            out.append(s.tobytes().decode())
+        return out
+
+    seqs += family(aa[rng.integers(0, 20, size=3000)], 1800, 0.05)                     # more than 1024 long columns
+    unit = aa[rng.integers(0, 20, size=12)]
+    seqs += family(np.concatenate([np.tile(unit, 150), aa[rng.integers(0, 20, size=300)]]), 1700, 0.01)  # counts ~ 140
+    tail = "MKVLAAGIWSTCDEFHNPQRY"
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    for i in range(0, len(seqs), 2):   # half of all rows share the tail's k-mers: df ~ 8 750 > 8192
+        seqs[i] += tail
+    res, off = pack_sequences(seqs)
+    n = len(seqs)
+    batch = engine.SeqBatch(ctx, res, off)
+    pipe = engine.Pipeline(ctx, lut, k)
+    pipe.vectorize(batch)
+    b = pipe.basis
+    ld = (n + 3) // 4 * 4
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SKM_HEAVY_PANEL", flag)
+        S = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, b.ncols_hint(), b.colptr, b.post, pipe.rnorm, mode=mode, ld=ld)
+        if flag == "1":
+            import ctypes as C
+
+            st = (C.c_int64 * 4)()
+            ctx.call("skm_cosine_csr_stats", st)
+            assert st[0] >= 6000  # rows handed to the heavy kernels
+        outs[flag] = S.download().reshape(-1, ld)[:n, :n].copy()
+        del S
+    assert (outs["0"] == outs["1"]).all()
+    # a row block (what one rank computes) through the panels
+    blk = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, b.ncols_hint(), b.colptr, b.post, pipe.rnorm, row0=3000, row1=9000,
+                               mode=mode, ld=ld).download().reshape(-1, ld)[:6000, :n]
+    assert (blk == outs["1"][3000:9000]).all()
+    o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off, threads=0)
+    ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first, threads=0)
+    assert int(o_counts.max()) > 127 and int(odf.max()) > 8192
+    rows = np.sort(rng.choice(n, 300, replace=False))
+    ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), rows)
+    if mode == 1:
+        ref = np.clip(1.0 - ref, 0, 2)
+        ref[np.arange(len(rows)), rows] = 0.0
+    assert np.abs(outs["1"][rows] - ref).max() <= COS_TOL
+
+
 @pytest.mark.cosine_paths
 def test_overlapped_cosine_schedule_equals_default(ctx, monkeypatch):
     """SKM_COSINE_OVERLAP=1 (row blocks; lists built on one CU-masked stream while the previous block

@@ -31,7 +31,7 @@ def main():
     dt = (time.perf_counter() - t0) / steps * 1e3
     prof = ctx.profile_dump()
     print(json.dumps({"n": n, "post_bits": pipe.basis.post_bits, "ms_per_step": dt,
-                      "stages": {k: round(v[1] / steps, 3) for k, v in prof.items() if v[1] / steps > 0.3}}))
+                      "stages": {k: round(v[1] / steps, 3) for k, v in prof.items() if v[1] / steps > 0.05}}))
 
 
 if __name__ == "__main__":
