@@ -659,6 +659,32 @@ def skewed_workload(ctx, engine, alphabet, args, pipe, line):
         "stage_ms_per_step": stages,
         "stage_vs_uniform_families": {k: (v / uniform[k] if uniform.get(k) else None) for k, v in stages.items()},
     }
+    # the heavy rows' long-list columns on the matrix cores (skm_heavy_panel.h): chosen by the library from the
+    # previous step's heavy-row count, so the warm-up steps above switched it on
+    ps = (C.c_int64 * 6)()
+    ctx.call("skm_heavy_panel_stats", ps)
+    gemm_ms = stages.get("k_panel_gemm", 0.0)
+    out["heavy_panels"] = {
+        "used": bool(gemm_ms > 0), "heavy_rows": int(ps[0]), "blocks_of_256_rows": int(ps[1]), "blocks_without_panel": int(ps[2]),
+        "mean_panel_columns": ps[3] / max(ps[1] - ps[2], 1), "mean_panel_rows": ps[4] / max(ps[1] - ps[2], 1),
+        "gemm_int8_ops": int(2 * ps[5]), "gemm_ms": gemm_ms,
+        "mfma_util": (2 * ps[5] / (gemm_ms * 1e-3) / (I8_PEAK_TOPS * 1e12)) if gemm_ms > 0 else None,
+        "mfma_util_note": "k_panel_gemm builds every B tile in LDS from the posting lists (a cursor per column, one thread each) "
+                          "before multiplying: the kernel's time is that fill, not the matrix pipe",
+        "pipeline_ms": sum(v for kk, v in stages.items() if kk.startswith("k_panel_") or kk == "onesweep_sort_heavy_rows"),
+    }
+    # the same batch with the panels off (every posting list walked): what they buy
+    os.environ["SKM_HEAVY_PANEL"] = "0"
+    try:
+        p.step(batch)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            p.step(batch)
+        ctx.sync()
+        out["ms_per_step_without_panels"] = (time.perf_counter() - t1) / 3 * 1e3
+    finally:
+        del os.environ["SKM_HEAVY_PANEL"]
     p.out = None
     return out
 

@@ -251,6 +251,12 @@ int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint
  * [3] = 8-row strips that held a wide row (float64 cursor kernel).  Synchronises the stream. */
 int skm_cosine_csr_stats(skm_ctx *ctx, int64_t *h_out4);
 
+/* Reporting only: the heavy-row panel pipeline of the last list-path skm_cosine_csr call that ran it (rows the first
+ * pass handed on are clustered, blocks of 256 of them get int8 panels over their shared long-list columns and an MFMA
+ * GEMM; skm_cosine_csr.hip).  h_out6 = heavy rows, blocks, blocks without a panel, sum of panel columns, sum of panel
+ * rows, multiply-accumulates of the GEMMs.  Synchronises the stream. */
+int skm_heavy_panel_stats(skm_ctx *ctx, int64_t *h_out6);
+
 /* The reference's metric="jaccard" branch (snekmer/score.py:166-168) is 1 - hamming distance on the
  * binary presence matrix: 1 - (|a| + |b| - 2|a&b|) / ncols.  Given d_out holding the exact
  * intersection sizes |a&b| (skm_cosine_csr on a 0/1 CSR with all norms = 1), rewrite it in place.

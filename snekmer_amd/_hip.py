@@ -96,6 +96,7 @@ _SIGNATURES = {
     ),
     "skm_hamming_similarity_from_gram": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _i64]),
     "skm_cosine_csr_stats": (C.c_int, [_p, _p]),
+    "skm_heavy_panel_stats": (C.c_int, [_p, _p]),
     "skm_setsim_f64": (C.c_int, [_p, C.c_int, _i64, _i64, _i64, _p, _p, _p, _p, _i64, _p, _i64]),
     "skm_pairwise_f64": (C.c_int, [_p, C.c_int, C.c_double, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64]),
     "skm_row_top2": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p]),

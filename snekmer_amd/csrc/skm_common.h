@@ -51,6 +51,9 @@ struct skm_ctx {
     std::vector<hipEvent_t> sync_events;
     int overlap_state = 0;
     std::vector<hipEvent_t> user_events;  // skm_event_record slots, created on first use
+    // last run of the heavy-row panel pipeline (skm_cosine_csr.hip), for skm_heavy_panel_stats: device pointers
+    const uint32_t *panel_meta = nullptr, *panel_rows = nullptr;
+    int panel_nb = 0;
     // RCCL (loaded lazily with dlopen; see skm_comm.hip)
     void *rccl_lib = nullptr;
     void *comm = nullptr;

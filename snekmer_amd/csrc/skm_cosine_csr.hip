@@ -1326,6 +1326,9 @@ int heavy_panels_run(skm_ctx *ctx, const int64_t *d_xrowptr, const uint32_t *d_x
         rc = skm_check_launch("k_panel_gemm");
     } while (0);
     ctx->stream = saved;
+    ctx->panel_meta = pb.meta;
+    ctx->panel_rows = row_count;
+    ctx->panel_nb = pb.nb;
     *out = pb;
     return rc;
 }
@@ -1633,6 +1636,38 @@ extern "C" int skm_cosine_csr_stats(skm_ctx *ctx, int64_t *h_out4)
     h_out4[1] = host.fb_count;
     h_out4[2] = (int64_t)(host.g_counter - host.first_entry);
     h_out4[3] = host.wide_count;
+    return SKM_OK;
+}
+
+// Reporting only (bench.py's skewed workload): what the last panel pipeline of this context did.  h_out6 = heavy rows,
+// blocks of 256 of them, blocks without a panel (their rows were walked in full), sum of panel columns K, sum of panel
+// rows |J|, multiply-accumulates of the panel GEMMs (256 x |J| x K rounded up to 64, per block).  Synchronises the stream.
+extern "C" int skm_heavy_panel_stats(skm_ctx *ctx, int64_t *h_out6)
+{
+    SKM_REQUIRE(ctx && h_out6, SKM_E_BADARG, "skm_heavy_panel_stats: bad argument");
+    for (int q = 0; q < 6; ++q)
+        h_out6[q] = 0;
+    if (!ctx->panel_meta || ctx->panel_nb <= 0)
+        return SKM_OK;
+    SKM_HIP(hipSetDevice(ctx->device));
+    SKM_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> meta(4 * (size_t)ctx->panel_nb);
+    uint32_t rows = 0;
+    SKM_HIP(hipMemcpy(meta.data(), ctx->panel_meta, sizeof(uint32_t) * meta.size(), hipMemcpyDeviceToHost));
+    SKM_HIP(hipMemcpy(&rows, ctx->panel_rows, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const int64_t used = std::min<int64_t>(ctx->panel_nb, ((int64_t)rows + PB_ROWS - 1) / PB_ROWS);
+    h_out6[0] = rows;
+    h_out6[1] = used;
+    for (int64_t b = 0; b < used; ++b) {
+        const int64_t K = meta[4 * b], J = meta[4 * b + 1];
+        if (K == 0) {
+            ++h_out6[2];
+            continue;
+        }
+        h_out6[3] += K;
+        h_out6[4] += J;
+        h_out6[5] += (int64_t)PB_ROWS * J * ((K + 63) / 64 * 64);
+    }
     return SKM_OK;
 }
 
