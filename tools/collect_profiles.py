@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def avg(path, counter):
@@ -26,16 +26,11 @@ def avg(path, counter):
 
 
 shutil.copy(os.path.join(G, "bench.json"), os.path.join(P, f"bench_{tag}.json"))
-def newest_db(d):
-    return sorted((f for f in os.listdir(d) if f.endswith(".db")), key=lambda f: os.path.getmtime(os.path.join(d, f)))[-1]
-
-
-# timed workload only (python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras) and the same with the extras
-for sub, name in (("prof", f"{tag}_kernel_stats.csv"), ("prof_x", f"{tag}_kernel_stats_with_extras.csv")):
-    d = os.path.join(G, sub)
-    if os.path.isdir(d):
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "rocpd_stats.py"), os.path.join(d, newest_db(d)),
-                               os.path.join(P, name)])
+# timed workload only (python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras) and the same with the extras:
+# tools/profile_round.sh already reduced the trace databases to the --stats tables (tools/rocpd_stats.py) on the GPU box
+for src, name in (("kernel_stats.csv", f"{tag}_kernel_stats.csv"), ("kernel_stats_with_extras.csv", f"{tag}_kernel_stats_with_extras.csv")):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, name))
 shutil.copy(os.path.join(G, "prof_bench.json"), os.path.join(P, f"bench_{tag}_under_rocprofv3.json"))
 os.makedirs(os.path.join(P, f"{tag}_pmc"), exist_ok=True)
 wcsv, fcsv = os.path.join(G, "pmc_w", "write_size_counter_collection.csv"), os.path.join(G, "pmc_f", "fetch_size_counter_collection.csv")
