@@ -1394,6 +1394,34 @@ def test_config3_full_size_100k_red6_k12(ctx):
     _sampled_row_check(ctx, "red6", 12, 100000, seed_idx=2, full_stats=True)
 
 
+def test_heavy_panels_at_100k_skewed_rows_equal_the_walk(ctx, monkeypatch):
+    """bench.py's skewed workload at full size (100 k rows, 79 k of them heavy, families to 5 000): the whole 10^10-cell
+    matrix with the heavy rows' long-list columns on the matrix cores against the same matrix with every list walked,
+    reduced on the device to a float64 sum and a non-zero count per row (skm_matrix_row_stats).  Both forms compute
+    exact integers and scale them alike, so every row must agree exactly."""
+    import ctypes as C
+
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import BASE_SEED, synth_skewed
+
+    n = 100000
+    res, off, _ = synth_skewed(n, seed=BASE_SEED + 12)
+    batch = engine.SeqBatch(ctx, res, off)
+    pipe = engine.Pipeline(ctx, A.build_lut("red6"), 12)
+    stats = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SKM_HEAVY_PANEL", flag)
+        out = pipe.step(batch)
+        stats[flag] = engine.matrix_row_stats(ctx, out, n, n, out.shape[1])
+    ps = (C.c_int64 * 6)()
+    ctx.call("skm_heavy_panel_stats", ps)
+    assert ps[0] > 50000 and ps[2] <= ps[1] // 10  # tens of thousands of heavy rows, nearly every block with a panel
+    assert (stats["0"][1] == stats["1"][1]).all()   # non-zero cells per row
+    assert (stats["0"][0] == stats["1"][0]).all()   # row sums
+    pipe.out = None
+
+
 def test_config3_real_alphabet_standard_k12_u64_codes(ctx):
     """Same shape with the nearest reference alphabet (`standard`, 7^12 needs uint64 codes)."""
     _sampled_row_check(ctx, "standard", 12, 30000, seed_idx=2)
