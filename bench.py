@@ -980,7 +980,7 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
     pm = ctx.profile_dump()
     ms_sym = pm["k_cosine_dense_i8"][1] / pm["k_cosine_dense_i8"][0]
     # the same kernel without the X-is-Y shortcut (what a rectangular X, Y call runs): every tile computed
-    os.environ["SKM_DENSE_VARIANT"] = "7"
+    os.environ["SKM_DENSE_VARIANT"] = "11"
     ctx.profile_reset()
     for _ in range(3):
         engine.cosine_dense_i8(ctx, nm, nm, dp.kdim, dp.dense, dp.dense, dp.rnorm, dp.rnorm, out=dp.out)
@@ -993,17 +993,19 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
     note("extras: dense_mfma")
     line["dense_mfma"] = {
         "shape": f"N = M = {nm}, K = {dp.kdim} (hydro k=14 full basis), int8 x int8 -> int32 -> float32",
-        "kernel": "k_cosine_dense_i8_v4 (v_mfma_i32_32x32x32_i8, 256x256 tile, staggered wave groups, operands staged from a "
-                  "tiled copy made by k_retile_i8 inside the timed call)",
+        "kernel": "k_cosine_dense_i8_v5 (v_mfma_i32_32x32x32_i8, 256x256 tile, 1 x 8 waves in two staggered groups; A staged through "
+                  "LDS from a tiled copy, B loaded straight into the MFMA operand registers from a lane-order copy; both copies "
+                  "are made inside the timed call)",
         "ms": ms_full, "ops": ops_full, "POPS": ops_full / (ms_full * 1e-3) / 1e15, "peak_POPS": I8_PEAK_TOPS / 1e3,
         "frac": ops_full / (ms_full * 1e-3) / 1e12 / I8_PEAK_TOPS,
         "symmetric": {"what": "X is Y: tiles on or above the diagonal only, mirrored stores (what DensePipeline runs)",
                       "ms": ms_sym, "executed_ops": ops_sym, "POPS_executed": ops_sym / (ms_sym * 1e-3) / 1e15,
                       "frac_executed": ops_sym / (ms_sym * 1e-3) / 1e12 / I8_PEAK_TOPS,
                       "speedup_over_full": ms_full / ms_sym},
-        "bound": "L2 -> LDS fill rate: the launch without MFMAs takes 0.87 of the full time (137 GB staged at 12 TB/s; the "
-                 "microarchitecture guide measures 17-19 TB/s for L2-resident rows and 7-9 TB/s beyond L2; 88 % of the requests "
-                 "hit), without staging 0.67 (profiles/r02_dense_mfma.json)",
+        "bound": "L2 -> CU operand traffic: 32 KiB per tile and K stage = 137 GB per launch; every variant measured in round 4 "
+                 "(v5, v4 with B in registers, a software-pipelined loop) stops at 137 GB / 11.2 ms = 12.2 TB/s, the rate round "
+                 "2 measured for the staging alone (the microarchitecture guide: 17-19 TB/s for L2-resident rows, 7-9 TB/s "
+                 "beyond L2; 88 % of the requests hit); profiles/r04_dense_mfma.json",
         "dense_pipeline_ms_per_step": dt_pipe * 1e3, "dense_pipeline_sequences_per_s": nm / dt_pipe,
         "stage_ms": {k: v[1] / v[0] for k, v in pm.items()},
     }

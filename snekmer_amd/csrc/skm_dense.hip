@@ -16,6 +16,7 @@
 //                       acc * rnorm_x[i] * rnorm_y[j].
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include <rocprim/rocprim.hpp>
 
@@ -660,6 +661,230 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v4(int64_t n, int64_t m
     }
 }
 
+// ------------------------------------------------------------------------------- i8 MFMA cosine, v5
+// v4 stages both operands through LDS, and its LDS-DMA issue (60-185 cycles per instruction, four per wave and stage)
+// and fragment reads leave the matrix pipe idle 45 % of the time (section 5.2 of DESIGN.md).  Here only A goes
+// through LDS.  The eight waves sit side by side (1 x 8): wave w owns all 256 rows x columns [32 w, 32 w + 32) of the
+// tile, so
+//   A (256 rows x 64 B per stage) goes through LDS (two LDS-DMA instructions per wave per stage, a ring of eight
+//     16 KiB slots, staged DA = 3 stages ahead) and every wave reads all of it (16 ds_read_b128 per stage);
+//   B (this wave's 32 columns x 64 B per stage) is loaded by the wave itself, three stages ahead, straight into the
+//     MFMA operand registers from an image laid out in LANE ORDER by k_retile_b_i8 (piece (stage s, column block cb,
+//     half ks) = 1 KiB at (((s * ncb + cb) * 2 + ks) * 1024), lane l at l * 16: row cb * 32 + l % 32, K chunk
+//     2 ks + l / 32): one fully coalesced 1 KiB load per MFMA K step, no LDS, no duplicate.
+// Same staggered wave groups as v4 (waves 4-7 one interval behind), same barriers, same symmetric form.
+// vm queue of a wave: every COMPUTE interval issues B(s+3) [2 loads] then A(s+DA) [2 LDS-DMA]; at the end of LOAD(s)
+// it needs B(s) (the first two of compute(s-3)'s four) and its part of A(s+1) (the last two of compute(s+1-DA)'s):
+// with DA = 3 the four operations of compute(s-1) may still fly -> vmcnt(4), on every path (past the end the last stage
+// is re-fetched into dead slots / registers, so that the count never depends on s).
+// Measured (profiles/r04_dense_mfma.json, N = M = 32 768, K = 16 384): 11.1-11.4 ms against v4's 12.7 rectangular,
+// 6.9 against 7.4 symmetric.  Tried around it and not kept (profiles/r04_experiments/README.md): v4 with only B moved
+// to registers (its 2 x 4 wave grid fetches B twice: 11.6-12.0), the memory instructions issued beside the fragment
+// reads instead of among the MFMAs (12.7-12.9), DA = 4 / 6 (same), a software-pipelined K loop with one barrier per
+// stage and no staggered groups (same: 11.3).  All of them stop at 137 GB / 11.2 ms = 12.2 TB/s of L2 -> CU traffic.
+constexpr int NSLOT5 = 8;
+constexpr int SLOT5_BYTES = BM3 * BK4;  // 16 KiB
+
+__global__ __launch_bounds__(256) void k_retile_b_i8(int64_t rows, int64_t kdim, const int8_t *__restrict__ in, int64_t ncb,
+                                                     int8_t *__restrict__ out)
+{
+    const int64_t total = kdim / 64 * ncb * 2 * 64;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)(t & 63);
+        const int64_t piece = t >> 6;
+        const int ks = (int)(piece & 1);
+        const int64_t cb = (piece >> 1) % ncb, sidx = (piece >> 1) / ncb;
+        const int64_t r = cb * 32 + (l & 31);
+        int4 v = make_int4(0, 0, 0, 0);
+        if (r < rows)
+            v = *reinterpret_cast<const int4 *>(in + r * kdim + sidx * 64 + (ks * 2 + (l >> 5)) * 16);
+        *reinterpret_cast<int4 *>(out + t * 16) = v;
+    }
+}
+
+template <int MODE, bool SYM, int DA = 3>
+__global__ __launch_bounds__(512) void k_cosine_dense_i8_v5(int64_t n, int64_t m, int64_t kdim,
+                                                            const int8_t *__restrict__ X,   // A image (k_retile_i8)
+                                                            const int8_t *__restrict__ YB,  // B image (k_retile_b_i8)
+                                                            const float *__restrict__ xr,
+                                                            const float *__restrict__ yr, float *__restrict__ out,
+                                                            int64_t ld)
+{
+    __shared__ __attribute__((aligned(16))) int8_t s_t[NSLOT5 * SLOT5_BYTES];  // the ONLY shared object (128 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t nty = (n + BM3 - 1) / BM3, ntx = (m + BN3 - 1) / BN3;
+    const int64_t nsx = (ntx + 7) / 8;
+    const int64_t nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+    const int64_t seq = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+    int64_t st = seq / 32;
+    const int64_t within = seq % 32;
+    int64_t sy, sx;
+    if (SYM) {  // as v4: only the supertiles that reach the diagonal or lie above it
+        sy = 0;
+        for (;; ++sy) {
+            const int64_t cnt = nsx - sy / 2;
+            if (st < cnt)
+                break;
+            st -= cnt;
+        }
+        sx = sy / 2 + st;
+    } else {
+        sy = st / nsx;
+        sx = st % nsx;
+    }
+    const int64_t ty = sy * 4 + within / 8, tx = sx * 8 + within % 8;
+    if (ty >= nty || tx >= ntx || (SYM && ty > tx))
+        return;
+    const int64_t row0 = ty * BM3, col0 = tx * BN3;
+
+    i32x16 acc[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[a][r] = 0;
+
+    const int64_t nst = kdim / BK4;  // a multiple of 4 (the launcher's condition)
+    const int64_t nrbx = nty * (BM3 / 16);
+    // A staging: wave w lands rows [32 w, 32 w + 32) of the stage, two instructions of 16 rows x 64 B
+    auto stage_a = [&](int64_t slot_of, int64_t sidx, int q) {  // stage sidx into the slot of stage slot_of
+        const int64_t rb = row0 / 16 + wid * 2 + q;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(X + ((sidx * nrbx + rb) * 64 + lane) * 16),
+                                         (__attribute__((address_space(3))) void *)(s_t + (int)(slot_of & (NSLOT5 - 1)) * SLOT5_BYTES + (wid * 32 + q * 16) * BK4),
+                                         16, 0, 0);
+    };
+    const int64_t ncb = ntx * (BN3 / 32);
+    const int8_t *bp = YB + ((col0 / 32 + wid) * 2) * 1024 + lane * 16;
+    const int64_t bstride = ncb * 2048;  // bytes per K stage of the B image
+    i32x4 fbq[4][2];                     // ring by stage
+    auto load_b = [&](auto BUF, int64_t sidx, int ks) {
+        constexpr int buf = decltype(BUF)::value;
+        fbq[buf][ks] = *reinterpret_cast<const i32x4 *>(bp + sidx * bstride + ks * 1024);
+    };
+#pragma unroll
+    for (int s0 = 0; s0 < DA; ++s0) {
+        stage_a(s0, s0, 0);
+        stage_a(s0, s0, 1);
+    }
+    load_b(std::integral_constant<int, 0>{}, 0, 0);
+    load_b(std::integral_constant<int, 0>{}, 0, 1);
+    load_b(std::integral_constant<int, 1>{}, 1, 0);
+    load_b(std::integral_constant<int, 1>{}, 1, 1);
+    load_b(std::integral_constant<int, 2>{}, 2, 0);
+    load_b(std::integral_constant<int, 2>{}, 2, 1);
+    // builtin waits (0x0F70 = vmcnt(0), 0x0F78 = vmcnt(8); the other counters untouched), not asm: the compiler's own
+    // wait-count model must see them, or it waits for everything before the first MFMA of a stage
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // once per tile
+    __builtin_amdgcn_s_barrier();
+    if (wid >= 4)
+        __builtin_amdgcn_s_barrier();  // waves 4-7 run one interval behind
+
+    const int fr = lane & 31, fh = lane >> 5;
+    i32x4 fa[8][2];
+    auto body = [&](auto CUR, int64_t s) {
+        constexpr int cur = decltype(CUR)::value;
+        const int8_t *sa = s_t + (int)(s & (NSLOT5 - 1)) * SLOT5_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int ra = t * 32 + fr;
+                fa[t][ks] = *reinterpret_cast<const i32x4 *>(sa + ra * BK4 + (((ks * 2 + fh) ^ ((ra >> 2) & 3)) * 16));
+            }
+        static_assert(DA == 3 || DA == 4, "vmcnt below");
+        __builtin_amdgcn_s_waitcnt(DA == 3 ? 0x0F74 : 0x0F78);  // vmcnt(4 / 8): low four bits of the immediate
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers: the slot may be restaged
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        const int64_t na = min(s + DA, nst - 1), nb = min(s + 3, nst - 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a][ks], fbq[cur][ks], acc[a], 0, 0, 0);
+                if ((a & 3) == 3) {  // after every fourth MFMA
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int piece = ks * 2 + (a >> 2);  // 0, 1: B(s+3) halves; 2, 3: A(s+DA) halves
+                    if (piece < 2)
+                        load_b(std::integral_constant<int, (cur + 3) & 3>{}, nb, piece);
+                    else  // past the end: the last stage again, into the (dead) slot of stage s + DA - 8
+                        stage_a(s + DA, na, piece - 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int64_t s = 0; s < nst; s += 4) {
+        body(std::integral_constant<int, 0>{}, s);
+        body(std::integral_constant<int, 1>{}, s + 1);
+        body(std::integral_constant<int, 2>{}, s + 2);
+        body(std::integral_constant<int, 3>{}, s + 3);
+    }
+    if (wid < 4)
+        __builtin_amdgcn_s_barrier();  // pairs with the extra barrier of waves 4-7
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // the dead re-fetches have landed before the epilogue reuses the LDS
+    __builtin_amdgcn_s_barrier();
+
+    // epilogue (as v4's, for this wave's 8 sub-tiles of 32 x 32)
+    const int ccol = lane & 31, chalf = lane >> 5;
+    const bool mirror = SYM && ty < tx;
+    constexpr int TROW = 36;
+    float *tbuf = reinterpret_cast<float *>(s_t) + wid * (32 * TROW);
+    const bool vec_ok = (ld & 3) == 0 && ((uintptr_t)out & 15) == 0;
+    const int64_t jbase = col0 + wid * 32;
+    const int64_t j = jbase + ccol;
+    const float rj = j < m ? yr[j] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int64_t ibase = row0 + a * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int li = 8 * q + 4 * chalf;  // registers 4q .. 4q+3 hold rows li .. li+3 of the sub-tile
+            float o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = ibase + li + u;
+                float v = 0.0f;
+                if (i < n && j < m) {
+                    v = (float)acc[a][4 * q + u] * xr[i] * rj;
+                    if (MODE == 1) {
+                        v = fminf(fmaxf(1.0f - v, 0.0f), 2.0f);
+                        if (i == j)
+                            v = 0.0f;
+                    }
+                    out[i * ld + j] = v;
+                }
+                o[u] = v;
+            }
+            if (mirror)
+                *reinterpret_cast<float4 *>(tbuf + ccol * TROW + li) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        if (mirror) {
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int c = pass * 8 + (lane >> 3), i4 = (lane & 7) * 4;
+                const float4 v = *reinterpret_cast<const float4 *>(tbuf + c * TROW + i4);
+                const int64_t jj = jbase + c, ii = ibase + i4;
+                if (jj < m) {
+                    float *dst = out + jj * ld + ii;
+                    if (vec_ok && ii + 3 < n) {
+                        *reinterpret_cast<float4 *>(dst) = v;
+                    } else {
+                        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (ii + u < n)
+                                dst[u] = e[u];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- dense -> CSR
 // Sparse view of a dense count matrix (the inverse of k_count_dense / k_csr_to_dense).  A workgroup of
 // four waves owns a row; wave w owns the contiguous quarter [w * seg, (w + 1) * seg) of its columns, so
@@ -896,9 +1121,12 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
     const bool v2 = kdim % BK2 == 0 && forced != 1;
     const bool v3 = v2 && forced != 2 && n >= 1024 && m >= 1024;
     // v4 (staggered wave groups, 64-byte K stages; symmetric form when X is Y): the default for large problems
-    // 6: v4 staging from tiled operand copies (the default), 7: the same without symmetry
-    const bool v4 = kdim % BK4 == 0 && kdim >= 4 * BK4 && n >= 1024 && m >= 1024 && (forced == 0 || forced == 4 || forced0 == 6 || forced0 == 7);
-    const bool sym = d_x == d_y && n == m && d_xrnorm == d_yrnorm && forced0 != 5 && forced0 != 7;
+    // 6: v4 staging from tiled operand copies, 7: the same without symmetry
+    // 10: v5 (1 x 8 waves, B straight into registers from a lane-order image; the default where K % 256 == 0), 11: the
+    // same without symmetry
+    const bool v4 = kdim % BK4 == 0 && kdim >= 4 * BK4 && n >= 1024 && m >= 1024 &&
+                    (forced == 0 || forced == 4 || forced0 == 6 || forced0 == 7 || forced0 == 10 || forced0 == 11);
+    const bool sym = d_x == d_y && n == m && d_xrnorm == d_yrnorm && forced0 != 5 && forced0 != 7 && forced0 != 11;
     SKM_PROF(ctx, "k_cosine_dense_i8");
     if (v4) {
         const int64_t nsy4 = skm_ceil_div(skm_ceil_div(n, BM3), 4), nsx4 = skm_ceil_div(skm_ceil_div(m, BN3), 8);
@@ -922,8 +1150,34 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
         if (dabl >= 1 && dabl <= 3)
             return skm_check_launch("k_cosine_dense_i8");
 #endif
-        // default: stage from a tiled copy of the operands (SKM_DENSE_VARIANT=4 / 5 keep the row-major form, for A/B)
-        if (forced0 == 0 || forced0 == 6 || forced0 == 7) {
+        // default where K is a multiple of 256: v5 (SKM_DENSE_VARIANT=10; 11 the same without symmetry)
+        if ((forced0 == 0 || forced0 == 10 || forced0 == 11) && kdim % (4 * BK4) == 0) {
+            const int64_t nrbx = skm_ceil_div(n, BM3) * (BM3 / 16), ncb = skm_ceil_div(m, BN3) * (BN3 / 32);
+            void *p;
+            SKM_TRY(skm_ws(ctx, WS_K, (size_t)nrbx * 16 * (size_t)kdim, &p));
+            int8_t *xt = (int8_t *)p;
+            SKM_TRY(skm_ws(ctx, WS_L, (size_t)ncb * 32 * (size_t)kdim, &p));
+            int8_t *ybt = (int8_t *)p;
+            k_retile_i8<<<skm_grid_cap(ctx, skm_ceil_div(nrbx * 16 * kdim / 16, 256), 8), 256, 0, ctx->stream>>>(n, kdim, d_x, nrbx, xt);
+            k_retile_b_i8<<<skm_grid_cap(ctx, skm_ceil_div(ncb * 32 * kdim / 16, 256), 8), 256, 0, ctx->stream>>>(m, kdim, d_y, ncb, ybt);
+            SKM_TRY(skm_check_launch("k_retile_i8"));
+#define SKM_V5(MODE, SYM) k_cosine_dense_i8_v5<MODE, SYM><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, xt, ybt, d_xrnorm, d_yrnorm, d_out, ld)
+            if (mode == 0) {
+                if (sym)
+                    SKM_V5(0, true);
+                else
+                    SKM_V5(0, false);
+            } else {
+                if (sym)
+                    SKM_V5(1, true);
+                else
+                    SKM_V5(1, false);
+            }
+#undef SKM_V5
+            return skm_check_launch("k_cosine_dense_i8");
+        }
+        // otherwise v4 staging from a tiled copy of the operands (SKM_DENSE_VARIANT=4 / 5 keep the row-major form, for A/B)
+        if (forced0 == 0 || forced0 == 6 || forced0 == 7 || forced0 == 10 || forced0 == 11) {
             const bool sym6 = sym;
             const int64_t nrbx = skm_ceil_div(n, BM3) * (BM3 / 16), nrby = skm_ceil_div(m, BN3) * (BN3 / 16);
             void *p;

@@ -688,10 +688,18 @@ def test_cosine_dense_i8_mfma_exact_gram_and_scaling(ctx):
         _check_dense_gram(ctx, rng, 200, 333, kdim)
     _check_dense_gram(ctx, rng, 129, 1, 128)
     _check_dense_gram(ctx, rng, 5, 300, 1024)
-    _check_dense_gram(ctx, rng, 1100, 1029, 256)  # 256 x 256 tile kernels incl. ragged edges
-    _check_dense_gram(ctx, rng, 1300, 2100, 448)   # K a multiple of 64 only: the staggered kernel's own K step
-    _check_dense_symmetric(ctx, rng, 1500, 320)    # X is Y: upper tiles + mirrored stores, ragged, odd ld
+    _check_dense_gram(ctx, rng, 1100, 1029, 256)  # 256 x 256 tile kernels incl. ragged edges (K % 256 == 0: v5, one K round)
+    _check_dense_gram(ctx, rng, 1030, 1290, 1024)  # v5, several K rounds, ragged in both directions
+    _check_dense_gram(ctx, rng, 1300, 2100, 448)   # K a multiple of 64 only: v4, the staggered kernel's own K step
+    _check_dense_symmetric(ctx, rng, 1500, 320)    # X is Y: upper tiles + mirrored stores, ragged, odd ld (v4)
+    _check_dense_symmetric(ctx, rng, 1500, 768)    # the same through v5
     _check_dense_symmetric(ctx, rng, 2304, 256)    # whole tiles
+    for variant in ("6", "7", "11"):  # the kernels the default route no longer picks at this shape stay exact
+        os.environ["SKM_DENSE_VARIANT"] = variant
+        try:
+            _check_dense_gram(ctx, rng, 1100, 1029, 512)
+        finally:
+            os.environ.pop("SKM_DENSE_VARIANT")
 
 
 def _check_dense_gram(ctx, rng, n, m, kdim):
