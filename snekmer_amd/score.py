@@ -251,9 +251,12 @@ def pairwise_distances(X, metric: str = "euclidean", p: float = 2.0, ctx=None) -
     rogerstanimoto, russellrao, sokalmichener, sokalsneath, yule; the input read as x != 0); "cosine", "hamming" /
     "matching" go to their own kernels.  Square float64 matrix with an exact-zero diagonal.  "euclidean" / "l2" sum
     (x - y)^2 directly where sklearn takes sqrt(xx + yy - 2 xy): the two agree to the rounding error of sklearn's
-    expansion (eps * (xx + yy) in the squared distance), and duplicate rows get an exact 0 here.  Metrics that need more
-    than the two rows (mahalanobis, seuclidean, correlation, ...) raise NotImplementedError: no Snekmer rule passes
-    them."""
+    expansion (eps * (xx + yy) in the squared distance), and duplicate rows get an exact 0 here.
+    The three metrics that need more than the two rows are one O(n d^2) pass over the matrix on the host followed by a
+    device kernel on the transformed rows (`_whole_matrix_metric`): "correlation" = cosine distance of the row-centred
+    matrix, "seuclidean" = euclidean after dividing every column by its standard deviation (V = var(X, ddof=1), what
+    sklearn passes to scipy), "mahalanobis" = euclidean after X -> X L with L L^T = VI = inv(cov(X^T))^T.  Anything else
+    raises NotImplementedError: no Snekmer rule passes another metric."""
     import ctypes as C
 
     from . import _hip
@@ -262,10 +265,13 @@ def pairwise_distances(X, metric: str = "euclidean", p: float = 2.0, ctx=None) -
         return cosine_similarity(X, None, mode=1, ctx=ctx)
     if metric in ("hamming", "matching"):
         return _set_measure(X, 2, ctx)
+    if metric in ("correlation", "seuclidean", "mahalanobis"):
+        return _whole_matrix_metric(X, metric, ctx)
     if metric not in PAIRWISE_METRICS:
         raise NotImplementedError(
             f"metric={metric!r}: implemented on the device are 'cosine', 'hamming', the reference's default 'jaccard' "
-            f"(= 1 - hamming) and {sorted(PAIRWISE_METRICS)} (snekmer/score.py:166-171); no Snekmer rule passes another metric")
+            f"(= 1 - hamming), 'correlation', 'seuclidean', 'mahalanobis' and {sorted(PAIRWISE_METRICS)} (snekmer/score.py:166-171); "
+            f"no Snekmer rule passes another metric")
     ctx = ctx or _hip.default_context()
     A = _plain(X)
     if hasattr(A, "toarray"):
@@ -285,6 +291,56 @@ def pairwise_distances(X, metric: str = "euclidean", p: float = 2.0, ctx=None) -
     ctx.call("skm_pairwise_f64", PAIRWISE_METRICS[metric], C.c_double(p), C.c_int64(n), C.c_int64(n), C.c_int64(k), C.c_void_p(dx.ptr),
              C.c_int64(k), C.c_void_p(dx.ptr), C.c_int64(k), C.c_void_p(out.ptr), C.c_int64(n))
     return out.download().reshape(n, n)
+
+
+def _whole_matrix_metric(X, metric: str, ctx=None) -> np.ndarray:
+    """sklearn.metrics.pairwise_distances(X, metric=metric) for "correlation", "seuclidean" and "mahalanobis"
+    (snekmer/score.py:169-171: sklearn hands these to scipy's pdist, with V / VI computed from X).  The part that
+    looks at the whole matrix (row means; column variances; the inverse covariance and its Cholesky factor) is O(n d^2)
+    on the host in float64; the O(n^2 d) pairwise part runs on the device on the transformed rows.  NaN where scipy
+    gives NaN: a constant row has no correlation with anything, a constant column has no standardised difference."""
+    A = _plain(X)
+    if hasattr(A, "toarray"):
+        raise TypeError("scipy distance metrics do not support sparse matrices.")
+    A = np.ascontiguousarray(np.asarray(A), dtype=np.float64)
+    if A.ndim != 2:
+        raise ValueError("expected a 2-D feature matrix")
+    if not np.all(np.isfinite(A)):
+        raise ValueError("Input contains NaN or infinity.")
+    n, d = A.shape
+    if d == 0:
+        raise ValueError("feature matrix has no columns")
+    if n < 2:
+        return np.zeros((n, n), dtype=np.float64)
+    if metric == "correlation":
+        centred = A - A.mean(axis=1, keepdims=True)
+        D = _cosine_f64(ctx or _default_ctx(), centred, None, 1)
+        flat = ~np.any(centred != 0, axis=1)  # scipy: 0 / 0
+        if flat.any():
+            D[flat, :] = np.nan
+            D[:, flat] = np.nan
+            np.fill_diagonal(D, 0.0)
+        return D
+    if metric == "seuclidean":
+        V = np.var(A, axis=0, ddof=1)
+        if np.any(V == 0):  # every difference in that column is 0: 0 / 0 in each pair's sum
+            D = np.full((n, n), np.nan)
+            np.fill_diagonal(D, 0.0)
+            return D
+        return pairwise_distances(A / np.sqrt(V), metric="euclidean", ctx=ctx)
+    VI = np.linalg.inv(np.atleast_2d(np.cov(A.T))).T  # sklearn's _precompute_metric_params; LinAlgError when singular
+    try:
+        L = np.linalg.cholesky(0.5 * (VI + VI.T))  # the quadratic form only sees the symmetric part
+    except np.linalg.LinAlgError:
+        raise ValueError("mahalanobis: the inverse covariance of X is not positive definite (more columns than "
+                         "independent rows?); scipy's result is not a distance there") from None
+    return pairwise_distances(A @ L, metric="euclidean", ctx=ctx)
+
+
+def _default_ctx():
+    from . import _hip
+
+    return _hip.default_context()
 
 
 def jaccard_distance(feature_matrix, ctx=None) -> np.ndarray:

@@ -555,7 +555,7 @@ def test_connection_matrix_and_feature_matrix_goldens(ctx):
     for key, M in (("jaccard_x", g["X"]), ("jaccard_demo_counts", counts), ("jaccard_float", g15["F"])):
         assert (skm.score.jaccard_distance(M) == g15[key]).all(), key
     with pytest.raises(NotImplementedError):
-        skm.score.connection_matrix_from_features(g["X"], metric="seuclidean")
+        skm.score.connection_matrix_from_features(g["X"], metric="jensenshannon")
     with pytest.raises(ValueError):
         skm.score.connection_matrix_from_features(np.asarray([[1.0, np.nan], [0.0, 1.0]]))
     for case in gjson("g7_feature_matrix.json"):
@@ -620,8 +620,25 @@ def test_connection_matrix_other_sklearn_metrics_match_sklearn(ctx):
                 assert np.nanmax(np.abs(got - want), initial=0.0) <= tol, (metric, X.shape)
     got = skm.score.pairwise_distances(real, metric="minkowski", p=3.0)
     assert np.abs(got - pairwise_distances(real, metric="minkowski", p=3.0)).max() <= 1e-12
+    # the three metrics that look at the whole matrix (V / VI computed from X, as sklearn does before calling scipy)
+    tall = rng.normal(size=(90, 7)) * np.array([1, 5, 0.2, 3, 1, 1, 40.0]) + rng.normal(size=(90, 1))
+    tall[11] = tall[10]
+    for X, metrics in ((tall, ("correlation", "seuclidean", "mahalanobis")), (counts, ("correlation",)),
+                       (np.vstack([tall[:5], np.full((1, 7), 2.5)]), ("correlation",)),   # a constant row: NaN like scipy
+                       (np.hstack([tall[:9], np.ones((9, 1))]), ("seuclidean",)),         # a constant column: NaN like scipy
+                       (tall[:1], ("correlation", "seuclidean"))):
+        for metric in metrics:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                want = pairwise_distances(X, metric=metric)
+                got = skm.score.connection_matrix_from_features(X, metric=metric)
+            assert got.dtype == np.float64 and got.shape == want.shape, metric
+            assert (np.isnan(got) == np.isnan(want)).all(), (metric, X.shape)
+            assert np.nanmax(np.abs(got - want), initial=0.0) <= 1e-10 * max(1.0, float(np.nanmax(np.abs(want), initial=0.0))), (metric, X.shape)
+    with pytest.raises(np.linalg.LinAlgError):
+        skm.score.connection_matrix_from_features(np.hstack([tall, tall[:, :1]]), metric="mahalanobis")  # singular covariance
     with pytest.raises(NotImplementedError):
-        skm.score.connection_matrix_from_features(counts, metric="mahalanobis")
+        skm.score.connection_matrix_from_features(counts, metric="jensenshannon")
 
 
 # ------------------------------------------------------------------ BASELINE sizes: properties
