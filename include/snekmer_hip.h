@@ -512,9 +512,13 @@ int skm_fasta_parse(const uint8_t *h_buf, int64_t len, int nthreads, int64_t nre
  * snekmer/rules/kmerize.smk:132-139; read back by snekmer/io.py:46-96 through np.load).  Writes a zip archive with one
  * member "<names[m]>.npy" per array = h_headers[m] (the .npy header bytes, numpy.lib.format) followed by h_data[m]
  * (the C-contiguous array bytes).  level: -1 = zlib's default (6, what numpy uses), 1-9, or 0 = stored (np.savez).
- * Every member is deflated in 2 MiB chunks by nthreads threads (< 1: all hardware threads), each chunk a run of raw
+ * Every member is deflated in 512 KiB chunks by nthreads threads (< 1: all hardware threads), each chunk a run of raw
  * deflate blocks closed by a sync flush, the chunks' CRC-32s combined: one ordinary deflate stream per member that any
- * unzip reads.  *out_file_bytes (optional) = size of the file written. */
+ * unzip reads.  Members whose .npy header says '<U' (little-endian UTF-32: kmerlist, ids, seqs - three quarters of the
+ * bytes) are tokenised by the library itself (a 4-byte unit repeats the previous item, repeats the previous unit, or
+ * is one literal + a 3-byte match; dynamic Huffman per chunk; `level` only says compressed or stored there): 5-7x
+ * zlib's speed on such bytes, 4-13 % larger; other chunks go through zlib at `level`, Huffman-only when a probe says
+ * string matching buys nothing (column ids).  *out_file_bytes (optional) = size of the file written. */
 int skm_npz_write(const char *path, int nmembers, const char *const *names, const void *const *h_headers,
                   const int64_t *header_bytes, const void *const *h_data, const int64_t *data_bytes, int level,
                   int nthreads, int64_t *out_file_bytes);

@@ -330,6 +330,8 @@ extern "C" int skm_fasta_parse(const uint8_t *h_buf, int64_t len, int nthreads, 
 // closed by a sync flush (byte-aligned, not final), the last chunk of a member is finished, so their concatenation is
 // ONE valid raw-deflate stream; the member's CRC-32 is combined from the chunks' CRCs.  The result is an ordinary zip
 // archive (zip64 records as numpy itself writes them) that np.load / snekmer.io.load_npz read unchanged.
+#include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
@@ -348,7 +350,449 @@ struct npz_chunk {
     std::vector<uint8_t> out;
     uint32_t crc = 0;
     int err = Z_OK;
+    int utf32_item = 0;  // > 0: the bytes are little-endian UTF-32 strings ('<U' arrays) of this many bytes per item
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A deflate encoder for numpy '<U' arrays (UTF-32: kmerlist, seqs, ids - three quarters of a k-mer file's bytes).
+// zlib spends its time in hash chains there: every position of "c 0 0 0 c 0 0 0 ..." hashes like thousands of earlier
+// ones, and at level 6 it walks 128 of them per byte (16-22 MB/s per thread).  The structure is known, so no search is
+// needed: a 4-byte unit either repeats the unit at the same place of the previous item (sorted k-mers share long
+// prefixes: one match of distance item-size), or repeats the previous unit (zero padding), or is one literal followed
+// by a 3-byte match at distance 4 (the three zero bytes of every character below U+0100).  The tokens are coded with
+// dynamic Huffman trees built per chunk (RFC 1951 section 3.2.7); any inflate reads the result.
+namespace utf32_deflate {
+
+struct bit_writer {
+    std::vector<uint8_t> &out;
+    uint64_t acc = 0;
+    int nbits = 0;
+    explicit bit_writer(std::vector<uint8_t> &o) : out(o) {}
+    void put(uint32_t value, int n)  // n <= 32, least significant bit first
+    {
+        acc |= (uint64_t)value << nbits;
+        nbits += n;
+        while (nbits >= 8) {
+            out.push_back((uint8_t)acc);
+            acc >>= 8;
+            nbits -= 8;
+        }
+    }
+    void align()
+    {
+        if (nbits > 0) {
+            out.push_back((uint8_t)acc);
+            acc = 0;
+            nbits = 0;
+        }
+    }
+};
+
+// Code lengths (<= maxbits) of a Huffman code for freq[0..n): a plain Huffman tree, then the usual repair of the
+// length histogram when the tree is deeper than maxbits.  At least two symbols get a code (a lone symbol's partner is
+// the unused symbol next to it), so the code is always complete.
+void code_lengths(const uint32_t *freq, int n, int maxbits, uint8_t *len)
+{
+    std::vector<int> used;
+    for (int i = 0; i < n; ++i) {
+        len[i] = 0;
+        if (freq[i])
+            used.push_back(i);
+    }
+    if (used.empty())
+        used.push_back(0);
+    if (used.size() == 1)
+        used.push_back(used[0] == 0 ? 1 : used[0] - 1);
+    std::sort(used.begin(), used.end(), [&](int a, int b) { return freq[a] != freq[b] ? freq[a] < freq[b] : a < b; });
+    const int m = (int)used.size();
+    // two-queue construction over the sorted leaves; node 0..m-1 leaves, m.. internal
+    std::vector<uint64_t> w((size_t)2 * m);
+    std::vector<int> parent((size_t)2 * m, -1);
+    for (int i = 0; i < m; ++i)
+        w[i] = freq[used[i]] ? freq[used[i]] : 1;
+    int leaf = 0, inner = m, next = m;
+    auto take = [&]() {
+        if (leaf < m && (inner >= next || w[leaf] <= w[inner]))
+            return leaf++;
+        return inner++;
+    };
+    while (next < 2 * m - 1) {
+        const int a = take(), b = take();
+        w[next] = w[a] + w[b];
+        parent[a] = parent[b] = next;
+        ++next;
+    }
+    std::vector<int> count((size_t)maxbits + 64, 0);
+    std::vector<int> depth((size_t)2 * m, 0);
+    for (int i = 2 * m - 3; i >= 0; --i)
+        depth[i] = depth[parent[i]] + 1;
+    int deepest = 0;
+    for (int i = 0; i < m; ++i) {
+        const int d = depth[i] < maxbits + 60 ? depth[i] : maxbits + 60;
+        ++count[d];
+        deepest = d > deepest ? d : deepest;
+    }
+    if (deepest > maxbits) {
+        for (int d = maxbits + 1; d <= deepest; ++d) {
+            count[maxbits] += count[d];
+            count[d] = 0;
+        }
+        uint64_t total = 0;
+        for (int d = maxbits; d >= 1; --d)
+            total += (uint64_t)count[d] << (maxbits - d);
+        while (total != ((uint64_t)1 << maxbits)) {  // over-subscribed: lengthen one short code, pair up a longest one
+            --count[maxbits];
+            for (int d = maxbits - 1; d >= 1; --d)
+                if (count[d]) {
+                    --count[d];
+                    count[d + 1] += 2;
+                    break;
+                }
+            --total;
+        }
+    }
+    // the rarest symbols get the longest codes
+    int at = 0;
+    for (int d = maxbits; d >= 1; --d)
+        for (int c = 0; c < count[d]; ++c)
+            len[used[at++]] = (uint8_t)d;
+}
+
+void canonical_codes(const uint8_t *len, int n, uint16_t *code)
+{
+    int bl[16] = {};
+    for (int i = 0; i < n; ++i)
+        ++bl[len[i]];
+    bl[0] = 0;
+    uint32_t next[16] = {};
+    uint32_t c = 0;
+    for (int b = 1; b < 16; ++b) {
+        c = (c + (uint32_t)bl[b - 1]) << 1;
+        next[b] = c;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!len[i]) {
+            code[i] = 0;
+            continue;
+        }
+        uint32_t v = next[len[i]]++, r = 0;  // Huffman codes go out most significant bit first
+        for (int b = 0; b < len[i]; ++b)
+            r |= ((v >> b) & 1u) << (len[i] - 1 - b);
+        code[i] = (uint16_t)r;
+    }
+}
+
+const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+const uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+struct len_table {
+    uint8_t sym[259];
+    len_table()
+    {
+        for (int length = 0; length < 259; ++length) {
+            int s = 28;
+            while (s > 0 && LEN_BASE[s] > length)
+                --s;
+            sym[length] = (uint8_t)s;
+        }
+    }
+};
+inline int len_symbol(int length)  // 3..258 -> 0..28
+{
+    static const len_table t;
+    return t.sym[length];
+}
+inline int dist_symbol(int dist)  // 1..32768 -> 0..29
+{
+    if (dist <= 4)
+        return dist - 1;
+    const int top = 31 - __builtin_clz((unsigned)(dist - 1));  // 2^top <= dist - 1 < 2^(top + 1)
+    return 2 * top + (((dist - 1) >> (top - 1)) & 1);
+}
+
+// token: literal byte, or 0x80000000 | length << 16 | (distance - 1)
+inline uint32_t match_token(int length, int dist) { return 0x80000000u | ((uint32_t)length << 16) | (uint32_t)(dist - 1); }
+
+// One chunk (a whole number of 4-byte units; a whole number of items when item_bytes > 0) -> raw deflate: one dynamic
+// block, then an empty stored block that byte-aligns the stream (what Z_SYNC_FLUSH leaves) or, for the member's last
+// chunk, closes it.
+void encode(const uint8_t *src, size_t len, int item_bytes, bool last, std::vector<uint8_t> &out)
+{
+    const size_t units = len / 4;
+    const size_t w = item_bytes > 0 && item_bytes <= 32768 ? (size_t)item_bytes / 4 : 0;  // the window reaches one item back
+    auto unit = [&](size_t i) {
+        uint32_t v;
+        memcpy(&v, src + 4 * i, 4);
+        return v;
+    };
+    std::vector<uint32_t> tok;
+    tok.reserve(units + 16);
+    uint32_t flit[286] = {}, fdist[30] = {};
+    // only two distances occur: the previous unit (4) and the previous item
+    const int ds_unit = dist_symbol(4);
+    auto emit_match = [&](size_t nunits, int dist) {
+        const int ds = dist == 4 ? ds_unit : dist_symbol(dist);
+        while (nunits) {
+            const size_t piece = nunits < 64 ? nunits : 64;  // 256 bytes: the longest whole number of units <= 258
+            tok.push_back(match_token((int)piece * 4, dist));
+            ++flit[257 + len_symbol((int)piece * 4)];
+            ++fdist[ds];
+            nunits -= piece;
+        }
+    };
+    // third candidate, for items longer than 32 characters: the last place the same PAIR of units stood (one table
+    // entry per pair hash, no chains): free text (protein sequences) repeats pairs and triples of characters within the
+    // 8192 characters the window holds.
+    // A far match pays ~4 + log2(distance in units) bits, a unit coded alone ~3 + log2(distinct byte values): the match
+    // is taken when it is the cheaper way to code its units.
+    constexpr int HBITS = 15;
+    std::vector<uint32_t> head, head_wide;
+    // and, before it, the last place the same RUN of `wide` units stood, `wide` chosen so that a run is unlikely to
+    // recur by chance inside the window (6 units for a 6-letter alphabet, 4 for 20 letters): in a file of protein
+    // families that is the same stretch of a relative a few records back, and the match runs on for dozens of units.
+    size_t wide = 4;
+    auto pair_hash = [&](size_t i) { return (uint32_t)(((uint64_t)unit(i) * 0x9E3779B1u + (uint64_t)unit(i + 1) * 0x85EBCA77u) >> 7) & ((1u << HBITS) - 1u); };
+    double unit_bits = 7.0;
+    // (measured: free text - protein sequences, 20 letters - shrinks 9 % with the pair matches; sorted k-mer lists of
+    // every alphabet and id lists grow 1-8 % with them, because the frequent short codes get longer: short items go without)
+    const bool far_ok = item_bytes <= 0 || item_bytes > 4 * 32;
+    {
+        bool seen[256] = {};
+        int distinct = 0;
+        for (size_t i = 0; i < units && i < 4096; ++i) {
+            const uint8_t b = src[4 * i];
+            distinct += !seen[b];
+            seen[b] = true;
+        }
+        unit_bits = 3.0 + log2((double)(distinct > 1 ? distinct : 2));
+        wide = (size_t)ceil(15.0 / log2((double)(distinct > 1 ? distinct : 2)));
+        wide = wide < 3 ? 3 : (wide > 8 ? 8 : wide);
+    }
+    if (far_ok) {
+        head.assign((size_t)1 << HBITS, 0xFFFFFFFFu);
+        head_wide.assign((size_t)1 << HBITS, 0xFFFFFFFFu);
+    }
+    auto wide_hash = [&](size_t i) {
+        uint64_t h = 0;
+        for (size_t j = 0; j < wide; ++j)
+            h = (h + unit(i + j)) * 0x9E3779B97F4A7C15ull;
+        return (uint32_t)(h >> (64 - HBITS));
+    };
+    auto note = [&](size_t from, size_t count) {  // positions a token covered enter the tables
+        if (!far_ok)
+            return;
+        for (size_t i = from; i < from + count && i + 1 < units; ++i) {
+            head[pair_hash(i)] = (uint32_t)i;
+            if (i + wide <= units)
+                head_wide[wide_hash(i)] = (uint32_t)i;
+        }
+    };
+    for (size_t p = 0; p < units;) {
+        const uint32_t u = unit(p);
+        size_t r_item = 0, r_unit = 0, r_far = 0, far_at = 0, r_shift = 0;
+        if (w && p >= w)
+            while (p + r_item < units && unit(p + r_item) == unit(p + r_item - w))
+                ++r_item;
+        if (p >= 1 && u == unit(p - 1)) {
+            r_unit = 1;
+            while (p + r_unit < units && unit(p + r_unit) == u)
+                ++r_unit;
+        }
+        if (w > 2 && p >= w - 1 && r_item < w - 1)  // the previous item moved up by one character (k-mers in window order)
+            while (p + r_shift < units && unit(p + r_shift) == unit(p + r_shift - (w - 1)))
+                ++r_shift;
+        if (r_shift > r_item && r_shift > r_unit && r_shift >= 2) {
+            emit_match(r_shift, (int)(w - 1) * 4);
+            note(p, r_shift);
+            p += r_shift;
+            continue;
+        }
+        if (far_ok && r_item < wide && r_unit < wide && p + wide <= units) {
+            const uint32_t q = head_wide[wide_hash(p)];
+            if (q != 0xFFFFFFFFu && p - q <= 8192) {
+                size_t r = 0;
+                while (r < 64 && p + r < units && unit(q + r) == unit(p + r))
+                    ++r;
+                if (r >= wide) {
+                    r_far = r;
+                    far_at = q;
+                }
+            }
+        }
+        if (far_ok && r_far == 0 && r_item < 2 && r_unit < 2 && p + 1 < units) {
+            const uint32_t q = head[pair_hash(p)];
+            if (q != 0xFFFFFFFFu && p - q <= 8192 && unit(q) == u && unit(q + 1) == unit(p + 1)) {
+                r_far = 2;
+                while (r_far < 64 && p + r_far < units && unit(q + r_far) == unit(p + r_far))
+                    ++r_far;
+                far_at = q;
+                if (4.0 + log2((double)(p - q)) + 2.0 >= unit_bits * (double)r_far)
+                    r_far = 0;
+            }
+        }
+        if (r_unit >= r_item && r_unit >= r_far && r_unit > 0) {
+            emit_match(r_unit, 4);
+            note(p, r_unit);
+            p += r_unit;
+        } else if (r_item >= r_far && r_item > 0) {
+            emit_match(r_item, (int)w * 4);
+            note(p, r_item);
+            p += r_item;
+        } else if (r_far > 0) {
+            const int dist = (int)(p - far_at) * 4;
+            tok.push_back(match_token((int)r_far * 4, dist));
+            ++flit[257 + len_symbol((int)r_far * 4)];
+            ++fdist[dist_symbol(dist)];
+            note(p, r_far);
+            p += r_far;
+        } else {
+            note(p, 1);
+            tok.push_back(u & 0xFFu);
+            ++flit[u & 0xFFu];
+            if (p >= 1 && (u >> 8) == (unit(p - 1) >> 8)) {
+                tok.push_back(match_token(3, 4));
+                ++flit[257];
+                ++fdist[ds_unit];
+            } else {
+                for (int b = 1; b < 4; ++b) {
+                    tok.push_back((u >> (8 * b)) & 0xFFu);
+                    ++flit[(u >> (8 * b)) & 0xFFu];
+                }
+            }
+            ++p;
+        }
+    }
+    for (size_t i = units * 4; i < len; ++i) {  // (a '<U' array is whole units; kept for safety)
+        tok.push_back(src[i]);
+        ++flit[src[i]];
+    }
+    ++flit[256];
+    uint8_t llen[286], dlen[30];
+    uint16_t lcode[286], dcode[30];
+    code_lengths(flit, 286, 15, llen);
+    code_lengths(fdist, 30, 15, dlen);
+    canonical_codes(llen, 286, lcode);
+    canonical_codes(dlen, 30, dcode);
+    int hlit = 286, hdist = 30;
+    while (hlit > 257 && llen[hlit - 1] == 0)
+        --hlit;
+    while (hdist > 1 && dlen[hdist - 1] == 0)
+        --hdist;
+    // the two length vectors, run-length coded with the symbols 16 / 17 / 18
+    std::vector<uint8_t> seq(llen, llen + hlit);
+    seq.insert(seq.end(), dlen, dlen + hdist);
+    std::vector<uint16_t> cl;  // symbol | extra << 8
+    uint32_t fcl[19] = {};
+    for (size_t i = 0; i < seq.size();) {
+        size_t run = 1;
+        while (i + run < seq.size() && seq[i + run] == seq[i])
+            ++run;
+        const uint8_t v = seq[i];
+        size_t left = run;
+        if (v == 0) {
+            while (left >= 3) {
+                const size_t take = left < 138 ? left : 138;
+                if (take >= 11) {
+                    cl.push_back((uint16_t)(18 | ((take - 11) << 8)));
+                    ++fcl[18];
+                } else {
+                    cl.push_back((uint16_t)(17 | ((take - 3) << 8)));
+                    ++fcl[17];
+                }
+                left -= take;
+            }
+        } else {
+            cl.push_back(v);
+            ++fcl[v];
+            --left;
+            while (left >= 3) {
+                const size_t take = left < 6 ? left : 6;
+                cl.push_back((uint16_t)(16 | ((take - 3) << 8)));
+                ++fcl[16];
+                left -= take;
+            }
+        }
+        for (; left; --left) {
+            cl.push_back(v);
+            ++fcl[v];
+        }
+        i += run;
+    }
+    uint8_t cllen[19];
+    uint16_t clcode[19];
+    code_lengths(fcl, 19, 7, cllen);
+    canonical_codes(cllen, 19, clcode);
+    static const uint8_t ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    int hclen = 19;
+    while (hclen > 4 && cllen[ORDER[hclen - 1]] == 0)
+        --hclen;
+    {
+        // characters that do not compress (random code points): the coded size would exceed the raw one -> stored blocks
+        uint64_t bits = 0;
+        for (int i = 0; i < 286; ++i)
+            bits += (uint64_t)flit[i] * (llen[i] + (i >= 257 ? LEN_EXTRA[i - 257] : 0));
+        for (int i = 0; i < 30; ++i)
+            bits += (uint64_t)fdist[i] * (dlen[i] + DIST_EXTRA[i]);
+        if (bits / 8 + 600 >= len) {
+            out.reserve(out.size() + len + len / 65535 * 5 + 16);
+            for (size_t at = 0; at < len;) {
+                const size_t piece = len - at < 65535 ? len - at : 65535;
+                const bool fin = last && at + piece == len;
+                out.push_back(fin ? 1 : 0);  // BFINAL, BTYPE = 00, padding to the byte
+                out.push_back((uint8_t)piece);
+                out.push_back((uint8_t)(piece >> 8));
+                out.push_back((uint8_t)~piece);
+                out.push_back((uint8_t)(~piece >> 8));
+                out.insert(out.end(), src + at, src + at + piece);
+                at += piece;
+            }
+            return;
+        }
+    }
+    out.reserve(out.size() + len / 6 + 1024);
+    bit_writer bw(out);
+    bw.put(0, 1);  // not the final block: the stored block below closes the chunk
+    bw.put(2, 2);  // dynamic Huffman
+    bw.put((uint32_t)(hlit - 257), 5);
+    bw.put((uint32_t)(hdist - 1), 5);
+    bw.put((uint32_t)(hclen - 4), 4);
+    for (int i = 0; i < hclen; ++i)
+        bw.put(cllen[ORDER[i]], 3);
+    for (uint16_t c : cl) {
+        const int sym = c & 0xFF;
+        bw.put(clcode[sym], cllen[sym]);
+        if (sym == 16)
+            bw.put(c >> 8, 2);
+        else if (sym == 17)
+            bw.put(c >> 8, 3);
+        else if (sym == 18)
+            bw.put(c >> 8, 7);
+    }
+    for (uint32_t t : tok) {
+        if (t & 0x80000000u) {
+            const int length = (int)((t >> 16) & 0x1FFu), dist = (int)(t & 0xFFFFu) + 1;
+            const int ls = len_symbol(length), ds = dist == 4 ? ds_unit : dist_symbol(dist);
+            bw.put(lcode[257 + ls], llen[257 + ls]);
+            bw.put((uint32_t)(length - LEN_BASE[ls]), LEN_EXTRA[ls]);
+            bw.put(dcode[ds], dlen[ds]);
+            bw.put((uint32_t)(dist - DIST_BASE[ds]), DIST_EXTRA[ds]);
+        } else {
+            bw.put(lcode[t], llen[t]);
+        }
+    }
+    bw.put(lcode[256], llen[256]);
+    bw.put(last ? 1 : 0, 1);  // empty stored block: final for the member's last chunk, a byte-aligning flush otherwise
+    bw.put(0, 2);
+    bw.align();
+    out.push_back(0);
+    out.push_back(0);
+    out.push_back(0xFF);
+    out.push_back(0xFF);
+}
+
+}  // namespace utf32_deflate
 
 void put16(std::vector<uint8_t> &b, uint32_t v)
 {
@@ -377,9 +821,36 @@ void npz_deflate_chunk(npz_chunk &c, int level)
     if (level == 0) {  // stored member: the bytes are written from the caller's buffer
         return;
     }
+    if (c.utf32_item > 0 && c.len >= 64) {
+        utf32_deflate::encode(c.src, c.len, c.utf32_item, c.last, c.out);
+        return;
+    }
+    // Numeric members (column ids, row starts): when a probe of the chunk's first 64 KiB says that string matching buys
+    // nothing over entropy coding alone, the chunk is Huffman-coded only (5x faster, same size within 2 %)
+    int strategy = Z_DEFAULT_STRATEGY;
+    if (c.len >= ((size_t)1 << 17)) {
+        const size_t probe = (size_t)1 << 15;
+        std::vector<uint8_t> tmp(compressBound((uLong)probe) + 64);
+        size_t got[2] = {0, 0};
+        for (int which = 0; which < 2; ++which) {
+            z_stream ps;
+            memset(&ps, 0, sizeof(ps));
+            if (deflateInit2(&ps, 1, Z_DEFLATED, -15, 8, which ? Z_HUFFMAN_ONLY : Z_DEFAULT_STRATEGY) != Z_OK)
+                break;
+            ps.next_in = const_cast<Bytef *>(c.src + c.len / 2 - probe / 2);  // the middle of the chunk
+            ps.avail_in = (uInt)probe;
+            ps.next_out = tmp.data();
+            ps.avail_out = (uInt)tmp.size();
+            if (deflate(&ps, Z_FINISH) == Z_STREAM_END)
+                got[which] = ps.total_out;
+            deflateEnd(&ps);
+        }
+        if (got[0] && got[1] && (double)got[1] <= 1.05 * (double)got[0])
+            strategy = Z_HUFFMAN_ONLY;
+    }
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
-    c.err = deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    c.err = deflateInit2(&zs, level, Z_DEFLATED, -15, 8, strategy);
     if (c.err != Z_OK)
         return;
     c.out.resize(deflateBound(&zs, (uLong)c.len) + 16);
@@ -405,7 +876,10 @@ extern "C" int skm_npz_write(const char *path, int nmembers, const char *const *
     SKM_REQUIRE(level >= -1 && level <= 9, SKM_E_BADARG, "skm_npz_write: level must be -1 (zlib's default) or 0 (stored) to 9");
     if (level < 0)
         level = 6;
-    constexpr size_t CHUNK = (size_t)1 << 21;  // 2 MiB: ~64 back-reference windows, a few ms of deflate
+    // 512 KiB: 16 back-reference windows (the chunk's first window starts empty: < 1 % of size), and short enough that
+    // the slowest kind of chunk (zlib level 6 on near-random integers, ~17 MB/s) takes 30 ms, not 120: a 10 k-sequence
+    // file has only ~200 of them to spread over the threads
+    constexpr size_t CHUNK = (size_t)1 << 19;
     std::vector<npz_chunk> chunks;
     std::vector<size_t> first_chunk((size_t)nmembers + 1, 0);
     for (int m = 0; m < nmembers; ++m) {
@@ -415,9 +889,22 @@ extern "C" int skm_npz_write(const char *path, int nmembers, const char *const *
         first_chunk[m] = chunks.size();
         const bool empty = data_bytes[m] == 0;
         chunks.push_back({m, (const uint8_t *)h_headers[m], (size_t)header_bytes[m], empty, {}, 0, Z_OK});
-        for (size_t at = 0; at < (size_t)data_bytes[m]; at += CHUNK) {
-            const size_t len = (size_t)data_bytes[m] - at < CHUNK ? (size_t)data_bytes[m] - at : CHUNK;
+        // a little-endian UTF-32 member ('descr': '<U12'): chunks of whole items for the string encoder
+        int item = 0;
+        {
+            const std::string hdr((const char *)h_headers[m], (size_t)header_bytes[m]);
+            const size_t at = hdr.find("'descr': '<U");
+            if (at != std::string::npos) {
+                const long chars = strtol(hdr.c_str() + at + 12, nullptr, 10);
+                if (chars > 0 && chars < ((long)1 << 28) && (int64_t)chars * 4 <= data_bytes[m] && data_bytes[m] % (chars * 4) == 0)
+                    item = (int)(chars * 4);
+            }
+        }
+        const size_t step = item > 0 && (size_t)item <= CHUNK ? CHUNK / (size_t)item * (size_t)item : CHUNK;
+        for (size_t at = 0; at < (size_t)data_bytes[m]; at += step) {
+            const size_t len = (size_t)data_bytes[m] - at < step ? (size_t)data_bytes[m] - at : step;
             chunks.push_back({m, (const uint8_t *)h_data[m] + at, len, at + len == (size_t)data_bytes[m], {}, 0, Z_OK});
+            chunks.back().utf32_item = item;
         }
     }
     first_chunk[nmembers] = chunks.size();

@@ -110,7 +110,7 @@ def save_npz(filename: str, arrays: Dict[str, np.ndarray], compressed: bool = Tr
              _lib=None) -> int:
     """``np.savez_compressed(filename, **arrays)`` (compressed=True: what rules/kmerize.smk:132-139 calls) or
     ``np.savez`` (compressed=False) through the C library's threaded writer (skm_npz_write: host code, no GPU): the same
-    zip-of-.npy container, every member deflated in 2 MiB chunks on all cores instead of on one thread.  np.load and
+    zip-of-.npy container, every member deflated in 512 KiB chunks on all cores instead of on one thread.  np.load and
     the reference's io.load_npz (snekmer/io.py:46-96) read the file unchanged.  Like numpy, ".npz" is appended to a
     name without it.  Object arrays (which numpy would pickle) are not supported.  Returns the file's size in bytes."""
     import ctypes as C

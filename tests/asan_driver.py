@@ -107,7 +107,7 @@ def check_fasta(lib):
 
 
 def check_npz(lib):
-    """The threaded .npz writer: members of every size class around the 2 MiB chunk (exactly sized inputs: an overrun is
+    """The threaded .npz writer: members of every size class around the chunk size (512 KiB, formerly 2 MiB; exactly sized inputs: an overrun is
     a heap-buffer-overflow report), compressed and stored, read back by numpy."""
     from snekmer_amd import io
 
@@ -115,7 +115,13 @@ def check_npz(lib):
     arrays = {"kmerlist": np.array(["ACDEFGHIKLMN", "AAAAAAAAAAAD"] * 3, dtype=str), "ids": np.array([], dtype=str),
               "vecs": np.asfortranarray(rng.integers(0, 2, (33, 17)).astype(np.float64)), "scalar": np.float32(2.5),
               "edge": rng.integers(0, 9, size=(1 << 21) - 128, dtype=np.uint8), "edge1": rng.integers(0, 9, size=(1 << 21) - 127, dtype=np.uint8),
-              "big": rng.integers(0, 300, size=1_300_001, dtype=np.uint32), "empty2d": np.zeros((0, 5))}
+              "edge2": rng.integers(0, 9, size=(1 << 19) - 128, dtype=np.uint8), "edge3": rng.integers(0, 9, size=(1 << 19) - 127, dtype=np.uint8),
+              "big": rng.integers(0, 300, size=1_300_001, dtype=np.uint32), "empty2d": np.zeros((0, 5)),
+              # the '<U' encoder: sorted k-mers over more than one chunk, ragged text beyond latin-1 / the BMP, one item
+              # longer than the deflate window, incompressible numbers (Huffman-only probe)
+              "sorted": np.unique(np.array(["".join(r) for r in rng.choice(list("SNDQEH"), size=(60000, 12))])),
+              "text": np.array(["", "αβγ", "😀x", "A" * 700, "日本語"] * 400), "long": np.array(["Q" * 40000, "QR" * 9]),
+              "noise": rng.integers(0, 1 << 32, size=300_000, dtype=np.uint64)}
     with tempfile.TemporaryDirectory() as tmp:
         for compressed in (True, False):
             for th in (1, 4):

@@ -378,7 +378,7 @@ def dense_round(ctx, seed):
     rng = np.random.default_rng(seed)
     n = int(rng.choice([rng.integers(1, 300), rng.integers(900, 1200), rng.integers(1024, 2600)]))
     m = int(rng.choice([rng.integers(1, 300), rng.integers(900, 1200), rng.integers(1024, 2600)]))
-    kdim = 64 * int(rng.choice([1, 2, 3, 4, 5, 6, 8, 9, 16]))
+    kdim = 64 * int(rng.choice([1, 2, 3, 4, 5, 6, 8, 9, 12, 16, 20]))
     sym = rng.random() < 0.35
     if sym:
         m = n

@@ -185,7 +185,9 @@ def test_reference_written_kmers_pickle_loads_through_the_module_alias():
 def test_threaded_npz_writer_matches_numpy_savez(tmp_path):
     """skm_npz_write (host code) against np.savez_compressed / np.savez on the rule's members (rules/kmerize.smk:132-139):
     the same member names, dtypes, shapes and values through np.load and through the reference-shaped io.load_npz, a valid
-    zip (CRCs checked by zipfile), and a size close to numpy's own."""
+    zip (CRCs checked by zipfile), and a size close to numpy's own (the '<U' members go through the library's own
+    deflate encoder, 5-7x faster than zlib level 6 per thread and 4-13 % larger on k-mer lists; numeric members that do
+    not compress beyond entropy coding are Huffman-coded only)."""
     import zipfile
 
     from snekmer_amd import io as sio
@@ -214,10 +216,40 @@ def test_threaded_npz_writer_matches_numpy_savez(tmp_path):
         for key in arrays:
             assert got[key].dtype == want[key].dtype and got[key].shape == want[key].shape and (got[key] == want[key]).all()
         if compressed:
-            assert size <= 1.02 * os.path.getsize(ref)
+            assert size <= 1.15 * os.path.getsize(ref)
         (kmerlist,), df = sio.load_npz(path)
         assert list(kmerlist) == list(arrays["kmerlist"]) and list(df["sequence_id"]) == list(arrays["ids"])
         assert (np.asarray(list(df["sequence_vector"])) == arrays["vecs"]).all()
+    # the string encoder on everything a '<U' array can hold: characters beyond latin-1 and beyond the BMP, empty and
+    # ragged strings, 2-D, width 1, items longer than the 32 KiB window and longer than a chunk, sorted k-mers of
+    # every size from none to several chunks; big-endian strings take the zlib path
+    words = ["", "a", "αβγδ", "日本語テキスト", "😀😀x", "A" * 999, "z" * 5, "mixedΩ😀"]
+    arr = np.array([words[i] for i in rng.integers(0, len(words), size=3000)])
+    cases = [{"s": arr, "t": arr.reshape(30, 100), "one": np.array(list("ACDEFGHIKLMNPQRSTVWY" * 50)), "e": np.array([""] * 7),
+              "num": np.arange(100000), "be": arr[:200].astype(">U999")},
+             {"wide": np.array(["".join(chr(c) for c in rng.integers(65, 91, size=int(L))) for L in rng.integers(0, 12000, size=120)])},
+             {"huge": np.array(["Q" * 600000, "R" * 10])}]
+    for nk in (0, 1, 2, 5, 1000, 120000):
+        codes = np.unique(rng.integers(0, 6**12, size=nk, dtype=np.int64)) if nk else np.zeros(0, np.int64)
+        digits = (codes[:, None] // (6 ** np.arange(11, -1, -1))) % 6
+        cases.append({"kmerlist": np.frombuffer(b"SNDQEH", dtype=np.uint8)[digits].astype(np.uint8).view("S12").reshape(-1).astype("<U12")
+                      if nk else np.zeros(0, "<U12")})
+    for i, members in enumerate(cases):
+        path = str(tmp_path / f"strings_{i}.npz")
+        sio.save_npz(path, members, threads=3)
+        with zipfile.ZipFile(path) as z:
+            assert z.testzip() is None
+        with np.load(path) as got:
+            for key, want in members.items():
+                assert got[key].dtype == want.dtype and got[key].shape == want.shape and (got[key] == want).all(), (i, key)
+    # units that do not compress at all (random 32-bit patterns viewed as '<U1'): the encoder falls back to stored blocks
+    for count in (16, 1000, 300001):
+        raw = rng.integers(0, 2**32, size=count, dtype=np.uint32)
+        path = str(tmp_path / f"noise_{count}.npz")
+        size = sio.save_npz(path, {"a": raw.view("<U1")}, threads=3)
+        with zipfile.ZipFile(path) as z:
+            assert z.testzip() is None and z.read("a.npy")[-4 * count:] == raw.tobytes()
+        assert size <= 4 * count + 600
     with pytest.raises(TypeError):
         sio.save_npz(str(tmp_path / "obj"), {"o": np.array([{}], dtype=object)})
     with pytest.raises(_hip.HipError):
