@@ -352,6 +352,11 @@ def main():
     sharded = world > 1 or os.environ.get("SKM_BENCH_FORCE_SHARDED") == "1"
     dist = None
     if sharded:
+        # a rank that waits for ever (a collective whose peer died, a transport that never connects) must not hold its GPU
+        # until somebody else's time limit: after 15 minutes the rank prints where it stands and exits
+        import faulthandler
+
+        faulthandler.dump_traceback_later(900, exit=True)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         # torch.distributed (gloo) is control plane only: id broadcast, barriers, max-over-ranks.
@@ -524,6 +529,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        import faulthandler
+
+        faulthandler.cancel_dump_traceback_later()
 
 
 def sharded_stage_rooflines(engine, args, pipe, prof, world, residues_local, rows_local):
@@ -635,11 +643,13 @@ def skewed_workload(ctx, engine, alphabet, args, pipe, line):
     ctx.profile_enable(True)
     ctx.profile_reset()
     reps = 5
-    t1 = time.perf_counter()
-    for _ in range(reps):
+    per_step = []
+    for _ in range(reps):  # every step timed by itself (one host wait in 24 ms): the median survives a stalled step
+        t1 = time.perf_counter()
         p.step(batch)
-    ctx.sync()
-    dt = (time.perf_counter() - t1) / reps
+        ctx.sync()
+        per_step.append(time.perf_counter() - t1)
+    dt = float(np.median(per_step))
     prof = ctx.profile_dump()
     ctx.profile_enable(False)
     st = (C.c_int64 * 4)()
@@ -653,7 +663,8 @@ def skewed_workload(ctx, engine, alphabet, args, pipe, line):
                     f"{int((sizes == 1).sum())} singletons), lengths {int(lens.min())}..{int(lens.max())} (median {int(np.median(lens))}), "
                     f"2 % indels, 5 % low-complexity inserts; {args.alphabet} k={args.k}",
         "residues": int(off[-1]), "nnz": p.csr.nnz, "basis_columns": p.basis.ncols, "generator_s": gen_s,
-        "ms_per_step": dt * 1e3, "sequences_per_s": n / dt, "residues_per_s": int(off[-1]) / dt,
+        "ms_per_step": dt * 1e3, "ms_per_step_each": [round(x * 1e3, 3) for x in per_step], "sequences_per_s": n / dt,
+        "residues_per_s": int(off[-1]) / dt,
         "rows_sent_to_large_table_pass": int(st[0]), "strips_left_to_cursor_kernel": int(st[1]),
         "neighbour_list_entries_behind_fixed_slots": int(st[2]), "wide_strips": int(st[3]),
         "stage_ms_per_step": stages,
