@@ -517,8 +517,9 @@ int skm_fasta_parse(const uint8_t *h_buf, int64_t len, int nthreads, int64_t nre
  * unzip reads.  Members whose .npy header says '<U' (little-endian UTF-32: kmerlist, ids, seqs - three quarters of the
  * bytes) are tokenised by the library itself (a 4-byte unit repeats the previous item, repeats the previous unit, or
  * is one literal + a 3-byte match; dynamic Huffman per chunk; `level` only says compressed or stored there): 5-7x
- * zlib's speed on such bytes, 4-13 % larger; other chunks go through zlib at `level`, Huffman-only when a probe says
- * string matching buys nothing (column ids).  *out_file_bytes (optional) = size of the file written. */
+ * zlib's speed on such bytes, 2-13 % larger; '<u4' / '<i4' / '<u8' / '<i8' members take the same tokeniser on 4-byte
+ * units (column ids: zlib's size at 5x its speed); other chunks go through zlib at `level`, or through the library's
+ * Huffman coder when a probe says string matching buys nothing.  *out_file_bytes (optional) = size of the file written. */
 int skm_npz_write(const char *path, int nmembers, const char *const *names, const void *const *h_headers,
                   const int64_t *header_bytes, const void *const *h_data, const int64_t *data_bytes, int level,
                   int nthreads, int64_t *out_file_bytes);

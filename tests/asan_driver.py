@@ -121,7 +121,9 @@ def check_npz(lib):
               # longer than the deflate window, incompressible numbers (Huffman-only probe)
               "sorted": np.unique(np.array(["".join(r) for r in rng.choice(list("SNDQEH"), size=(60000, 12))])),
               "text": np.array(["", "αβγ", "😀x", "A" * 700, "日本語"] * 400), "long": np.array(["Q" * 40000, "QR" * 9]),
-              "noise": rng.integers(0, 1 << 32, size=300_000, dtype=np.uint64)}
+              "noise": rng.integers(0, 1 << 32, size=300_000, dtype=np.uint64),
+              "ids": np.tile(np.sort(rng.integers(0, 90000, size=(40, 289)), axis=1).astype(np.uint32), (9, 1)).reshape(-1),
+              "rowptr": np.cumsum(rng.integers(200, 300, size=70001)), "bytes": rng.integers(0, 7, size=400_001, dtype=np.uint8)}
     with tempfile.TemporaryDirectory() as tmp:
         for compressed in (True, False):
             for th in (1, 4):

@@ -242,6 +242,22 @@ def test_threaded_npz_writer_matches_numpy_savez(tmp_path):
         with np.load(path) as got:
             for key, want in members.items():
                 assert got[key].dtype == want.dtype and got[key].shape == want.shape and (got[key] == want).all(), (i, key)
+    # integer members take the same unit encoder (no item structure): column ids with repeated stretches, counts, row
+    # starts (8-byte elements that differ in the low byte), negative values, sizes around the chunk size
+    ids = np.sort(rng.integers(0, 90000, size=(700, 289)), axis=1).astype(np.uint32)
+    ids[1::3] = ids[0::3][: len(ids[1::3])]  # every third row repeats its neighbour, like a relative's row of k-mer ids
+    numbers = {"col": ids.reshape(-1), "val": (1 + (rng.random(300000) < 0.02)).astype(np.uint32), "rowptr": np.cumsum(rng.integers(200, 300, size=40001)),
+               "neg": rng.integers(-5, 5, size=(1 << 17) + 3).astype(np.int32), "edge": np.arange((1 << 19) // 8 + 1, dtype=np.int64),
+               "u8": rng.integers(0, 2**63, size=70000, dtype=np.uint64), "f4": rng.normal(size=3000).astype(np.float32)}
+    path = str(tmp_path / "numbers.npz")
+    size = sio.save_npz(path, numbers, threads=4)
+    np.savez_compressed(tmp_path / "numbers_ref.npz", **numbers)
+    assert size <= 1.10 * os.path.getsize(tmp_path / "numbers_ref.npz")
+    with zipfile.ZipFile(path) as z:
+        assert z.testzip() is None
+    with np.load(path) as got:
+        for key, want in numbers.items():
+            assert got[key].dtype == want.dtype and (got[key] == want).all(), key
     # units that do not compress at all (random 32-bit patterns viewed as '<U1'): the encoder falls back to stored blocks
     for count in (16, 1000, 300001):
         raw = rng.integers(0, 2**32, size=count, dtype=np.uint32)
