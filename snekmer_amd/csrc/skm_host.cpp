@@ -988,7 +988,23 @@ extern "C" int skm_npz_write(const char *path, int nmembers, const char *const *
     // 512 KiB: 16 back-reference windows (the chunk's first window starts empty: < 1 % of size), and short enough that
     // the slowest kind of chunk (zlib level 6 on near-random integers, ~17 MB/s) takes 30 ms, not 120: a 10 k-sequence
     // file has only ~200 of them to spread over the threads
-    constexpr size_t CHUNK = (size_t)1 << 19;
+    constexpr size_t CHUNK_MAX = (size_t)1 << 19, CHUNK_MIN = (size_t)1 << 17;
+    unsigned hw = std::thread::hardware_concurrency();
+    {
+        cpu_set_t set;  // the cores this process may run on (a cgroup / taskset share of the host), not the host's
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0)
+            hw = (unsigned)CPU_COUNT(&set);
+    }
+    size_t nt = nthreads >= 1 ? (size_t)nthreads : (hw ? hw : 1);
+    if (nt > 64)
+        nt = 64;
+    // a small file (one proteome: 40 MB of arrays) has few chunks of 512 KiB in its slowest member (8 for 4 MB of column
+    // ids): members are cut so that every thread gets about two chunks, down to 128 KiB (four windows)
+    int64_t total_bytes = 0;
+    for (int m = 0; m < nmembers; ++m)
+        total_bytes += data_bytes && data_bytes[m] > 0 ? data_bytes[m] : 0;
+    size_t CHUNK = ((size_t)(total_bytes / (int64_t)(2 * nt)) + 65535) / 65536 * 65536;
+    CHUNK = CHUNK < CHUNK_MIN ? CHUNK_MIN : (CHUNK > CHUNK_MAX ? CHUNK_MAX : CHUNK);
     std::vector<npz_chunk> chunks;
     std::vector<size_t> first_chunk((size_t)nmembers + 1, 0);
     for (int m = 0; m < nmembers; ++m) {
@@ -1025,15 +1041,6 @@ extern "C" int skm_npz_write(const char *path, int nmembers, const char *const *
         }
     }
     first_chunk[nmembers] = chunks.size();
-    unsigned hw = std::thread::hardware_concurrency();
-    {
-        cpu_set_t set;  // the cores this process may run on (a cgroup / taskset share of the host), not the host's
-        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0)
-            hw = (unsigned)CPU_COUNT(&set);
-    }
-    size_t nt = nthreads >= 1 ? (size_t)nthreads : (hw ? hw : 1);
-    if (nt > 64)
-        nt = 64;
     if (nt > chunks.size())
         nt = chunks.size() ? chunks.size() : 1;
     std::atomic<size_t> next{0};
