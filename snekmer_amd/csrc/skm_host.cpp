@@ -999,11 +999,13 @@ extern "C" int skm_npz_write(const char *path, int nmembers, const char *const *
     if (nt > 64)
         nt = 64;
     // a small file (one proteome: 40 MB of arrays) has few chunks of 512 KiB in its slowest member (8 for 4 MB of column
-    // ids): members are cut so that every thread gets about two chunks, down to 128 KiB (four windows)
+    // ids, 4-5 ms each, while the padded strings beside them run five times faster): members are cut so that every
+    // thread gets about eight chunks, down to 128 KiB (four windows).  (Measured and not kept: worker threads that
+    // outlive the call and per-thread scratch buffers - the same 6-7 ms for that file, +4 % at 100 k sequences.)
     int64_t total_bytes = 0;
     for (int m = 0; m < nmembers; ++m)
         total_bytes += data_bytes && data_bytes[m] > 0 ? data_bytes[m] : 0;
-    size_t CHUNK = ((size_t)(total_bytes / (int64_t)(2 * nt)) + 65535) / 65536 * 65536;
+    size_t CHUNK = ((size_t)(total_bytes / (int64_t)(8 * nt)) + 65535) / 65536 * 65536;
     CHUNK = CHUNK < CHUNK_MIN ? CHUNK_MIN : (CHUNK > CHUNK_MAX ? CHUNK_MAX : CHUNK);
     std::vector<npz_chunk> chunks;
     std::vector<size_t> first_chunk((size_t)nmembers + 1, 0);
