@@ -1563,7 +1563,7 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
             SKM_PROF_ON(ctx, "k_cosine_heavy", s_w);
 #define SKM_HEAVY(MODE, VEC)                                                                                         \
     do {                                                                                                             \
-        if (use_panels) /* rows with a panel: 16384-column steps, two workgroups per CU */                           \
+        if (use_panels) /* rows with a panel first (the PANEL form skips the others) */                              \
             k_cosine_heavy<MODE, VEC, PW, true, HEAVYP_CH, HEAVYP_TB, HEAVYP_EMAX><<<skm_grid_cap(ctx, bn, 1), HEAVYP_TB, 0, s_w>>>( \
                 d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, d_ypost, d_ypostcnt, d_yrnorm, row0, b0, b_over_list, \
                 b_over_count, g_len, d_out, ld, pnl);                                                                \
