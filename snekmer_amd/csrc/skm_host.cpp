@@ -528,6 +528,21 @@ void encode(const uint8_t *src, size_t len, int item_bytes, bool last, std::vect
         memcpy(&v, src + 4 * i, 4);
         return v;
     };
+    // units from `from` on that equal the unit `back` units before them (two units per step while both match)
+    auto run_back = [&](size_t from, size_t back) {
+        size_t r = 0;
+        while (from + r + 2 <= units) {
+            uint64_t a, b;
+            memcpy(&a, src + 4 * (from + r), 8);
+            memcpy(&b, src + 4 * (from + r - back), 8);
+            if (a != b)
+                break;
+            r += 2;
+        }
+        while (from + r < units && unit(from + r) == unit(from + r - back))
+            ++r;
+        return r;
+    };
     std::vector<uint32_t> tok;
     tok.reserve(units + 16);
     uint32_t flit[286] = {}, fdist[30] = {};
@@ -597,21 +612,13 @@ void encode(const uint8_t *src, size_t len, int item_bytes, bool last, std::vect
         const uint32_t u = unit(p);
         size_t r_item = 0, r_unit = 0, r_far = 0, far_at = 0, r_shift = 0, r_two = 0;
         if (w && p >= w)
-            while (p + r_item < units && unit(p + r_item) == unit(p + r_item - w))
-                ++r_item;
-        if (p >= 1 && u == unit(p - 1)) {
-            r_unit = 1;
-            while (p + r_unit < units && unit(p + r_unit) == u)
-                ++r_unit;
-        }
-        if (w == 0 && p >= 2 && r_unit == 0 && u == unit(p - 2)) {  // numbers: the unit two back (8-byte elements)
-            r_two = 1;
-            while (p + r_two < units && unit(p + r_two) == unit(p + r_two - 2))
-                ++r_two;
-        }
+            r_item = run_back(p, w);
+        if (p >= 1 && u == unit(p - 1))
+            r_unit = run_back(p, 1);
+        if (w == 0 && p >= 2 && r_unit == 0 && u == unit(p - 2))  // numbers: the unit two back (8-byte elements)
+            r_two = run_back(p, 2);
         if (w > 2 && p >= w - 1 && r_item < w - 1)  // the previous item moved up by one character (k-mers in window order)
-            while (p + r_shift < units && unit(p + r_shift) == unit(p + r_shift - (w - 1)))
-                ++r_shift;
+            r_shift = run_back(p, w - 1);
         if (r_shift > r_item && r_shift > r_unit && r_shift >= 2) {
             emit_match(r_shift, (int)(w - 1) * 4);
             note(p, r_shift);
