@@ -238,6 +238,11 @@ def connection_matrix_from_features(feature_matrix, metric="jaccard"):
     return pairwise_distances(feature_matrix, metric=metric)
 
 
+# what sklearn.metrics.pairwise_distances accepts as a metric name (scikit-learn 1.7: _VALID_METRICS + "precomputed")
+SKLEARN_METRICS = ("braycurtis", "canberra", "chebyshev", "cityblock", "correlation", "cosine", "dice", "euclidean", "hamming", "haversine",
+                   "jaccard", "l1", "l2", "mahalanobis", "manhattan", "matching", "minkowski", "nan_euclidean", "precomputed", "rogerstanimoto",
+                   "russellrao", "seuclidean", "sokalmichener", "sokalsneath", "sqeuclidean", "wminkowski", "yule")
+
 # metric name -> id of skm_pairwise_f64 (include/snekmer_hip.h)
 PAIRWISE_METRICS = {"cityblock": 0, "manhattan": 0, "l1": 0, "sqeuclidean": 1, "euclidean": 2, "l2": 2, "chebyshev": 3, "canberra": 4,
                     "braycurtis": 5, "minkowski": 6, "dice": 10, "rogerstanimoto": 11, "russellrao": 12, "sokalmichener": 13,
@@ -255,8 +260,10 @@ def pairwise_distances(X, metric: str = "euclidean", p: float = 2.0, ctx=None) -
     The three metrics that need more than the two rows are one O(n d^2) pass over the matrix on the host followed by a
     device kernel on the transformed rows (`_whole_matrix_metric`): "correlation" = cosine distance of the row-centred
     matrix, "seuclidean" = euclidean after dividing every column by its standard deviation (V = var(X, ddof=1), what
-    sklearn passes to scipy), "mahalanobis" = euclidean after X -> X L with L L^T = VI = inv(cov(X^T))^T.  Anything else
-    raises NotImplementedError: no Snekmer rule passes another metric."""
+    sklearn passes to scipy), "mahalanobis" = euclidean after X -> X L with L L^T = VI = inv(cov(X^T))^T.  The rest of
+    scikit-learn's names ("haversine", "nan_euclidean", "precomputed", "wminkowski", the true "jaccard" through this
+    function) raise NotImplementedError - no Snekmer rule passes them -, a name scikit-learn does not know raises its
+    ValueError."""
     import ctypes as C
 
     from . import _hip
@@ -267,6 +274,10 @@ def pairwise_distances(X, metric: str = "euclidean", p: float = 2.0, ctx=None) -
         return _set_measure(X, 2, ctx)
     if metric in ("correlation", "seuclidean", "mahalanobis"):
         return _whole_matrix_metric(X, metric, ctx)
+    if not isinstance(metric, str) or metric not in SKLEARN_METRICS:
+        # scikit-learn's own refusal (an InvalidParameterError, which is a ValueError) for a name it does not know
+        raise ValueError(f"The 'metric' parameter of pairwise_distances must be a str among {set(SKLEARN_METRICS)} or a callable. "
+                         f"Got {metric!r} instead.")
     if metric not in PAIRWISE_METRICS:
         raise NotImplementedError(
             f"metric={metric!r}: implemented on the device are 'cosine', 'hamming', the reference's default 'jaccard' "

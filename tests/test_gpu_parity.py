@@ -555,6 +555,8 @@ def test_connection_matrix_and_feature_matrix_goldens(ctx):
     for key, M in (("jaccard_x", g["X"]), ("jaccard_demo_counts", counts), ("jaccard_float", g15["F"])):
         assert (skm.score.jaccard_distance(M) == g15[key]).all(), key
     with pytest.raises(NotImplementedError):
+        skm.score.connection_matrix_from_features(g["X"], metric="haversine")
+    with pytest.raises(ValueError):  # a name scikit-learn itself refuses
         skm.score.connection_matrix_from_features(g["X"], metric="jensenshannon")
     with pytest.raises(ValueError):
         skm.score.connection_matrix_from_features(np.asarray([[1.0, np.nan], [0.0, 1.0]]))
@@ -638,7 +640,11 @@ def test_connection_matrix_other_sklearn_metrics_match_sklearn(ctx):
     with pytest.raises(np.linalg.LinAlgError):
         skm.score.connection_matrix_from_features(np.hstack([tall, tall[:, :1]]), metric="mahalanobis")  # singular covariance
     with pytest.raises(NotImplementedError):
+        skm.score.connection_matrix_from_features(counts, metric="nan_euclidean")
+    with pytest.raises(ValueError):
         skm.score.connection_matrix_from_features(counts, metric="jensenshannon")
+    with pytest.raises(ValueError):
+        pairwise_distances(counts, metric="jensenshannon")  # scikit-learn's InvalidParameterError is a ValueError too
 
 
 # ------------------------------------------------------------------ BASELINE sizes: properties
