@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SKM_ABI_VERSION 3
+#define SKM_ABI_VERSION 4
 
 #define SKM_OK 0
 #define SKM_E_BADARG (-1)
@@ -53,6 +53,12 @@ int skm_abi_version(void);
 const char *skm_last_error(void);
 int skm_device_count(int *h_count);
 int skm_create(int device_id, skm_ctx **out_ctx);
+/* A context whose stream may only use the compute-unit groups first..last of 0..7 (group of CU i: (i / 8) % 8, i.e. eight
+ * CUs of every XCD per group).  For a SIDE context: engine.OverlappedPipeline vectorizes the next batch on one confined
+ * to groups 0-3 while the main context's store-bound writer runs, so that neither fills the other's wave slots (9.66
+ * against 10.5 ms per step unconfined and 10.8 on one stream; no reference counterpart: one process per FASTA file,
+ * snekmer/rules/kmerize.smk:57-65).  SKM_E_UNSUPPORTED on devices with fewer than 64 or more than 512 CUs. */
+int skm_create_confined(int device_id, int first_cu_group, int last_cu_group, skm_ctx **out_ctx);
 int skm_destroy(skm_ctx *ctx);
 /* Ordering between two contexts of one process on one device (a context is one stream): skm_event_record marks the
  * current end of ctx's stream in slot [0, SKM_EVENT_SLOTS); skm_stream_wait makes everything queued on ctx from now

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNEKMER_HIP_LIB") or os.path.join(_HERE, "libsnekmer_hip.so")
 
 SKM_OK = 0
-ABI_VERSION = 3  # SKM_ABI_VERSION of include/snekmer_hip.h
+ABI_VERSION = 4  # SKM_ABI_VERSION of include/snekmer_hip.h
 ERRORS = {-1: "BADARG", -2: "NOMEM", -3: "HIP", -4: "OVERFLOW", -5: "UNSUPPORTED", -6: "COMM"}
 COMM_ID_BYTES = 128
 
@@ -49,6 +49,7 @@ _SIGNATURES = {
     "skm_last_error": (C.c_char_p, []),
     "skm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "skm_create": (C.c_int, [C.c_int, C.POINTER(_p)]),
+    "skm_create_confined": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_p)]),
     "skm_destroy": (C.c_int, [_p]),
     "skm_sync": (C.c_int, [_p]),
     "skm_event_record": (C.c_int, [_p, C.c_int]),
@@ -230,14 +231,20 @@ class Context:
     small-batch arena of engine.recode_host / kmer_codes_host is per context and unguarded); distinct contexts may be
     used from distinct threads."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, cu_groups: Optional[Tuple[int, int]] = None):
+        """`cu_groups=(first, last)`: the context's stream may only use those compute-unit groups of 0..7
+        (skm_create_confined): a side context for work that should run beside another context's kernels."""
         self.lib = load_library()
         if device_count() <= device:
             raise HipUnavailable(
                 f"no HIP device {device} visible ({device_count()} found); snekmer_amd has no CPU fallback"
             )
         handle = _p()
-        _check(self.lib, self.lib.skm_create(device, C.byref(handle)))
+        if cu_groups is None:
+            _check(self.lib, self.lib.skm_create(device, C.byref(handle)))
+        else:
+            _check(self.lib, self.lib.skm_create_confined(device, int(cu_groups[0]), int(cu_groups[1]), C.byref(handle)))
+        self.cu_groups = cu_groups
         self.handle = handle
         self.device = device
 

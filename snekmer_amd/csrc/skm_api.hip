@@ -22,25 +22,52 @@ extern "C" int skm_device_count(int *h_count)
     return SKM_OK;
 }
 
-extern "C" int skm_create(int device_id, skm_ctx **out_ctx)
+namespace {
+// first_group < 0: an ordinary stream.  Otherwise the context's stream is confined to the CU groups first..last of 0..7
+// (mask bit i: group (i / 8) % 8 - every group has eight CUs in every XCD -, as the two streams of the overlapped cosine
+// schedule are).
+int create_ctx(int device_id, int first_group, int last_group, skm_ctx **out_ctx, const char *who)
 {
-    SKM_REQUIRE(out_ctx, SKM_E_BADARG, "skm_create: null output");
+    SKM_REQUIRE(out_ctx, SKM_E_BADARG, "%s: null output", who);
     *out_ctx = nullptr;
     int n = 0;
     SKM_HIP(hipGetDeviceCount(&n));
-    SKM_REQUIRE(device_id >= 0 && device_id < n, SKM_E_BADARG,
-                "skm_create: device %d out of range (%d visible)", device_id, n);
+    SKM_REQUIRE(device_id >= 0 && device_id < n, SKM_E_BADARG, "%s: device %d out of range (%d visible)", who, device_id, n);
     SKM_HIP(hipSetDevice(device_id));
-    skm_ctx *ctx = new skm_ctx();
-    ctx->device = device_id;
     hipDeviceProp_t prop;
     SKM_HIP(hipGetDeviceProperties(&prop, device_id));
+    hipStream_t stream = nullptr;
+    if (first_group >= 0) {
+        const int ncu = prop.multiProcessorCount;
+        SKM_REQUIRE(first_group <= last_group && last_group <= 7, SKM_E_BADARG, "%s: CU groups %d..%d (want 0 <= first <= last <= 7)", who,
+                    first_group, last_group);
+        SKM_REQUIRE(ncu >= 64 && ncu <= 512, SKM_E_UNSUPPORTED, "%s: %d compute units", who, ncu);
+        uint32_t mask[16] = {};
+        for (int i = 0; i < ncu; ++i)
+            if ((i / 8) % 8 >= first_group && (i / 8) % 8 <= last_group)
+                mask[i / 32] |= 1u << (i % 32);
+        SKM_HIP(hipExtStreamCreateWithCUMask(&stream, (uint32_t)((ncu + 31) / 32), mask));
+    } else {
+        SKM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    }
+    skm_ctx *ctx = new skm_ctx();
+    ctx->device = device_id;
     ctx->num_cus = prop.multiProcessorCount;
-    SKM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->stream = stream;
     SKM_HIP(hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocDefault));
     memset(ctx->h_pinned, 0, 4096);  // (offset 2048: the previous cosine call's heavy-row count, skm_cosine_csr.hip)
     *out_ctx = ctx;
     return SKM_OK;
+}
+}  // namespace
+
+extern "C" int skm_create(int device_id, skm_ctx **out_ctx) { return create_ctx(device_id, -1, -1, out_ctx, "skm_create"); }
+
+extern "C" int skm_create_confined(int device_id, int first_cu_group, int last_cu_group, skm_ctx **out_ctx)
+{
+    SKM_REQUIRE(first_cu_group >= 0, SKM_E_BADARG, "skm_create_confined: CU groups %d..%d (want 0 <= first <= last <= 7)", first_cu_group,
+                last_cu_group);
+    return create_ctx(device_id, first_cu_group, last_cu_group, out_ctx, "skm_create_confined");
 }
 
 extern "C" int skm_destroy(skm_ctx *ctx)

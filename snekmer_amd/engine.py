@@ -728,9 +728,10 @@ class Pipeline:
 class OverlappedPipeline:
     """Pipeline for a STREAM of batches: while batch i's cosine runs on the main context, batch i+1 is vectorized on a
     second context (its own HIP stream and scratch) into a second set of buffers.  The stages in front of the writer
-    are latency- and issue-bound (0.13-0.29 of HBM each), so the next batch's count / sort / scatter
-    fill the machine beside this batch's sparse Gram; the HBM-bound writer then runs as before.  Results are the
-    single-stream Pipeline's, bit for bit (same kernels, same inputs; tests/test_gpu_parity.py).
+    are latency- and issue-bound (0.13-0.29 of HBM each) and the writer is store-bound; side by side on
+    the whole chip each crawls in the other's wave slots (10.5 against 10.8 ms per step), so the side context's stream is
+    confined to half of the compute units (skm_create_confined): 9.66 ms per step.  Results are the single-stream
+    Pipeline's, bit for bit (same kernels, same inputs; tests/test_gpu_parity.py).
 
         pipe = OverlappedPipeline(ctx, lut, k)
         pipe.prefetch(batch0)
@@ -742,9 +743,16 @@ class OverlappedPipeline:
 
     EV_VEC, EV_COS = 0, 2  # event slots: EV_VEC + set on the side context, EV_COS + set on the main one
 
+    SIDE_CU_GROUPS = (0, 3)  # measured on the bench workload: groups 0-0 12.7 ms, 0-1 10.1, 0-2 10.0, 0-3 9.66, 0-4 10.35, all 10.5
+
     def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int, side_ctx: Optional[_hip.Context] = None):
         self.ctx, self.lut, self.k = ctx, lut, k
-        self.side = side_ctx or _hip.Context(ctx.device)
+        if side_ctx is None:
+            try:  # half of the compute units: what the next batch's kernels may fill beside this batch's writer
+                side_ctx = _hip.Context(ctx.device, cu_groups=self.SIDE_CU_GROUPS)
+            except _hip.HipError:  # a device the CU-group masks are not defined for
+                side_ctx = _hip.Context(ctx.device)
+        self.side = side_ctx
         self.sets = [[None, None, None], [None, None, None]]  # (csr, basis, rnorm) per buffer set
         self.ready = None   # set holding a vectorized batch that has not been consumed yet
         self.nxt = 0

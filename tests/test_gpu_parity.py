@@ -1296,6 +1296,29 @@ def test_overlapped_pipeline_equals_pipeline_on_a_stream_of_batches(ctx):
         assert pipe.csr.nnz == int(pipe.csr.rowptr.download(1, offset=b.n)[0]) and pipe.csr.n == b.n
     with pytest.raises(RuntimeError):
         pipe.step(None)
+    assert pipe.side.cu_groups == engine.OverlappedPipeline.SIDE_CU_GROUPS  # the side stream is confined to half the chip
+
+
+def test_confined_context_is_an_ordinary_context_on_fewer_compute_units(ctx):
+    """skm_create_confined: a context whose stream may only use some CU groups computes what any context computes;
+    ranges outside 0..7 are refused."""
+    from snekmer_amd import _hip
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+
+    lut = A.build_lut("red6")
+    res, off, _ = synth_families(900, 300, family=30, seed=411)
+    want = engine.Pipeline(ctx, lut, 12).step(engine.SeqBatch(ctx, res, off))
+    want = want.download().reshape(want.shape).copy()
+    for groups in ((0, 0), (0, 3), (5, 7), (0, 7)):
+        side = _hip.Context(ctx.device, cu_groups=groups)
+        got = engine.Pipeline(side, lut, 12).step(engine.SeqBatch(side, res, off))
+        assert (got.download().reshape(got.shape) == want).all(), groups
+        side.close()
+    for bad in ((-1, 3), (4, 2), (0, 8)):
+        with pytest.raises(_hip.HipError):
+            _hip.Context(ctx.device, cu_groups=bad)
 
 
 # ------------------------------------------------------------------ BASELINE full sizes

@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert set(_hip.EXPORTED_SYMBOLS) == declared
-    assert lib.skm_abi_version() == 3
+    assert lib.skm_abi_version() == 4
 
 
 def test_product_library_carries_no_result_invalidating_switches():

@@ -19,12 +19,23 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     alphabet.register_alphabet("red6", alphabet.RED6_GROUPS)
-    ctx = _hip.Context(0)
+    def groups(var):
+        v = os.environ.get(var)
+        return tuple(int(x) for x in v.split("-")) if v else None
+
+    ctx = _hip.Context(0, cu_groups=groups("SKM_AB_MAIN_GROUPS"))  # (a confined main context confines the baseline too)
     lut = alphabet.build_lut("red6")
     res, off, _ = synth_families(n, 300, family=100, seed=BASE_SEED + 2)
     batch = engine.SeqBatch(ctx, res, off)
     a = engine.Pipeline(ctx, lut, 12)
-    b = engine.OverlappedPipeline(ctx, lut, 12)
+    # SKM_AB_SIDE_GROUPS=a-b: the side context confined to those CU groups (default: OverlappedPipeline's own choice, 0-3);
+    # SKM_AB_SIDE_GROUPS=all: an unconfined side context
+    side = None
+    if os.environ.get("SKM_AB_SIDE_GROUPS") == "all":
+        side = _hip.Context(0)
+    elif os.environ.get("SKM_AB_SIDE_GROUPS"):
+        side = _hip.Context(0, cu_groups=groups("SKM_AB_SIDE_GROUPS"))
+    b = engine.OverlappedPipeline(ctx, lut, 12, side_ctx=side)
     b.out = a.step(batch)  # share the 40 GB result buffer
     ctx.sync()
     ld = a.out.shape[1]
