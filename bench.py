@@ -890,8 +890,10 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
     del op
     note("extras: overlapped_pipeline")
     line["overlapped_pipeline"] = {"ms_per_step": op_ms, "sequences_per_s": n_total / (op_ms * 1e-3),
-                                   "what": "engine.OverlappedPipeline: the next batch's count / sort / scatter run on a second context "
-                                           "(own stream, second buffer set) beside this batch's cosine; results identical to Pipeline's"}
+                                   "what": "engine.OverlappedPipeline, a stream of batches: the next batch's count / sort / scatter run on a "
+                                           "second context (own stream confined to half of the compute units by skm_create_confined, second "
+                                           "buffer set) beside this batch's cosine; every step holds one complete vectorize and one complete "
+                                           "cosine; results identical to Pipeline's"}
 
     if args.alphabet == "red6":
         # red6 is a benchmark alphabet; the nearest reference alphabet (`standard`,
