@@ -1192,8 +1192,12 @@ extern "C" int skm_neighbors_topk(skm_ctx *ctx, int64_t nrows, int64_t row0, con
 }
 
 namespace {
-// Two streams confined to disjoint CU sets (mask bit i: CU group (i / 8) % 8; groups 0-2 build the
-// neighbour lists, groups 3-7 write) and the events that chain them.
+// The two streams of the blocked schedule and the events that chain them.  The Gram stream is confined to half of the
+// compute units (mask bit i: CU group (i / 8) % 8; groups 0-3); the writer's stream is not confined: it needs every
+// CU's wave slots to keep the stores flowing, and what it must be protected from is the Gram's workgroups taking LDS
+// and wave slots on ALL of them.  Measured at config 3, one batch per step: back to back 10.90 ms, Gram on groups
+// 0-2 / writer on 3-7 (round 2's split) 10.48, Gram on 0-2 / writer anywhere 10.35, Gram on 0-3 / writer anywhere
+// 10.24-10.33, Gram on 0-4 11.7.
 int overlap_streams(skm_ctx *ctx)
 {
     if (ctx->overlap_state != 0)
@@ -1202,11 +1206,12 @@ int overlap_streams(skm_ctx *ctx)
     const int ncu = ctx->num_cus;
     if (ncu < 64 || ncu > 512)
         return SKM_E_UNSUPPORTED;
-    uint32_t mw[16] = {}, mg[16] = {};
-    for (int i = 0; i < ncu; ++i)  // measured best split: 3/8 of the CUs build lists, 5/8 write
-        ((i / 8) % 8 >= 3 ? mw : mg)[i / 32] |= 1u << (i % 32);
+    uint32_t mg[16] = {};
+    for (int i = 0; i < ncu; ++i)
+        if ((i / 8) % 8 < 4)
+            mg[i / 32] |= 1u << (i % 32);
     const uint32_t words = (uint32_t)((ncu + 31) / 32);
-    if (hipExtStreamCreateWithCUMask(&ctx->s_writer, words, mw) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&ctx->s_writer, hipStreamNonBlocking) != hipSuccess ||
         hipExtStreamCreateWithCUMask(&ctx->s_gram, words, mg) != hipSuccess) {
         (void)hipGetLastError();
         return SKM_E_UNSUPPORTED;
@@ -1237,8 +1242,12 @@ bool heavy_panels_wanted(skm_ctx *ctx, int64_t nrows, int64_t m)
     const char *e = getenv("SKM_HEAVY_PANEL");
     if (e)
         return atoi(e) != 0;
-    const uint32_t last = *(volatile uint32_t *)((uint8_t *)ctx->h_pinned + 2048);
-    return last >= 4096u && last != 0xFFFFFFFFu;
+    // (one counter per row block of the blocked schedule, 16 words: the whole-call form uses the first only)
+    const volatile uint32_t *last = (const volatile uint32_t *)((uint8_t *)ctx->h_pinned + 2048);
+    uint64_t heavy = 0;
+    for (int b = 0; b < 16; ++b)
+        heavy += last[b];
+    return heavy >= 4096u;
 }
 
 template <typename PW>
@@ -1463,17 +1472,21 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     constexpr int gabl = 0;
 #endif
 
-    // Schedule.  By default the three kernels run back to back on the context's stream.
-    // SKM_COSINE_OVERLAP=1 selects a blocked schedule for large outputs: the rows are cut into 8
-    // blocks; block b's lists are built on a stream confined to 3/8 of the CUs while block b-1 is
-    // written on a stream confined to the other 5/8 (unconfined, the Gram workgroups take the
-    // writer's LDS and wave slots and the pair runs slower than back to back).  Measured at config 3:
-    // 10.75 vs 10.97 ms per step (+2 %), but both kernels run slower side by side (writer 7.8 vs 6.8 ms
-    // summed over its launches: the Gram's 4.4 GB of gathers share HBM with the stores), so the
-    // writer's own roofline fraction drops from 0.72 to 0.64; it is therefore opt-in.
+    // Schedule.  By default the kernels run back to back on the context's stream.  SKM_COSINE_OVERLAP=1 selects a
+    // blocked schedule for outputs of 2 GB and more: the rows are cut into 8 blocks; block b's lists are built on a
+    // stream confined to half of the CUs while block b-1 is written on an unconfined one (overlap_streams above).
+    // Measured at config 3 (round 4): 10.45 against 10.98 ms per step, 10.70 against 11.06 with the per-stage events of
+    // the profiler on - and inside bench.py's timed region (events on, a box whose single stream took 10.6) 10.59
+    // against 10.61.  Both kernels run slower side by side (the Gram's 4.4 GB of gathers share HBM with the stores:
+    // the writer's launches sum to 7.5-7.7 ms instead of 6.6-7.1), so the writer's own roofline fraction drops from 0.72-0.76
+    // to 0.66 for a gain inside the box-to-box spread: it stays opt-in.  A batch whose previous call handed thousands of
+    // rows to the heavy kernel takes the panel pipeline (written for the whole call) whatever the variable says.
     const char *ov_env = getenv("SKM_COSINE_OVERLAP");
+    bool panels_first = false;
+    if constexpr (sizeof(PW) == 8)
+        panels_first = heavy_panels_wanted(ctx, nrows, m);
     int nblk = 1;
-    if (gabl == 0 && ov_env && atoi(ov_env) == 1 && nrows >= 4096 && (double)nrows * (double)ld * 4.0 >= 2e9 &&
+    if (gabl == 0 && ov_env && atoi(ov_env) == 1 && !panels_first && nrows >= 4096 && (double)nrows * (double)ld * 4.0 >= 2e9 &&
         overlap_streams(ctx) == SKM_OK)
         nblk = 8;
 #ifdef SKM_DIAG
@@ -1552,7 +1565,7 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
         panel_bufs pnl = {};
         bool use_panels = false;
         if constexpr (sizeof(PW) == 8) {
-            if (nblk == 1 && heavy_panels_wanted(ctx, nrows, m)) {
+            if (nblk == 1 && panels_first) {
                 SKM_TRY(heavy_panels_run<PW>(ctx, d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, m, row0, b0, bn,
                                              b_over_list, b_over_count, &pnl, s_w));
                 use_panels = true;
@@ -1576,11 +1589,6 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
 #undef SKM_HEAVY
         }
         SKM_TRY(skm_check_launch("k_cosine_heavy"));
-        if (nblk == 1) {
-            // how many rows this call handed on: the next call on this context reads it (without waiting) to decide
-            // whether the panel pipeline is worth its dozen launches (heavy_panels_wanted)
-            SKM_HIP(hipMemcpyAsync((uint8_t *)ctx->h_pinned + 2048, b_over_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s_w));
-        }
         {
             // one output row per workgroup of 1024 threads
             SKM_PROF_ON(ctx, "k_cosine_write", s_w);
@@ -1606,6 +1614,9 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
         SKM_HIP(hipStreamWaitEvent(st, ctx->sync_events[1 + MAXB], 0));
         SKM_HIP(hipStreamWaitEvent(st, ctx->sync_events[2 + MAXB], 0));
     }
+    // how many rows this call handed on (one counter per row block): the next call on this context reads them (without
+    // waiting) to decide whether the panel pipeline is worth its dozen launches (heavy_panels_wanted)
+    SKM_HIP(hipMemcpyAsync((uint8_t *)ctx->h_pinned + 2048, over_count, sizeof(uint32_t) * MAXB, hipMemcpyDeviceToHost, st));
     {
         // strips with a row still flagged; worst-case grid, surplus workgroups exit at once
         SKM_PROF(ctx, "k_cosine_strip");
