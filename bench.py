@@ -871,7 +871,8 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
         os.environ.pop("SKM_COSINE_OVERLAP", None)
     note("extras: overlap_schedule")
     line["overlap_schedule"] = {"ms_per_step": ov_ms, "sequences_per_s": n_total / (ov_ms * 1e-3),
-                                "what": "SKM_COSINE_OVERLAP=1: same step, Gram and writer kernels on two CU-partitioned streams"}
+                                "what": "SKM_COSINE_OVERLAP=1: same step in 8 row blocks, the Gram of block b+1 on a stream confined to half of the "
+                                        "compute units beside the writer of block b on an unconfined stream"}
 
     # engine.OverlappedPipeline: a stream of batches, batch i+1 vectorized on a second context while batch i's cosine runs
     op = engine.OverlappedPipeline(ctx, pipe.lut, pipe.k)
