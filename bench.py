@@ -297,6 +297,10 @@ def main():
     ap.add_argument("--length", type=int, default=300)
     ap.add_argument("--k", type=int, default=12)
     ap.add_argument("--alphabet", default="red6")
+    ap.add_argument("--pipeline", choices=("overlapped", "single"), default="overlapped",
+                    help="one GPU: 'overlapped' = engine.OverlappedPipeline, the steps of a stream of batches (the next batch's count / sort / "
+                         "basis run on a second, CU-confined stream beside this batch's cosine; every step holds one complete vectorize and "
+                         "one complete cosine); 'single' = engine.Pipeline, one batch at a time on one stream")
     ap.add_argument("--cpu-points", default="250,500,1000,2000",
                     help="N values at which the reference-equivalent numpy path is timed (BASELINE.md section 3)")
     ap.add_argument("--cpu-budget-s", type=float, default=210.0, help="wall-time bound of the CPU-baseline leg")
@@ -377,11 +381,21 @@ def main():
     n_total = args.n
     residues_total = int(off[-1])
 
+    op = None
     if not sharded:
         batch = engine.SeqBatch(ctx, res, off)
         pipe = engine.Pipeline(ctx, lut, args.k)
         step = lambda: pipe.step(batch)
         rows_local = n_total
+        if args.pipeline == "overlapped":
+            # a stream of batches (here: the same batch again and again, every step recomputing everything).  The one-stream
+            # pipeline runs once first: the 40 GB result buffer is shared, and the extras measure it by itself afterwards
+            pipe.step(batch)
+            ctx.sync()
+            op = engine.OverlappedPipeline(ctx, lut, args.k)
+            op.out = pipe.out
+            op.prefetch(batch)
+            step = lambda: op.step(batch)
     else:
         from snekmer_amd.dist import RcclExchange, ShardedPipeline, shard_bounds
 
@@ -402,6 +416,8 @@ def main():
 
     def barrier():
         ctx.sync()
+        if op is not None:
+            op.sync()
         if dist is not None:
             dist.barrier()
         ctx.sync()
@@ -410,17 +426,30 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.profile_enable(True)
-    ctx.profile_reset()
+    prof_ctxs = [ctx] + ([op.side] if op is not None else [])  # the side context times the vectorize stages of the next batch
+    for c in prof_ctxs:
+        c.profile_enable(True)
+        c.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = ctx.profile_dump()
-    ctx.profile_enable(False)
+    prof = {}
+    for c in prof_ctxs:
+        for key, (calls, ms) in c.profile_dump().items():
+            have = prof.get(key, (0, 0.0))
+            prof[key] = (have[0] + calls, have[1] + ms)
+        c.profile_enable(False)
     note(f"timed region: {elapsed / args.steps * 1e3:.3f} ms/step on rank {rank}")
+    if op is not None:
+        op.step(None)  # the batch still prefetched: nothing stays queued
+        op.sync()
+        op.out = None
+        side = op.side
+        op = prof_ctxs = None
+        side.close()  # its stream goes too: HIP maps streams onto four hardware queues, and the extras open more
 
     shard_check = None
     if dist is not None:
@@ -491,6 +520,14 @@ def main():
                 "basis_columns": pipe.basis.ncols,
                 "parallelism": f"row-sharded x{world}, postings built by k-mer owner (RCCL all-to-all + all-gathers)"
                 if sharded else "single GPU",
+                "pipelining": ("engine.OverlappedPipeline: the steps of a stream of batches.  While a step's cosine (sparse Gram + N x N writer) "
+                               "runs on the main stream, the NEXT batch's recode + count + sort + basis / postings run on a second stream "
+                               "confined to half of the compute units (skm_create_confined).  Every timed step holds one complete "
+                               "vectorize and one complete cosine - the batch vectorized in the last timed step is never consumed, the one "
+                               "consumed in the first was vectorized during the warm-up - and every result is recomputed from the residues, "
+                               "bit-identical to the one-stream pipeline's (tests/test_gpu_parity.py).  `single_batch_step` in this line: the "
+                               "same work for ONE batch on one stream (engine.Pipeline; python3 bench.py --pipeline single times that)")
+                if (not sharded and args.pipeline == "overlapped") else "none: one batch at a time on one stream",
             },
             "residues_per_s": residues_total / (elapsed / args.steps),
             "stage_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
@@ -582,7 +619,7 @@ def sharded_stage_rooflines(engine, args, pipe, prof, world, residues_local, row
     return out
 
 
-def stage_rooflines(ctx, engine, args, pipe, prof, residues_total):
+def stage_rooflines(ctx, engine, args, pipe, prof, residues_total, steps=None):
     """Every stage of the step: algorithmic bytes / measured time."""
     import ctypes as C
 
@@ -615,7 +652,7 @@ def stage_rooflines(ctx, engine, args, pipe, prof, residues_total):
         cnt, ms = prof.get(name, (0, 0.0))
         if not cnt:
             continue
-        per_step = ms / args.steps
+        per_step = ms / (steps or args.steps)
         gbs = nbytes / (per_step * 1e-3) / 1e9
         out.append({"kernel": name, "bound": "hbm", "algorithmic_bytes_per_step": int(nbytes), "ms_per_step": per_step,
                     "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS, "bytes_are": what})
@@ -839,7 +876,36 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
     from snekmer_amd.synth import BASE_SEED, synth_families
 
     n_total = args.n
-    line["stage_rooflines"], counts = stage_rooflines(ctx, engine, args, pipe, prof, int(off[-1]))
+    # ONE batch on one stream (engine.Pipeline), nothing of another batch beside it: the single-batch latency, and the
+    # stage times the per-stage rooflines are taken from (in the pipelined timed region every stage shares the chip with
+    # another batch's kernels)
+    pipe.step(batch)
+    ctx.sync()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    t1 = time.perf_counter()
+    for _ in range(10):
+        pipe.step(batch)
+    ctx.sync()
+    one_ms = (time.perf_counter() - t1) / 10 * 1e3
+    one_prof = ctx.profile_dump()
+    ctx.profile_enable(False)
+    w_calls, w_ms = one_prof.get("k_cosine_write", (0, 0.0))
+    w_avg = w_ms / max(w_calls, 1)
+    w_bytes = n_total * ((n_total + 3) // 4 * 4) * 4
+    note("extras: single_batch_step")
+    line["single_batch_step"] = {
+        "what": "engine.Pipeline.step: one batch, every kernel back to back on one stream (python3 bench.py --pipeline single times this as "
+                "the headline)",
+        "ms_per_step": one_ms, "sequences_per_s": n_total / (one_ms * 1e-3),
+        "stage_ms_per_step": {k: v[1] / 10 for k, v in one_prof.items()},
+        "k_cosine_write_alone": {"avg_launch_ms": w_avg, "GBps": w_bytes / (w_avg * 1e-3) / 1e9 if w_avg > 0 else None,
+                                 "frac_of_hbm_peak": w_bytes / (w_avg * 1e-3) / 1e9 / HBM_PEAK_GBS if w_avg > 0 else None},
+    }
+    line["roofline"]["single_batch"] = {"avg_launch_ms": w_avg, "achieved": w_bytes / (w_avg * 1e-3) / 1e9 if w_avg > 0 else None,
+                                        "frac": w_bytes / (w_avg * 1e-3) / 1e9 / HBM_PEAK_GBS if w_avg > 0 else None,
+                                        "what": "the same kernel in single_batch_step: one launch with the chip to itself"}
+    line["stage_rooflines"], counts = stage_rooflines(ctx, engine, args, pipe, one_prof, int(off[-1]), steps=10)
     line["config"].update(counts)
 
     # host -> result: H2D of the packed batch + one step, synchronised (FASTA parse excluded)
@@ -874,27 +940,28 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
                                 "what": "SKM_COSINE_OVERLAP=1: same step in 8 row blocks, the Gram of block b+1 on a stream confined to half of the "
                                         "compute units beside the writer of block b on an unconfined stream"}
 
-    # engine.OverlappedPipeline: a stream of batches, batch i+1 vectorized on a second context while batch i's cosine runs
-    op = engine.OverlappedPipeline(ctx, pipe.lut, pipe.k)
-    op.out = pipe.out  # share the 40 GB result buffer
-    op.prefetch(batch)
-    op.step(batch)
-    op.sync()
-    t1 = time.perf_counter()
-    for _ in range(10):
+    if args.pipeline != "overlapped":  # (the timed region itself otherwise)
+        # engine.OverlappedPipeline: a stream of batches, batch i+1 vectorized on a second context while batch i's cosine runs
+        op = engine.OverlappedPipeline(ctx, pipe.lut, pipe.k)
+        op.out = pipe.out  # share the 40 GB result buffer
+        op.prefetch(batch)
         op.step(batch)
-    op.sync()
-    op_ms = (time.perf_counter() - t1) / 10 * 1e3
-    op.step(None)  # consume the batch still prefetched
-    op.sync()
-    op.out = None
-    del op
-    note("extras: overlapped_pipeline")
-    line["overlapped_pipeline"] = {"ms_per_step": op_ms, "sequences_per_s": n_total / (op_ms * 1e-3),
-                                   "what": "engine.OverlappedPipeline, a stream of batches: the next batch's count / sort / scatter run on a "
-                                           "second context (own stream confined to half of the compute units by skm_create_confined, second "
-                                           "buffer set) beside this batch's cosine; every step holds one complete vectorize and one complete "
-                                           "cosine; results identical to Pipeline's"}
+        op.sync()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            op.step(batch)
+        op.sync()
+        op_ms = (time.perf_counter() - t1) / 10 * 1e3
+        op.step(None)  # consume the batch still prefetched
+        op.sync()
+        op.out = None
+        del op
+        note("extras: overlapped_pipeline")
+        line["overlapped_pipeline"] = {"ms_per_step": op_ms, "sequences_per_s": n_total / (op_ms * 1e-3),
+                                       "what": "engine.OverlappedPipeline, a stream of batches: the next batch's count / sort / scatter run on a "
+                                               "second context (own stream confined to half of the compute units by skm_create_confined, second "
+                                               "buffer set) beside this batch's cosine; every step holds one complete vectorize and one complete "
+                                               "cosine; results identical to Pipeline's"}
 
     if args.alphabet == "red6":
         # red6 is a benchmark alphabet; the nearest reference alphabet (`standard`,

@@ -152,6 +152,12 @@ def load_library():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C snekmer_amd/csrc`. snekmer_amd has no CPU fallback."
             )
+        # HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (4 unless set) and two streams on one
+        # queue run one after the other: with five streams alive engine.OverlappedPipeline's two fell on the same queue and
+        # a step took 11.9 instead of 9.7 ms (tools/ab_overlapped.py, SKM_AB_EXTRA_CTX).  The runtime reads the variable
+        # when it starts, so it is set here, before the library (and with it the runtime) is loaded, unless the caller
+        # chose a value; a process that initialised HIP earlier (another library) keeps what it had.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         try:
             lib = C.CDLL(LIB_PATH)
         except OSError as exc:  # e.g. libamdhip64 not found

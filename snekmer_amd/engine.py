@@ -739,7 +739,8 @@ class OverlappedPipeline:
             out = pipe.step(nxt)       # cosine of the prefetched batch; vectorize of `nxt` starts beside it
 
     `out` (float32 [n, ld], HBM) is shared by all steps: consume it (or copy it) before the next step's writer runs,
-    i.e. before calling step() again, exactly as with Pipeline."""
+    i.e. before calling step() again, exactly as with Pipeline.  The two streams must sit on different hardware queues:
+    snekmer_amd._hip asks the HIP runtime for eight (GPU_MAX_HW_QUEUES) when it loads the library first."""
 
     EV_VEC, EV_COS = 0, 2  # event slots: EV_VEC + set on the side context, EV_COS + set on the main one
 

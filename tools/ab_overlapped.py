@@ -27,6 +27,9 @@ def main():
     lut = alphabet.build_lut("red6")
     res, off, _ = synth_families(n, 300, family=100, seed=BASE_SEED + 2)
     batch = engine.SeqBatch(ctx, res, off)
+    # SKM_AB_EXTRA_CTX=n: n idle contexts (streams) alive beside the two that work: HIP maps streams onto a few hardware
+    # queues (GPU_MAX_HW_QUEUES, 4 by default), and two streams on one queue do not overlap
+    idle = [_hip.Context(0) for _ in range(int(os.environ.get("SKM_AB_EXTRA_CTX", "0")))]
     a = engine.Pipeline(ctx, lut, 12)
     # SKM_AB_SIDE_GROUPS=a-b: the side context confined to those CU groups (default: OverlappedPipeline's own choice, 0-3);
     # SKM_AB_SIDE_GROUPS=all: an unconfined side context
