@@ -3,7 +3,12 @@
 
 One "step" = one pass of the hot path over one synthetic batch that is already resident in
 HBM: recode + k-mer count (CSR) -> observed basis / postings -> row norms -> N x N float32
-cosine, all outputs left in HBM.  Workload at any --gpus: BASELINE.json configs[2]
+cosine, all outputs left in HBM.  On one GPU the steps are those of a STREAM of batches
+(engine.OverlappedPipeline, --pipeline overlapped, the default): while a step's cosine runs on the main
+stream, the next batch's recode / count / sort / basis run on a second stream confined to half of the
+compute units; every timed step holds one complete vectorize and one complete cosine, nothing is cached
+and the results are bit-identical to the one-stream pipeline's, whose step (--pipeline single) is carried
+in the same line as `single_batch_step`.  Workload at any --gpus: BASELINE.json configs[2]
 (100k x 300 aa, alphabet=red6, k=12); with N > 1 the same 100k sequences are sharded by rows
 (strong scaling): each rank vectorizes its shard, the ranks build the postings of the full
 matrix together (RCCL all-to-all by k-mer owner, all-gather of the postings; snekmer_amd/dist.py),
@@ -11,7 +16,8 @@ then each rank computes its row block of the matrix.
 
 Prints ONE JSON line on rank 0 (contract: see repo prompt / DESIGN.md section "Measurement").
 Besides the contract keys the line carries, all measured in this same run after the timed region:
-  stage_rooflines        every stage of the step with its algorithmic bytes and fraction of HBM peak
+  single_batch_step      one batch on one stream (engine.Pipeline): ms/step, stage times, the writer alone
+  stage_rooflines        every stage of that single-batch step with its algorithmic bytes and fraction of HBM peak
   config2                BASELINE configs[1] (10k sequences) ms/step
   host_to_result_ms      H2D of the packed batch + one step (the PCIe-inclusive figure; never `value`)
   reference_alphabet_check   the nearest reference alphabet (standard k=12, uint64 codes)
