@@ -432,7 +432,9 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    prof_ctxs = [ctx] + ([op.side] if op is not None else [])  # the side context times the vectorize stages of the next batch
+    # the side contexts time the vectorize stages of the next batch, the Gram of its last rows and (their scratch holds those
+    # lists) the writer launches for those rows
+    prof_ctxs = [ctx] + (list(dict.fromkeys(op.sides)) if op is not None else [])
     for c in prof_ctxs:
         c.profile_enable(True)
         c.profile_reset()
@@ -453,9 +455,10 @@ def main():
         op.step(None)  # the batch still prefetched: nothing stays queued
         op.sync()
         op.out = None
-        side = op.side
+        sides = list(dict.fromkeys(op.sides))
         op = prof_ctxs = None
-        side.close()  # its stream goes too: HIP maps streams onto four hardware queues, and the extras open more
+        for side in sides:
+            side.close()  # their streams go too: HIP maps streams onto a few hardware queues, and the extras open more
 
     shard_check = None
     if dist is not None:
@@ -528,7 +531,8 @@ def main():
                 if sharded else "single GPU",
                 "pipelining": ("engine.OverlappedPipeline: the steps of a stream of batches.  While a step's cosine (sparse Gram + N x N writer) "
                                "runs on the main stream, the NEXT batch's recode + count + sort + basis / postings run on a second stream "
-                               "confined to half of the compute units (skm_create_confined).  Every timed step holds one complete "
+                               "confined to half of the compute units (skm_create_confined), and so do the neighbour lists of that batch's "
+                               "last 60 % of rows (skm_cosine_csr_phase), which the main stream then only has to write.  Every timed step holds one complete "
                                "vectorize and one complete cosine - the batch vectorized in the last timed step is never consumed, the one "
                                "consumed in the first was vectorized during the warm-up - and every result is recomputed from the residues, "
                                "bit-identical to the one-stream pipeline's (tests/test_gpu_parity.py).  `single_batch_step` in this line: the "

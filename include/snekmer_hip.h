@@ -250,6 +250,16 @@ int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint
                    const uint32_t *d_ycolptr, const void *d_ypost, int post_bits, const uint32_t *d_ypostcnt,
                    const float *d_yrnorm, int64_t row0, int64_t row1, int mode, float *d_out,
                    int64_t ld);
+/* skm_cosine_csr in two calls, for a stream of batches (engine.OverlappedPipeline; no reference counterpart: the
+ * reference handles one FASTA file per process, snekmer/rules/kmerize.smk:57-65).  phase 1: prologue + sparse Gram of the
+ * row block on ctx; the neighbour lists stay in ctx's scratch; d_out may be NULL.  phase 2: everything behind them (heavy
+ * rows, streaming writer, cursor kernel, the mode-2 epilogue) on exec_ctx's STREAM (same device; NULL = ctx's own) with
+ * ctx's scratch.  The caller orders phase 2 behind phase 1 (skm_event_record / skm_stream_wait) and starts no new phase 1
+ * on ctx before the phase 2 reading its lists has finished.  Same arguments in both calls.  phase 0 = skm_cosine_csr. */
+int skm_cosine_csr_phase(skm_ctx *ctx, skm_ctx *exec_ctx, int phase, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
+                         const uint32_t *d_xcounts, const float *d_xrnorm, int64_t m, int64_t ncols, const uint32_t *d_ycolptr,
+                         const void *d_ypost, int post_bits, const uint32_t *d_ypostcnt, const float *d_yrnorm, int64_t row0,
+                         int64_t row1, int mode, float *d_out, int64_t ld);
 
 /* Reporting only: how the last neighbour-list skm_cosine_csr call of this context distributed its rows.
  * h_out4[0] = rows whose neighbours overflowed the first pass's table (handed to the fused heavy-row kernel), [1] =

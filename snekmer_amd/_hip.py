@@ -95,6 +95,10 @@ _SIGNATURES = {
         C.c_int,
         [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, C.c_int, _p, _p, _i64, _i64, C.c_int, _p, _i64],
     ),
+    "skm_cosine_csr_phase": (
+        C.c_int,
+        [_p, _p, C.c_int, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, C.c_int, _p, _p, _i64, _i64, C.c_int, _p, _i64],
+    ),
     "skm_hamming_similarity_from_gram": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _i64]),
     "skm_cosine_csr_stats": (C.c_int, [_p, _p]),
     "skm_heavy_panel_stats": (C.c_int, [_p, _p]),

@@ -1344,11 +1344,14 @@ int heavy_panels_run(skm_ctx *ctx, const int64_t *d_xrowptr, const uint32_t *d_x
 }  // namespace
 
 namespace {
+// phase 0: the whole call.  Phases 1 and 2 cut the list path in two (skm_cosine_csr_phase): 1 = prologue + sparse Gram
+// (the neighbour lists stay in the context's scratch), 2 = everything behind them (heavy rows, writer, cursor kernel).
+// The other routes (cursor kernel only) have no lists: phase 1 does nothing and phase 2 is the whole call.
 template <typename PW>
 int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx, const uint32_t *d_xcounts,
                     const float *d_xrnorm, int64_t m, int64_t ncols, const uint32_t *d_ycolptr, const PW *d_ypost,
                     const uint32_t *d_ypostcnt, const float *d_yrnorm, int64_t row0, int64_t row1, int mode, float *d_out,
-                    int64_t ld)
+                    int64_t ld, int phase = 0)
 {
     SKM_REQUIRE(ctx && n >= 0 && m >= 0 && ncols >= 0, SKM_E_BADARG, "skm_cosine_csr: bad argument");
     SKM_REQUIRE(row0 >= 0 && row0 <= row1 && row1 <= n, SKM_E_BADARG, "skm_cosine_csr: bad row range [%lld,%lld) of %lld",
@@ -1358,7 +1361,7 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     SKM_REQUIRE(m < ((int64_t)1 << 32) - 1, SKM_E_OVERFLOW, "skm_cosine_csr: m >= 2^32");
     if (row1 == row0 || m == 0)
         return SKM_OK;
-    SKM_REQUIRE(d_xrowptr && d_xrnorm && d_ycolptr && d_yrnorm && d_out, SKM_E_BADARG, "skm_cosine_csr: null array");
+    SKM_REQUIRE(d_xrowptr && d_xrnorm && d_ycolptr && d_yrnorm && (d_out || phase == 1), SKM_E_BADARG, "skm_cosine_csr: null array");
     SKM_HIP(hipSetDevice(ctx->device));
     const int64_t nrows = row1 - row0;
     const int64_t strips = skm_ceil_div(nrows, R);
@@ -1420,6 +1423,8 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
 #endif
     const char *path_env = getenv("SKM_COSINE_PATH");  // "cursor" forces the fallback kernel everywhere
     if (path_env && strcmp(path_env, "cursor") == 0) {
+        if (phase == 1)
+            return SKM_OK;
         SKM_TRY(cosine_prologue(ctx, nullptr, 0, state, 0ull, d_yrnorm, m, st));
         SKM_PROF(ctx, "k_cosine_strip");
         SKM_BY_MODE_VEC(SKM_CURSOR);
@@ -1433,6 +1438,8 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     // posting per memory round trip and list, so a k-mer shared by all rows costs it m round trips per strip
     // (measured, 200 - 1000 rows: 0.12 ms whatever the size, against 0.04 - 0.05 ms for the four list-path launches).
     if (m <= CH && nrows >= 8 * m && !(path_env && strcmp(path_env, "lists") == 0)) {  // SKM_COSINE_PATH=lists keeps the list path (tests)
+        if (phase == 1)
+            return SKM_OK;
         SKM_TRY(cosine_prologue(ctx, nullptr, 0, state, 0ull, d_yrnorm, m, st));
         SKM_PROF(ctx, "k_cosine_strip");
         SKM_BY_MODE_VEC(SKM_CURSOR);
@@ -1464,7 +1471,8 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     uint32_t *over_count = state->over_count;
     constexpr int MAXB = 16;  // row blocks of the overlapped schedule (one overflow counter each)
     // strip flags and counters cleared, list allocation behind the fixed slots, min_j yrnorm[j]: one launch
-    SKM_TRY(cosine_prologue(ctx, fb_flag, strips + 8, state, fixed_ent, d_yrnorm, m, st));
+    if (phase != 2)
+        SKM_TRY(cosine_prologue(ctx, fb_flag, strips + 8, state, fixed_ent, d_yrnorm, m, st));
 #ifdef SKM_DIAG
     const char *gabl_env = getenv("SKM_GRAM_ABLATE");  // diagnostic builds of k_gram_sparse (1, 2, 4: results NOT valid)
     const int gabl = gabl_env ? atoi(gabl_env) : 0;
@@ -1486,8 +1494,8 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     if constexpr (sizeof(PW) == 8)
         panels_first = heavy_panels_wanted(ctx, nrows, m);
     int nblk = 1;
-    if (gabl == 0 && ov_env && atoi(ov_env) == 1 && !panels_first && nrows >= 4096 && (double)nrows * (double)ld * 4.0 >= 2e9 &&
-        overlap_streams(ctx) == SKM_OK)
+    if (phase == 0 && gabl == 0 && ov_env && atoi(ov_env) == 1 && !panels_first && nrows >= 4096 &&
+        (double)nrows * (double)ld * 4.0 >= 2e9 && overlap_streams(ctx) == SKM_OK)
         nblk = 8;
 #ifdef SKM_DIAG
     if (nblk > 1 && getenv("SKM_OVERLAP_BLOCKS"))  // diagnostic: block count of the overlapped schedule (2..16)
@@ -1507,7 +1515,7 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
         const int64_t bn = b1 - b0;
         hipStream_t gs = b == 0 ? st : s_g;
         uint32_t *b_over_list = over_list + b0, *b_over_count = over_count + b;
-        {
+        if (phase != 2) {
             // one row per workgroup, 2048 slots: 26 KB of LDS -> 6 workgroups per CU
             SKM_PROF_ON(ctx, "k_gram_sparse", gs);
 #define SKM_GRAM(GABL)                                                                                               \
@@ -1558,6 +1566,8 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
 #undef SKM_GRAM
         }
         SKM_TRY(skm_check_launch("k_gram_sparse"));
+        if (phase == 1)
+            return SKM_OK;
         if (nblk > 1) {
             SKM_HIP(hipEventRecord(ctx->sync_events[1 + b], gs));
             SKM_HIP(hipStreamWaitEvent(s_w, ctx->sync_events[1 + b], 0));
@@ -1723,6 +1733,42 @@ extern "C" int skm_cosine_csr(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
                                        (const uint64_t *)d_ypost, nullptr, d_yrnorm, row0, row1, kmode, d_out, ld);
     }
     if (rc == SKM_OK && mode == 2)
+        rc = skm_similarity_to_distance(ctx, row1 - row0, m, d_out, ld);
+    return rc;
+}
+
+// skm_cosine_csr in two calls, for a stream of batches (engine.OverlappedPipeline): phase 1 builds the neighbour lists of
+// the row block on ctx (prologue + sparse Gram; they stay in ctx's scratch), phase 2 runs everything behind them - heavy
+// rows, streaming writer, cursor kernel, the mode-2 epilogue - on exec_ctx's STREAM, still with ctx's scratch.  The
+// caller orders the two (skm_event_record / skm_stream_wait) and does not start the next phase 1 on ctx before the
+// phase 2 that reads its lists has finished.  phase 0 = skm_cosine_csr on ctx.
+extern "C" int skm_cosine_csr_phase(skm_ctx *ctx, skm_ctx *exec_ctx, int phase, int64_t n, const int64_t *d_xrowptr,
+                                    const uint32_t *d_xcolidx, const uint32_t *d_xcounts, const float *d_xrnorm, int64_t m,
+                                    int64_t ncols, const uint32_t *d_ycolptr, const void *d_ypost, int post_bits,
+                                    const uint32_t *d_ypostcnt, const float *d_yrnorm, int64_t row0, int64_t row1, int mode,
+                                    float *d_out, int64_t ld)
+{
+    SKM_REQUIRE(ctx && phase >= 0 && phase <= 2, SKM_E_BADARG, "skm_cosine_csr_phase: phase must be 0, 1 or 2");
+    SKM_REQUIRE(post_bits == 64 || post_bits == 32, SKM_E_BADARG, "skm_cosine_csr_phase: post_bits must be 32 or 64");
+    SKM_REQUIRE(mode >= 0 && mode <= 2, SKM_E_BADARG, "skm_cosine_csr_phase: mode must be 0, 1 or 2");
+    SKM_REQUIRE(!exec_ctx || exec_ctx->device == ctx->device, SKM_E_BADARG, "skm_cosine_csr_phase: the two contexts are on different devices");
+    if (post_bits == 32)
+        SKM_REQUIRE(m <= ((int64_t)1 << 24), SKM_E_BADARG, "skm_cosine_csr_phase: 32-bit postings hold rows < 2^24");
+    struct stream_swap {  // phase 2: ctx's kernels, scratch and profiling scopes, on exec_ctx's stream
+        skm_ctx *c;
+        hipStream_t saved;
+        stream_swap(skm_ctx *c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
+        ~stream_swap() { c->stream = saved; }
+    } swap(ctx, phase == 2 && exec_ctx ? exec_ctx->stream : ctx->stream);
+    const int kmode = mode == 2 ? 0 : mode;
+    int rc;
+    if (post_bits == 32)
+        rc = cosine_csr_impl<uint32_t>(ctx, n, d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, ncols, d_ycolptr, (const uint32_t *)d_ypost,
+                                       d_ypostcnt, d_yrnorm, row0, row1, kmode, d_out, ld, phase);
+    else
+        rc = cosine_csr_impl<uint64_t>(ctx, n, d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, ncols, d_ycolptr, (const uint64_t *)d_ypost,
+                                       nullptr, d_yrnorm, row0, row1, kmode, d_out, ld, phase);
+    if (rc == SKM_OK && mode == 2 && phase != 1)
         rc = skm_similarity_to_distance(ctx, row1 - row0, m, d_out, ld);
     return rc;
 }

@@ -730,8 +730,12 @@ class OverlappedPipeline:
     second context (its own HIP stream and scratch) into a second set of buffers.  The stages in front of the writer
     are latency- and issue-bound (0.13-0.29 of HBM each) and the writer is store-bound; side by side on
     the whole chip each crawls in the other's wave slots (10.5 against 10.8 ms per step), so the side context's stream is
-    confined to half of the compute units (skm_create_confined): 9.66 ms per step.  Results are the single-stream
-    Pipeline's, bit for bit (same kernels, same inputs; tests/test_gpu_parity.py).
+    confined to half of the compute units (skm_create_confined): 9.66 ms per step.  The main stream then carries the
+    sparse Gram and the writer, the side stream less work than that: with `side_list_fraction` > 0 the neighbour lists
+    of the LAST rows of a batch (that fraction of them) are built on the side context too, right behind its vectorize
+    (skm_cosine_csr_phase 1), and the main stream only runs the writer for those rows (phase 2, reading the side
+    context's scratch).  The lists live in a context's scratch, so two side contexts alternate.  Results are the
+    single-stream Pipeline's, bit for bit (same kernels, same inputs; tests/test_gpu_parity.py).
 
         pipe = OverlappedPipeline(ctx, lut, k)
         pipe.prefetch(batch0)
@@ -739,39 +743,70 @@ class OverlappedPipeline:
             out = pipe.step(nxt)       # cosine of the prefetched batch; vectorize of `nxt` starts beside it
 
     `out` (float32 [n, ld], HBM) is shared by all steps: consume it (or copy it) before the next step's writer runs,
-    i.e. before calling step() again, exactly as with Pipeline.  The two streams must sit on different hardware queues:
+    i.e. before calling step() again, exactly as with Pipeline.  The streams must sit on different hardware queues:
     snekmer_amd._hip asks the HIP runtime for eight (GPU_MAX_HW_QUEUES) when it loads the library first."""
 
-    EV_VEC, EV_COS = 0, 2  # event slots: EV_VEC + set on the side context, EV_COS + set on the main one
-
+    EV_VEC, EV_COS = 0, 2  # event slots: EV_VEC + set on the side contexts, EV_COS + set on the main one
     SIDE_CU_GROUPS = (0, 3)  # measured on the bench workload: groups 0-0 12.7 ms, 0-1 10.1, 0-2 10.0, 0-3 9.66, 0-4 10.35, all 10.5
+    SIDE_LIST_FRACTION = 0.6  # bench workload, ms per step: 0 9.75, 0.2 9.74, 0.4 9.47, 0.5 9.29-9.36, 0.6 9.25, 0.7 9.27, 0.8 9.63, 1 9.99
+    SPLIT_MIN_ROWS = 16384  # below this a batch's lists all stay on the main context
 
-    def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int, side_ctx: Optional[_hip.Context] = None):
+    def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int, side_ctx: Optional[_hip.Context] = None,
+                 side_list_fraction: Optional[float] = None):
         self.ctx, self.lut, self.k = ctx, lut, k
-        if side_ctx is None:
+        self.fraction = self.SIDE_LIST_FRACTION if side_list_fraction is None else float(side_list_fraction)
+
+        def confined():
             try:  # half of the compute units: what the next batch's kernels may fill beside this batch's writer
-                side_ctx = _hip.Context(ctx.device, cu_groups=self.SIDE_CU_GROUPS)
+                return _hip.Context(ctx.device, cu_groups=self.SIDE_CU_GROUPS)
             except _hip.HipError:  # a device the CU-group masks are not defined for
-                side_ctx = _hip.Context(ctx.device)
-        self.side = side_ctx
+                return _hip.Context(ctx.device)
+
+        first = side_ctx if side_ctx is not None else confined()
+        second = first
+        if self.fraction > 0:  # lists on the side: one side context per buffer set
+            second = _hip.Context(ctx.device, cu_groups=first.cu_groups) if first.cu_groups else _hip.Context(ctx.device)
+        self.sides = [first, second]
+        self.side = first
         self.sets = [[None, None, None], [None, None, None]]  # (csr, basis, rnorm) per buffer set
         self.ready = None   # set holding a vectorized batch that has not been consumed yet
         self.nxt = 0
         self.out = None
         self.csr = self.basis = self.rnorm = None  # the set the last step() consumed
 
+    def _split_row(self, n: int) -> int:
+        """Rows [0, r) get their lists on the main context, rows [r, n) on the side context."""
+        if self.fraction <= 0 or n < self.SPLIT_MIN_ROWS:
+            return n
+        return max(0, min(n, int(n * (1.0 - self.fraction)) // 8 * 8))
+
+    def _block(self, call_ctx, s: int, row0: int, row1: int, phase: int, out_ptr: int, ld: int):
+        csr, b, rnorm = self.sets[s]
+        args = (_i64(csr.n), _ptr(csr.rowptr), _ptr(csr.colidx), _ptr(csr.counts), _ptr(rnorm), _i64(csr.n), _i64(b.ncols_hint()),
+                _ptr(b.colptr), _ptr(b.post), b.post_bits, _ptr(b.postcnt), _ptr(rnorm), _i64(row0), _i64(row1), 0,
+                C.c_void_p(out_ptr) if out_ptr else None, _i64(ld))
+        if phase == 0:
+            call_ctx.call("skm_cosine_csr", *args)
+        else:
+            call_ctx.call("skm_cosine_csr_phase", self.ctx.handle if phase == 2 else None, phase, *args)
+
     def prefetch(self, batch: SeqBatch) -> None:
-        """Vectorize `batch` on the side context into the free buffer set."""
+        """Vectorize `batch` on a side context into the free buffer set (and build the lists of its last rows there)."""
         if self.ready is not None:
             raise RuntimeError("a prefetched batch is waiting: call step() first")
         s = self.nxt
-        # the set's previous contents were last read by the cosine two steps ago
-        self.side.wait_event(self.ctx, self.EV_COS + s)
-        if batch.ctx is not self.side and batch.ctx is not self.ctx:
+        side = self.sides[s]
+        # the set's previous contents (and that side context's lists) were last read by the cosine two steps ago
+        side.wait_event(self.ctx, self.EV_COS + s)
+        if batch.ctx is not self.ctx and all(batch.ctx is not c for c in self.sides):
             raise ValueError("the batch must live on the pipeline's device")
         csr, basis, rnorm = self.sets[s]
-        self.sets[s] = list(vectorize_fused(self.side, batch, self.lut, self.k, csr=csr, basis=basis, rnorm=rnorm))
-        self.side.record_event(self.EV_VEC + s)
+        self.sets[s] = list(vectorize_fused(side, batch, self.lut, self.k, csr=csr, basis=basis, rnorm=rnorm))
+        n = self.sets[s][0].n
+        r = self._split_row(n)
+        if r < n:
+            self._block(side, s, r, n, 1, 0, (n + 3) // 4 * 4)
+        side.record_event(self.EV_VEC + s)
         self.ready = s
         self.nxt = 1 - s
 
@@ -781,20 +816,23 @@ class OverlappedPipeline:
             raise RuntimeError("nothing prefetched: call prefetch(batch) first")
         s, self.ready = self.ready, None
         self.csr, self.basis, self.rnorm = self.sets[s]
-        self.ctx.wait_event(self.side, self.EV_VEC + s)
+        self.ctx.wait_event(self.sides[s], self.EV_VEC + s)
         n = self.csr.n
         ld = (n + 3) // 4 * 4
         if self.out is None or self.out.shape != (max(n, 1), max(ld, 1)):
             self.out = None
             self.out = self.ctx.empty((max(n, 1), max(ld, 1)), np.float32)
-        b = self.basis
-        cosine_matrix(self.ctx, self.csr, self.rnorm, n, b.ncols_hint(), b.colptr, b.post, self.rnorm, out=self.out, ld=ld,
-                      post_bits=b.post_bits, postcnt=b.postcnt)
+        r = self._split_row(n)
+        if r > 0 or n == 0:
+            self._block(self.ctx, s, 0, r, 0, self.out.ptr, ld)
+        if r < n:
+            self._block(self.sides[s], s, r, n, 2, self.out.at(r * ld), ld)
         self.ctx.record_event(self.EV_COS + s)
         if next_batch is not None:
             self.prefetch(next_batch)
         return self.out
 
     def sync(self):
-        self.side.sync()
+        for c in dict.fromkeys(self.sides):
+            c.sync()
         self.ctx.sync()

@@ -1297,6 +1297,18 @@ def test_overlapped_pipeline_equals_pipeline_on_a_stream_of_batches(ctx):
     with pytest.raises(RuntimeError):
         pipe.step(None)
     assert pipe.side.cu_groups == engine.OverlappedPipeline.SIDE_CU_GROUPS  # the side stream is confined to half the chip
+    # the same stream of batches with the lists of the last rows built on the side contexts (skm_cosine_csr_phase):
+    # forced on for these small batches, several fractions, a fraction that leaves nothing to the main context
+    for fraction in (0.3, 0.6, 1.0):
+        split = engine.OverlappedPipeline(ctx, lut, 12, side_list_fraction=fraction)
+        split.SPLIT_MIN_ROWS = 64
+        assert split.sides[0] is not split.sides[1]
+        split.prefetch(batches[0])
+        for i, b in enumerate(batches):
+            out = split.step(batches[i + 1] if i + 1 < len(batches) else None)
+            split.sync()
+            got = out.download().reshape(out.shape)[: b.n, : b.n]
+            assert (got == want[i]).all(), (fraction, i)
 
 
 def test_confined_context_is_an_ordinary_context_on_fewer_compute_units(ctx):

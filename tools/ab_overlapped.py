@@ -38,7 +38,9 @@ def main():
         side = _hip.Context(0)
     elif os.environ.get("SKM_AB_SIDE_GROUPS"):
         side = _hip.Context(0, cu_groups=groups("SKM_AB_SIDE_GROUPS"))
-    b = engine.OverlappedPipeline(ctx, lut, 12, side_ctx=side)
+    # SKM_AB_FRACTION=f: the neighbour lists of the last f * n rows are built on the side context
+    frac = float(os.environ["SKM_AB_FRACTION"]) if os.environ.get("SKM_AB_FRACTION") else None
+    b = engine.OverlappedPipeline(ctx, lut, 12, side_ctx=side, side_list_fraction=frac)
     b.out = a.step(batch)  # share the 40 GB result buffer
     ctx.sync()
     ld = a.out.shape[1]
