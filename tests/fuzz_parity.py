@@ -7,7 +7,8 @@ stars, lowercase, empties, repeats, a few long records, now and then a homopolym
 beyond int32) and compares, bit for bit unless stated:
   * skm_count_csr and skm_vectorize_csr (CSR, basis codes, column starts, column ids, row norms) with the C oracle;
   * the N x N cosine by the neighbour-list path, by the cursor kernel and by the overlapped schedule with each other,
-    and with the oracle's float64 rows to 1e-5;
+    and with the oracle's float64 rows to 1e-5; every eighth round also as a stream of two batches through
+    engine.OverlappedPipeline with part of the neighbour lists built on its side contexts;
   * neighbour lists (skm_gram_neighbors) of a random row block: neighbour sets and exact integer dot products;
   * every fourth round: the rule body (`vectorize_records`: first-seen basis, min_filter, presence rows, reduced
     strings, explicit basis) against the oracle's restatement of rules/kmerize.smk:67-139;
@@ -144,6 +145,18 @@ def one_round(ctx, seed, verbose=False):
                     else:
                         os.environ[kk] = vv
             same(alt, S["three"], f"cosine under {env}")
+        if seed % 8 == 5:
+            # a stream of two batches through OverlappedPipeline with the lists of a random share of the rows built on the
+            # side contexts (skm_cosine_csr_phase), forced on whatever the size: the one-stream result both times
+            op = engine.OverlappedPipeline(ctx, lut, k, side_list_fraction=float(rng.choice([0.25, 0.6, 1.0])))
+            op.SPLIT_MIN_ROWS = 1
+            op.prefetch(batch)
+            for nxt in (batch, None):
+                got = op.step(nxt)
+                op.sync()
+                same(got.download().reshape(got.shape)[:n, :n], S["three"], "OverlappedPipeline with split lists")
+            for c in dict.fromkeys(op.sides):
+                c.close()
         # neighbour lists of a random row block: the same neighbour set and the exact integer dot products
         lo = int(rng.integers(0, n))
         hi = int(rng.integers(lo + 1, n + 1))
