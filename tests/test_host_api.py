@@ -26,7 +26,23 @@ def test_library_loads_and_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert set(_hip.EXPORTED_SYMBOLS) == declared
-    assert lib.skm_abi_version() == 4
+    assert lib.skm_abi_version() == _hip.ABI_VERSION
+    abi_h = int(re.search(r"#define\s+SKM_ABI_VERSION\s+(\d+)", header).group(1))
+    assert abi_h == _hip.ABI_VERSION
+
+
+def test_driver_build_hook_returns():
+    """__graft_entry__.build() is what the driver and README call: it must compile (a no-op when up to date),
+    load the library and agree with it on the ABI version and the symbol table."""
+    import shutil
+
+    import __graft_entry__ as entry
+
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc here: build() cannot compile")
+    entry.build()
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert not re.search(r"ABI_VERSION\s*==\s*\d", src), "build() must not pin the ABI to a literal"
 
 
 def test_product_library_carries_no_result_invalidating_switches():
