@@ -209,7 +209,18 @@ def pmc_child(args, seed):
     ctx = _hip.Context(0)
     res, off, _ = synth_families(args.n, args.length, family=100, seed=seed)
     batch = engine.SeqBatch(ctx, res, off)
-    pipe = engine.Pipeline(ctx, alphabet.build_lut(args.alphabet), args.k)
+    lut = alphabet.build_lut(args.alphabet)
+    if args.pipeline == "overlapped":
+        # the timed object: its k_cosine_write launches (two per step: the rows whose lists the main context built, then the
+        # rows whose lists a side context built) are the launches roofline.algorithmic_bytes_per_launch is stated for
+        op = engine.OverlappedPipeline(ctx, lut, args.k)
+        op.prefetch(batch)
+        for _ in range(3):
+            op.step(batch)
+        op.step(None)
+        op.sync()
+        return
+    pipe = engine.Pipeline(ctx, lut, args.k)
     for _ in range(3):
         pipe.step(batch)
     ctx.sync()
@@ -239,7 +250,7 @@ def live_pmc_traffic(args, budget_s=150.0):
                 return None, "live PMC passes ran out of their time budget"
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--n", str(args.n), "--length", str(args.length),
-                   "--k", str(args.k), "--alphabet", args.alphabet]
+                   "--k", str(args.k), "--alphabet", args.alphabet, "--pipeline", args.pipeline]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=left)
             except subprocess.TimeoutExpired:
@@ -258,8 +269,9 @@ def live_pmc_traffic(args, budget_s=150.0):
                 return None, f"rocprofv3 --pmc {counter}: no k_cosine_write dispatch in the output"
             got[counter] = (sum(vals) / len(vals) * 1024.0, len(vals))
     w, f = got["WRITE_SIZE"], got["FETCH_SIZE"]
-    return w[0] + 2.0 * f[0], (f"measured in this run: rocprofv3 --pmc WRITE_SIZE ({w[0] / 1e9:.2f} GB/launch, {w[1]} launches) and "
-                               f"--pmc FETCH_SIZE (2 x {f[0] / 1e9:.3f} GB), separate child passes, {time.perf_counter() - t0:.0f} s")
+    return w[0] + 2.0 * f[0], (f"measured in this run on the timed pipeline (--pipeline {args.pipeline}): rocprofv3 --pmc WRITE_SIZE "
+                               f"({w[0] / 1e9:.2f} GB/launch, {w[1]} launches) and --pmc FETCH_SIZE (2 x {f[0] / 1e9:.3f} GB), averaged over "
+                               f"the k_cosine_write dispatches, separate child passes, {time.perf_counter() - t0:.0f} s")
 
 
 def self_launch(n_ranks: int) -> int:
@@ -451,9 +463,29 @@ def main():
             prof[key] = (have[0] + calls, have[1] + ms)
         c.profile_enable(False)
     note(f"timed region: {elapsed / args.steps * 1e3:.3f} ms/step on rank {rank}")
+    identity = None
     if op is not None:
-        op.step(None)  # the batch still prefetched: nothing stays queued
+        last = op.step(None)  # the batch still prefetched: nothing stays queued
         op.sync()
+        # the timed object's result against the one-stream pipeline's, at the timed size: the WHOLE matrix of the last step
+        # reduced on the device (float64 sum + non-zero count per row, skm_matrix_row_stats; the same kernels on the same
+        # values in the same order, so equal results give equal sums), then the same buffer rewritten by Pipeline.step
+        ld_chk = last.shape[1]
+        got_sum, got_nnz = engine.matrix_row_stats(ctx, last, n_total, n_total, ld_chk)
+        probe_rows = np.unique(np.linspace(0, n_total - 1, 16).astype(np.int64))
+        got_rows = [last.download(n_total, offset=int(r) * ld_chk) for r in probe_rows]
+        ref_out = pipe.step(batch)
+        ctx.sync()
+        want_sum, want_nnz = engine.matrix_row_stats(ctx, ref_out, n_total, n_total, ld_chk)
+        rows_equal = all((g == ref_out.download(n_total, offset=int(r) * ld_chk)).all() for g, r in zip(got_rows, probe_rows))
+        identity = {"equal": bool((got_nnz == want_nnz).all() and (got_sum == want_sum).all() and rows_equal),
+                    "rows_with_different_nonzero_count": int((got_nnz != want_nnz).sum()),
+                    "rows_with_different_sum": int((got_sum != want_sum).sum()), "probe_rows_bitwise_equal": bool(rows_equal),
+                    "what": "last timed-object result vs engine.Pipeline.step on the same batch: per-row float64 sums and non-zero counts "
+                            "of all N x N cells (skm_matrix_row_stats) compared exactly, 16 rows compared bit for bit; parity of the "
+                            "object against the oracle at this size: tests/test_gpu_parity.py::"
+                            "test_config3_full_size_100k_overlapped_pipeline_the_timed_object"}
+        note(f"overlapped vs single: equal={identity['equal']}")
         op.out = None
         sides = list(dict.fromkeys(op.sides))
         op = prof_ctxs = None
@@ -556,6 +588,9 @@ def main():
                 "whole_step_frac": rows_local * ld * 4 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
         }
+        if identity is not None:
+            line["overlapped_equals_single"] = identity["equal"]
+            line["overlapped_vs_single"] = identity
         if shard_check is not None:
             line["sharded_result_check"] = shard_check
         if sharded and pipe.mode == "distributed":

@@ -7,8 +7,13 @@ rank 4): the integer count matrix in CSR form instead of the dense float64 prese
 ``read_fasta`` is the minimal reader the rule needs in place of Bio.SeqIO
 (rules/kmerize.smk:90-129 only uses ``record.id`` and ``record.seq``).
 """
+import importlib
+import pickle
+import sys
+import threading
+import types
 from os.path import basename, splitext
-from typing import Dict, List, Tuple
+from typing import Any, Dict, List, Tuple
 
 import numpy as np
 
@@ -79,6 +84,89 @@ def read_kmers(filename: str) -> List[str]:
     """One k-mer per line, verbatim order (snekmer/io.py:99-122)."""
     with open(filename) as f:
         return [line.strip() for line in f]
+
+
+# ``.kmers`` interchange.  rules/kmerize.smk:141-142 pickles a ``snekmer.vectorize.KmerVec``;
+# scripts/cluster_cluster.py:53-63 (and model / search) unpickle it with ``snekmer.io.load_pickle``.  A pickle names its
+# classes by module path, so a drop-in must WRITE that path: ``dump_kmers`` does (the three classes of
+# snekmer/vectorize.py keep their state in ``__dict__`` and define no pickling hook, so the stream is what the reference
+# writes), and ``load_pickle`` reads either path, with or without Snekmer installed.
+REFERENCE_MODULE = "snekmer.vectorize"
+_PICKLED_CLASSES = ("KmerVec", "KmerBasis", "KmerSet")
+_alias_lock = threading.Lock()
+
+
+def _reference_classes():
+    """(classes to name in the stream, modules to restore afterwards).  With Snekmer importable the real classes are
+    named; otherwise a throw-away module object stands in for the duration of the dump, because pickle checks that
+    ``sys.modules[module].name`` is the class it is asked to name."""
+    try:
+        mod = importlib.import_module(REFERENCE_MODULE)
+        return {name: getattr(mod, name) for name in _PICKLED_CLASSES}, None
+    except Exception:
+        pass
+    saved = {k: sys.modules.get(k) for k in ("snekmer", REFERENCE_MODULE)}
+    pkg, mod = types.ModuleType("snekmer"), types.ModuleType(REFERENCE_MODULE)
+    pkg.__path__ = []
+    pkg.vectorize = mod
+    classes = {}
+    for name in _PICKLED_CLASSES:
+        classes[name] = type(name, (), {"__module__": REFERENCE_MODULE, "__qualname__": name})
+        setattr(mod, name, classes[name])
+    sys.modules["snekmer"], sys.modules[REFERENCE_MODULE] = pkg, mod
+    return classes, saved
+
+
+def dump_kmers(obj: Any, file, protocol: int = 4, reference_pickle: bool = True) -> None:
+    """``pickle.dump(kmer, f)`` of rules/kmerize.smk:141-142.  With `reference_pickle` (default) the objects of
+    snekmer_amd.vectorize are written under the reference's class path ``snekmer.vectorize.*`` with the reference's
+    attribute set, so that Snekmer's own ``io.load_pickle`` reads the file unchanged; ``load_pickle`` here reads it too."""
+    if not reference_pickle:
+        pickle.dump(obj, file, protocol=protocol)
+        return
+    from . import vectorize as V
+
+    mine = {getattr(V, name): name for name in _PICKLED_CLASSES}
+    with _alias_lock:
+        classes, saved = _reference_classes()
+        try:
+            def convert(o):
+                name = mine.get(type(o))
+                if name is None:
+                    return o
+                get = getattr(type(o), "__getstate__", None)
+                state = get(o) if get is not None and get is not getattr(object, "__getstate__", None) else dict(o.__dict__)
+                twin = object.__new__(classes[name])  # same state under the reference's class: pickle then writes what Snekmer writes
+                twin.__dict__.update({k: convert(v) for k, v in state.items()})
+                return twin
+
+            pickle.dump(convert(obj), file, protocol=protocol)
+        finally:
+            if saved is not None:
+                for k, v in saved.items():
+                    if v is None:
+                        sys.modules.pop(k, None)
+                    else:
+                        sys.modules[k] = v
+
+
+class _KmersUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module == REFERENCE_MODULE and name in _PICKLED_CLASSES:
+            try:
+                return super().find_class(module, name)  # Snekmer is installed: its own classes
+            except Exception:
+                from . import vectorize as V
+
+                return getattr(V, name)
+        return super().find_class(module, name)
+
+
+def load_pickle(filename: str, mode: str = "rb") -> Any:
+    """snekmer/io.py:21-39 (wrapper for ``pickle.load``).  A ``.kmers`` file that names ``snekmer.vectorize.*`` —
+    written by Snekmer or by ``dump_kmers`` — loads as snekmer_amd.vectorize objects where Snekmer is not installed."""
+    with open(filename, mode) as f:
+        return _KmersUnpickler(f).load()
 
 
 def load_npz(

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import engine
 from .alphabet import FULL_ALPHABETS, build_lut
-from .io import read_fasta, read_fasta_packed, save_npz, save_npz_sparse
+from .io import dump_kmers, read_fasta, read_fasta_packed, save_npz, save_npz_sparse
 from .utils import pack_sequences
 from .vectorize import KmerVec, _restore_wide_chars
 
@@ -178,9 +178,11 @@ def vectorize_fasta(
     timings: Optional[dict] = None,
     dense: Optional[bool] = None,
     compressed: bool = True,
+    reference_pickle: bool = True,
 ) -> Dict[str, np.ndarray]:
     """FASTA -> the rule's outputs; optionally writes the ``.npz`` and the pickled KmerVec
-    (``.kmers``) exactly as rules/kmerize.smk:132-142 does.  `sparse_npz_out` writes the sparse
+    (``.kmers``) exactly as rules/kmerize.smk:132-142 does: the pickle names the reference's class path
+    (``snekmer.vectorize.KmerVec``; `reference_pickle=False` names this package's), so scripts/cluster_cluster.py:53-63 reads it.  `sparse_npz_out` writes the sparse
     variant (io.save_npz_sparse: CSR counts, no dense matrix); without `npz_out` the dense
     N x |basis| float64 matrix is then never built.  `dense=False` skips it when nothing is written either; `compressed=False`
     writes the ``.npz`` members uncompressed (np.load reads both; the reference compresses, rules/kmerize.smk:132).  `timings` (optional
@@ -205,7 +207,7 @@ def vectorize_fasta(
         kmer = KmerVec(alphabet=alphabet, k=k)
         kmer.set_kmer_set(out["kmerlist"])
         with open(kmers_out, "wb") as f:
-            pickle.dump(kmer, f)
+            dump_kmers(kmer, f, reference_pickle=reference_pickle)
     if timings is not None:
         timings["write_s"] = timings.get("write_s", 0.0) + time.perf_counter() - t0
     return out

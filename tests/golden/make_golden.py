@@ -511,9 +511,36 @@ def extra(ref_root):
     kmer = V.KmerVec(alphabet="hydro", k=14)
     kmer.set_kmer_set(out["kmerlist"][:200])
     blob = pickle.dumps(kmer, protocol=4)
+    # the reverse direction: a .kmers stream written by this repository (snekmer_amd.io.dump_kmers, host code only) is
+    # unpickled HERE by the imported reference, as snekmer/io.py:21-39 does, and read the way scripts/cluster_cluster.py:53-63
+    # reads it; the outcome is recorded as data in the fixture
+    import io as _io
+
+    import snekmer_amd
+
+    mine = snekmer_amd.vectorize.KmerVec("hydro", 14)
+    mine.set_kmer_set(out["kmerlist"][:200])
+    buf = _io.BytesIO()
+    snekmer_amd.io.dump_kmers(mine, buf)
+    back = pickle.loads(buf.getvalue())
+    assert type(back) is V.KmerVec and type(back.basis) is V.KmerBasis and type(back.kmer_set) is V.KmerSet
+    state_equal = (back.alphabet == kmer.alphabet and back.k == kmer.k and set(back.char_set) == set(kmer.char_set)
+                   and back.vector is None and sorted(back.__dict__) == sorted(kmer.__dict__)
+                   and (np.asarray(back.kmer_set._kmerlist) == np.asarray(kmer.kmer_set._kmerlist)).all()
+                   and sorted(back.basis.__dict__) == sorted(kmer.basis.__dict__)
+                   and all(np.array_equal(np.asarray(getattr(back.basis, a), dtype=object), np.asarray(getattr(kmer.basis, a), dtype=object))
+                           for a in kmer.basis.__dict__))
+    assert state_equal
+    # and the reference's own methods work on the object it loaded (a 2 x 3 array over 3 of the k-mers moved onto the 200-k-mer basis)
+    sub = [str(x) for x in out["kmerlist"][[5, 0, 150]]]
+    moved = back.basis.transform(np.arange(1, 7).reshape(2, 3), sub)
+    reverse = {"loaded_class": f"{type(back).__module__}.{type(back).__name__}", "state_equal": bool(state_equal),
+               "stream_bytes": len(buf.getvalue()), "reference_stream_bytes": len(blob),
+               "transform_nonzero_columns": [int(c) for c in np.flatnonzero(np.asarray(moved).any(axis=0))],
+               "transform_values": np.asarray(moved)[:, np.flatnonzero(np.asarray(moved).any(axis=0))].tolist(), "transform_kmers": sub}
     json.dump({"pickle_hex": blob.hex(), "alphabet": "hydro", "k": 14, "char_set": sorted(kmer.char_set),
                "n_kmers": 200, "first": [str(x) for x in out["kmerlist"][:5]],
-               "snekmer_version": kmer.snekmer_version, "attrs": sorted(kmer.__dict__.keys())},
+               "snekmer_version": kmer.snekmer_version, "attrs": sorted(kmer.__dict__.keys()), "reverse_direction": reverse},
               open(os.path.join(HERE, "g14_reference_kmers_pickle.json"), "w"))
     print("extra fixtures written: g12_apply_*.npz, g13_float_features.npz, g14_reference_kmers_pickle.json")
 

@@ -1460,6 +1460,56 @@ def test_config3_full_size_100k_red6_k12(ctx):
     _sampled_row_check(ctx, "red6", 12, 100000, seed_idx=2, full_stats=True)
 
 
+def test_config3_full_size_100k_overlapped_pipeline_the_timed_object(ctx):
+    """BASELINE configs[2] through the object bench.py times: engine.OverlappedPipeline with its defaults (60 % of a
+    batch's neighbour lists built on a CU-confined side context, default SPLIT_MIN_ROWS, two side contexts alternating),
+    four steps over two DIFFERENT 100 k batches (A B A B: every buffer set and side context is used twice, the second time
+    over the other batch's leftovers).  Every step's WHOLE 10^10-cell result is reduced on the device
+    (skm_matrix_row_stats): row non-zero counts equal to the C oracle's, row sums to float32 rounding; 48 sampled rows
+    <= 1e-5; counts bit-exact.  What every cell must equal: sklearn's cosine_similarity at rules/apply.smk:282-284."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+
+    orc = _oracle()
+    n, k = 100000, 12
+    lut = A.build_lut("red6")
+    pipe = engine.OverlappedPipeline(ctx, lut, k)
+    assert pipe.fraction == engine.OverlappedPipeline.SIDE_LIST_FRACTION > 0 and 0 < pipe._split_row(n) < n
+    assert pipe.sides[0] is not pipe.sides[1] and pipe.sides[0].cu_groups == engine.OverlappedPipeline.SIDE_CU_GROUPS
+    packed, batches, want = [], [], []
+    for seed_idx in (2, 31):
+        res, off = synth_families(n, 300, family=100, seed=20250523 + seed_idx)[:2]
+        packed.append((res, off))
+        batches.append(engine.SeqBatch(ctx, res, off))
+        o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off, threads=0)
+        ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first, threads=0)
+        _, o_sum, o_nnz = orc.cosine_all(o_rowptr, ocol, o_counts, len(ob), stats=True)
+        rows = np.sort(np.random.default_rng(seed_idx).choice(n, size=48, replace=False))
+        ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), rows)
+        want.append((o_rowptr, o_codes, o_counts, len(ob), o_sum, o_nnz, rows, ref))
+        del o_first, odf, otot, ofk, ocol
+    assert not (want[0][5] == want[1][5]).all()  # two different batches
+    order = (0, 1, 0, 1)
+    pipe.prefetch(batches[order[0]])
+    for step, which in enumerate(order):
+        nxt = batches[order[step + 1]] if step + 1 < len(order) else None
+        out = pipe.step(nxt)  # the next batch's vectorize + lists are queued beside this cosine, as in the bench
+        pipe.sync()
+        o_rowptr, o_codes, o_counts, ncols, o_sum, o_nnz, rows, ref = want[which]
+        ld = out.shape[1]
+        rowptr, codes, counts, _ = pipe.csr.host()
+        assert (rowptr == o_rowptr).all() and (codes.astype(np.uint64) == o_codes).all() and (counts == o_counts).all(), step
+        assert pipe.basis.ncols == ncols
+        rowsum, rownnz = engine.matrix_row_stats(ctx, out, n, n, ld)
+        assert (rownnz == o_nnz).all(), step
+        assert np.abs(rowsum - o_sum).max() <= 2e-6 * max(1.0, float(o_sum.max())), step
+        assert abs(float(rowsum.sum()) - float(o_sum.sum())) <= 1e-6 * float(o_sum.sum()), step
+        got = np.stack([out.download(n, offset=int(r) * ld) for r in rows])
+        assert np.abs(got - ref).max() <= COS_TOL, step
+    pipe.out = None
+
+
 def test_heavy_panels_at_100k_skewed_rows_equal_the_walk(ctx, monkeypatch):
     """bench.py's skewed workload at full size (100 k rows, 79 k of them heavy, families to 5 000): the whole 10^10-cell
     matrix with the heavy rows' long-list columns on the matrix cores against the same matrix with every list walked,

@@ -198,6 +198,58 @@ def test_reference_written_kmers_pickle_loads_through_the_module_alias():
     assert sorted(state.keys()) == g["attrs"]
 
 
+def test_kmers_written_here_is_the_stream_the_reference_writes(tmp_path):
+    """The reverse direction of G14: a .kmers file written by snekmer_amd (io.dump_kmers, what vectorize_fasta calls) names
+    ``snekmer.vectorize.KmerVec / KmerBasis / KmerSet`` and is, opcode for opcode, the stream the real reference wrote for the same
+    k-mer list (fixture G14) - so snekmer/io.py:21-39 + scripts/cluster_cluster.py:53-63 read it unchanged, with no snekmer_amd
+    installed.  (tests/golden/make_golden.py additionally unpickles such a file with the imported reference in the build
+    container and records the outcome in the fixture.)  Nothing named snekmer is left in sys.modules, and io.load_pickle reads
+    the file back as this package's classes."""
+    import io as _io
+    import pickletools
+    import sys
+
+    g = gjson("g14_reference_kmers_pickle.json")
+    ref_blob = bytes.fromhex(g["pickle_hex"])
+    (tmp_path / "ref.kmers").write_bytes(ref_blob)
+    ref_obj = skm.io.load_pickle(str(tmp_path / "ref.kmers"))  # the reference's own file, no alias needed
+    assert type(ref_obj) is skm.vectorize.KmerVec
+    mine = skm.vectorize.KmerVec(g["alphabet"], g["k"])
+    mine.set_kmer_set(ref_obj.kmer_set._kmerlist)
+    mine.snekmer_version = g["snekmer_version"]
+    mine._lut()
+    had = "snekmer" in sys.modules
+    buf = _io.BytesIO()
+    skm.io.dump_kmers(mine, buf)
+    assert ("snekmer" in sys.modules) == had and ("snekmer.vectorize" in sys.modules) == had
+    blob = buf.getvalue()
+
+    def ops(b):  # opcode stream without the frame sizes; the 2-element char_set is a set: its order follows the hash seed
+        out = []
+        for op, arg, _ in pickletools.genops(b):
+            if op.name == "FRAME":
+                continue
+            out.append((op.name, "<class letter>" if isinstance(arg, str) and len(arg) == 1 else
+                        (arg if not isinstance(arg, bytes) or len(arg) < 64 else hash(arg))))
+        return out
+
+    assert ops(blob) == ops(ref_blob)
+    assert len(blob) == len(ref_blob)
+    globals_named = [a for name, a in ops(blob) if isinstance(a, str) and (a.startswith("snekmer") or a.startswith("Kmer"))]
+    assert globals_named[:3] == ["snekmer.vectorize", "KmerVec", "KmerBasis"] and "KmerSet" in globals_named
+    assert not any("snekmer_amd" in str(a) for _, a in ops(blob))
+    # the flag off: this package's class path (a file for snekmer_amd only)
+    buf2 = _io.BytesIO()
+    skm.io.dump_kmers(mine, buf2, reference_pickle=False)
+    assert b"snekmer_amd.vectorize" in buf2.getvalue()
+    (tmp_path / "mine.kmers").write_bytes(blob)
+    back = skm.io.load_pickle(str(tmp_path / "mine.kmers"))
+    assert type(back) is skm.vectorize.KmerVec and type(back.basis) is skm.vectorize.KmerBasis and type(back.kmer_set) is skm.vectorize.KmerSet
+    assert sorted(back.__dict__) == g["attrs"] and (back.kmer_set._kmerlist == ref_obj.kmer_set._kmerlist).all()
+    if "reverse_direction" in g:  # recorded by make_golden.py with the real reference imported
+        assert g["reverse_direction"]["loaded_class"] == "snekmer.vectorize.KmerVec" and g["reverse_direction"]["state_equal"]
+
+
 def test_threaded_npz_writer_matches_numpy_savez(tmp_path):
     """skm_npz_write (host code) against np.savez_compressed / np.savez on the rule's members (rules/kmerize.smk:132-139):
     the same member names, dtypes, shapes and values through np.load and through the reference-shaped io.load_npz, a valid
