@@ -122,7 +122,10 @@ int skm_kmer_codes(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int cod
  * max_seq_len: an upper bound on the longest sequence of the batch (max of d_off[i+1] - d_off[i]; the offsets are host
  * data wherever a batch is packed), or 0 when the caller has none.  With the bound every count kernel is launched
  * with a worst-case grid and reads its work list on the device; without it the call also fetches the size classes
- * of the sequences to learn whether any has more than 8192 windows (one more host wait). */
+ * of the sequences to learn whether any has more than 8192 windows (one more host wait).  The bound is CHECKED on
+ * the device: a sequence with more windows than max_seq_len - k + 1 gets an empty row (it is never counted into scratch
+ * sized by the bound) and the context remembers it: this call (which waits for its entry count), or after
+ * skm_vectorize_csr the next skm_sync / skm_memcpy_d2h on the context, returns SKM_E_BADARG once. */
 int skm_count_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits,
                   const uint8_t *d_seq, const int64_t *d_off, int64_t n, int64_t total_residues,
                   int64_t max_seq_len, int64_t cap_entries, int64_t *d_rowptr, void *d_codes, uint32_t *d_counts,

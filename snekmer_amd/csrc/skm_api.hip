@@ -41,7 +41,14 @@ int create_ctx(int device_id, int first_group, int last_group, skm_ctx **out_ctx
         const int ncu = prop.multiProcessorCount;
         SKM_REQUIRE(first_group <= last_group && last_group <= 7, SKM_E_BADARG, "%s: CU groups %d..%d (want 0 <= first <= last <= 7)", who,
                     first_group, last_group);
-        SKM_REQUIRE(ncu >= 64 && ncu <= 512, SKM_E_UNSUPPORTED, "%s: %d compute units", who, ncu);
+        // The mask layout below (bit i = compute unit i, group (i / 8) % 8, every group holding eight CUs of every XCD) was
+        // verified on MI355X only: 256 CUs in 8 XCDs.  Anything else gets no confined stream (the callers fall back to an
+        // ordinary context).  NOTE: hipExtStreamCreateWithCUMask has no flags argument - the stream it returns is a BLOCKING
+        // stream, i.e. it synchronises implicitly with the legacy null stream of the process.  The library itself never
+        // uses the null stream (every copy and launch names a stream); a host program that does (e.g. another framework's
+        // default stream in the same process) serialises against confined contexts.
+        SKM_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0 && ncu == 256, SKM_E_UNSUPPORTED,
+                    "%s: CU-group masks are defined for gfx950 with 256 compute units (this device: %s, %d)", who, prop.gcnArchName, ncu);
         uint32_t mask[16] = {};
         for (int i = 0; i < ncu; ++i)
             if ((i / 8) % 8 >= first_group && (i / 8) % 8 <= last_group)
@@ -56,6 +63,11 @@ int create_ctx(int device_id, int first_group, int last_group, skm_ctx **out_ctx
     ctx->stream = stream;
     SKM_HIP(hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocDefault));
     memset(ctx->h_pinned, 0, 4096);  // (offset 2048: the previous cosine call's heavy-row count, skm_cosine_csr.hip)
+    void *dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, ctx->h_pinned, 0) == hipSuccess && dev)
+        ctx->d_err = (uint32_t *)dev + SKM_DEVERR_WORD;
+    else
+        (void)hipGetLastError();
     *out_ctx = ctx;
     return SKM_OK;
 }
@@ -130,11 +142,27 @@ extern "C" int skm_stream_wait(skm_ctx *ctx, skm_ctx *src, int slot)
     return SKM_OK;
 }
 
+int skm_check_device_error(skm_ctx *ctx, const char *who)
+{
+    volatile uint32_t *w = (volatile uint32_t *)ctx->h_pinned + SKM_DEVERR_WORD;
+    const uint32_t bits = *w;
+    if (!bits)
+        return SKM_OK;
+    *w = 0;
+    if (bits & SKM_DEVERR_SEQ_TOO_LONG) {
+        skm_set_error("%s: an earlier skm_count_csr / skm_vectorize_csr call on this context was given a max_seq_len smaller than "
+                      "one of its sequences; the rows of those sequences were left EMPTY (pass 0 or a true bound)", who);
+        return SKM_E_BADARG;
+    }
+    skm_set_error("%s: a kernel reported error bits 0x%x", who, bits);
+    return SKM_E_HIP;
+}
+
 extern "C" int skm_sync(skm_ctx *ctx)
 {
     SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
     SKM_HIP(hipStreamSynchronize(ctx->stream));
-    return SKM_OK;
+    return skm_check_device_error(ctx, "skm_sync");
 }
 
 extern "C" int skm_device_info(skm_ctx *ctx, char *h_name, int name_cap, int *h_cus, int64_t *h_mem_bytes)
@@ -227,7 +255,7 @@ extern "C" int skm_memcpy_d2h(skm_ctx *ctx, void *h_dst, const void *d_src, size
         return SKM_OK;
     SKM_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SKM_HIP(hipStreamSynchronize(ctx->stream));
-    return SKM_OK;
+    return skm_check_device_error(ctx, "skm_memcpy_d2h");
 }
 
 extern "C" int skm_memcpy_d2d(skm_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)

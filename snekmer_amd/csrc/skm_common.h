@@ -41,6 +41,10 @@ struct skm_ctx {
     void *ws[WS_COUNT] = {};
     size_t ws_bytes[WS_COUNT] = {};
     void *h_pinned = nullptr;  // small pinned buffer for count read-backs
+    // Sticky device-side error word: word SKM_DEVERR_WORD of h_pinned, written by kernels through its device address when an
+    // argument the host cannot check turns out wrong on the device (a sequence longer than the caller's max_seq_len); read
+    // and cleared by skm_check_device_error wherever the library has just waited for the stream.  nullptr: not addressable.
+    uint32_t *d_err = nullptr;
     hipEvent_t ev_host = nullptr;  // marks an asynchronous read-back the host waits for while later kernels run
     bool profiling = false;
     std::vector<skm_prof_entry> prof;
@@ -61,6 +65,10 @@ struct skm_ctx {
 };
 
 int skm_ws(skm_ctx *ctx, int slot, size_t bytes, void **out);
+constexpr int SKM_DEVERR_WORD = 768;  // byte 3072 of h_pinned
+constexpr uint32_t SKM_DEVERR_SEQ_TOO_LONG = 1u;
+// Call after a stream synchronise: reports (once) what kernels flagged since the last check.
+int skm_check_device_error(skm_ctx *ctx, const char *who);
 // similarity -> distance in place over a float32 block: out = clamp(1 - out, 0, 2), no diagonal rule (the epilogue of
 // mode 2 of skm_cosine_csr / skm_cosine_dense_i8: sklearn's cosine_distances(X, Y) with Y another matrix than X);
 // defined in skm_cosine_csr.hip

@@ -1674,8 +1674,11 @@ extern "C" int skm_heavy_panel_stats(skm_ctx *ctx, int64_t *h_out6)
     SKM_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<uint32_t> meta(4 * (size_t)ctx->panel_nb);
     uint32_t rows = 0;
-    SKM_HIP(hipMemcpy(meta.data(), ctx->panel_meta, sizeof(uint32_t) * meta.size(), hipMemcpyDeviceToHost));
-    SKM_HIP(hipMemcpy(&rows, ctx->panel_rows, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // on the context's own stream: a plain hipMemcpy goes through the null stream, which a CU-masked (blocking) stream of
+    // another context would synchronise with
+    SKM_HIP(hipMemcpyAsync(meta.data(), ctx->panel_meta, sizeof(uint32_t) * meta.size(), hipMemcpyDeviceToHost, ctx->stream));
+    SKM_HIP(hipMemcpyAsync(&rows, ctx->panel_rows, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SKM_HIP(hipStreamSynchronize(ctx->stream));
     const int64_t used = std::min<int64_t>(ctx->panel_nb, ((int64_t)rows + PB_ROWS - 1) / PB_ROWS);
     h_out6[0] = rows;
     h_out6[1] = used;

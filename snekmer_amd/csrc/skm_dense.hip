@@ -1411,7 +1411,10 @@ __global__ __launch_bounds__(256) void k_cosine_fixup_rows(int64_t n, const int6
             }
         }
         if (j < n) {
-            float o = (float)(acc * (double)rnorm[i] * (double)rnorm[j]);
+            // a cell whose row AND column are irregular is written by two work items ((i, j) and (j, i)); the integer sum is
+            // the same in both (exact in float64 below 2^53) and the scale is formed symmetrically, so both store one value
+            const double scale = (double)rnorm[i < j ? i : j] * (double)rnorm[i < j ? j : i];
+            float o = (float)(acc * scale);
             if (MODE == 1) {
                 o = fminf(fmaxf(1.0f - o, 0.0f), 2.0f);
                 if (i == j)

@@ -62,7 +62,8 @@ __global__ void k_recode_bytes(skm_lut256 lut, const uint8_t *__restrict__ seq, 
 // Stripped length (trailing '*' removed, snekmer/vectorize.py:193), window count and size class.
 __global__ void k_classify(const uint8_t *__restrict__ seq, const int64_t *__restrict__ off, int64_t n, int k,
                            int32_t *__restrict__ slen, int32_t *__restrict__ nwin, uint32_t *__restrict__ lists,
-                           uint32_t *__restrict__ bucket_fill, int32_t *__restrict__ row_nnz)
+                           uint32_t *__restrict__ bucket_fill, int32_t *__restrict__ row_nnz, int64_t max_win = -1,
+                           uint32_t *err = nullptr)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -74,6 +75,13 @@ __global__ void k_classify(const uint8_t *__restrict__ seq, const int64_t *__res
     int64_t w = len - k + 1;
     if (w < 0)
         w = 0;
+    if (max_win >= 0 && w > max_win) {
+        // longer than the bound the caller gave (which sized the launches and the scratch behind this kernel): the row
+        // stays empty and the context's sticky error word says so at the next host wait (skm_check_device_error)
+        w = 0;
+        if (err)
+            __hip_atomic_fetch_or(err, SKM_DEVERR_SEQ_TOO_LONG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (slen)
         slen[i] = (int32_t)len;
     if (nwin)
@@ -761,8 +769,9 @@ int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const u
     SKM_HIP(hipMemsetAsync(fill, 0, sizeof(uint32_t) * NBUCKET, st));
     {
         SKM_PROF(ctx, "k_classify");
+        const int64_t max_win = max_seq_len > 0 ? (max_seq_len - k + 1 > 0 ? max_seq_len - k + 1 : 0) : -1;
         k_classify<<<(unsigned)skm_ceil_div(n, 256), 256, 0, st>>>(d_seq, d_off, n, k, slen, nullptr, lists, fill,
-                                                                     row_nnz);
+                                                                     row_nnz, max_win, ctx->d_err);
     }
     SKM_TRY(skm_check_launch("k_classify"));
     // Every count kernel reads its list length on the device and is launched with a grid that covers the worst case,
@@ -868,6 +877,7 @@ int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const u
         SKM_HIP(hipMemcpyAsync(h_n, d_rowptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         SKM_HIP(hipStreamSynchronize(st));
         *h_nnz = *h_n;
+        SKM_TRY(skm_check_device_error(ctx, "skm_count_csr"));
     }
     return SKM_OK;
 }

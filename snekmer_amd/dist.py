@@ -310,7 +310,11 @@ class ShardedPipeline:
             self.local = loc = e.count_csr(ctx, shard_batch, self.lut, self.k, out=self.local)
             e.row_norms(ctx, nloc, loc.rowptr, loc.counts, out=rn)
             cap = 1
-        # 1. entries grouped by owner rank (sized by the capacity; the entry count stays on the device)
+        # 1. entries grouped by owner rank (sized by the capacity; the entry count stays on the device).  The grouping is one
+        # digit of the library's one-sweep sort, whose tile words hold 30-bit positions: a shard is limited to 2^30 - 1
+        # residues (3.5 M sequences of 300 aa on ONE rank; include/snekmer_hip.h, skm_bucket_partition)
+        if cap >= 1 << 30:
+            raise ValueError(f"rank {me}: a shard of {cap - 1} residues; ShardedPipeline holds at most 2^30 - 1 per rank: use more ranks")
         p_codes = self._need("p_codes", cap, self.code_dtype)
         p_rc = self._need("p_rc", cap, np.uint64)
         ctx.call("skm_bucket_partition", self.code_bits, G, _i64(loc.n), _i64(cap), _p(loc.rowptr.ptr),

@@ -1893,6 +1893,31 @@ def test_c_abi_error_codes_and_messages(ctx):
     assert e.value.code == -1 and "row range" in str(e.value)
     out = C.c_void_p()
     assert lib.skm_create(99, C.byref(out)) == -1 and b"out of range" in lib.skm_last_error()
+    # max_seq_len is checked on the device: sequences longer than the bound get EMPTY rows (nothing is counted into scratch
+    # sized by the bound) and the call that waits - or, after the fused call, the next wait on the context - says so once
+    rng = np.random.default_rng(5)
+    aa = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+    seqs = ["MKVLAAGIW", aa[rng.integers(0, 20, 700)].tobytes().decode(), "MKVLAAGIWMKV", aa[rng.integers(0, 20, 9000)].tobytes().decode(),
+            aa[rng.integers(0, 20, 20000)].tobytes().decode()]
+    big = engine.SeqBatch.from_strings(ctx, seqs)
+    good = engine.count_csr(ctx, big, lut, 4)
+    want_rowptr = good.rowptr.download(6)
+    for bound in (12, 100, 8000, 9500):  # below the wave kernel's, the workgroup kernel's and the global-scratch kernel's sizes
+        fake = engine.SeqBatch.from_strings(ctx, seqs)
+        fake.max_len = bound
+        with pytest.raises(_hip.HipError) as e:
+            engine.count_csr(ctx, fake, lut, 4)
+        assert e.value.code == -1 and "max_seq_len" in str(e.value)
+        csr, _, _ = engine.vectorize_fused(ctx, fake, lut, 4)   # no wait inside: the error surfaces at the next one
+        with pytest.raises(_hip.HipError) as e:
+            ctx.sync()
+        assert e.value.code == -1 and "EMPTY" in str(e.value)
+        ctx.sync()  # reported once
+        got = np.diff(csr.rowptr.download(6))
+        lens = np.array([len(s) for s in seqs])
+        assert (got[lens <= bound] == np.diff(want_rowptr)[lens <= bound]).all() and (got[lens > bound] == 0).all()
+    again = engine.count_csr(ctx, big, lut, 4)  # the context is healthy afterwards
+    assert (again.rowptr.download(6) == want_rowptr).all()
 
 
 @pytest.mark.cosine_paths
