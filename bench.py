@@ -23,6 +23,9 @@ Besides the contract keys the line carries, all measured in this same run after 
   reference_alphabet_check   the nearest reference alphabet (standard k=12, uint64 codes)
   config5_count_dense    BASELINE configs[4]: 100k x 2^20 uint16 dense count scatter (210 GB)
   dense_mfma             the i8 MFMA cosine GEMM at hydro k=14, N = 32768
+  apply_chain            SURVEY 8(f) f1/f2: learn aggregation + fused apply epilogue, 100 k queries x 1000 family totals
+  config4_one_rank_share BASELINE configs[3]: 1 M sequences vectorized + one rank's 125 k x 1 M neighbour lists + top-10
+  overlapped_equals_single   the timed object's last result against the one-stream pipeline's, whole matrix, in this run
   cpu_baseline           reference-equivalent numpy path at several N with a quadratic fit, and the
                          sparse C restatement on one core and on all cores of this GPU's host share
 """
@@ -914,6 +917,132 @@ def api_vectorize_fasta(args, seed):
     return out
 
 
+def apply_chain(ctx, engine, alphabet, args, seed):
+    """SURVEY 8(f) rows f1/f2, the reference's only real consumer of the cosine (rules/apply.smk:278-342, rules/learn.smk:385-408,
+    811-849): N query sequences against A family-total rows.  Timed: the learn aggregation (skm_csr_group_sum), the fused
+    epilogue (skm_apply_top2: exact int64 dots, float64 scores, top-2 per query, the N x A block never stored) and, for
+    comparison, the materialised N x A float32 block (skm_cosine_csr) + skm_row_top2.  Roofline of k_apply_top2: postings
+    walked x 8 B (every entry of a query row reads the posting list of its column in the totals matrix)."""
+    from snekmer_amd import apply as skm_apply
+    from snekmer_amd.synth import synth_families
+
+    n = args.n
+    lut = alphabet.build_lut(args.alphabet)
+    res, off, fam = synth_families(n, args.length, family=100, seed=seed)
+    batch = engine.SeqBatch(ctx, res, off)
+    csr = engine.count_csr(ctx, batch, lut, args.k)
+    basis = engine.build_basis(ctx, csr, lut.nsym, args.k, postings=False)
+    nfam = int(fam.max()) + 1
+    groups = fam.astype(np.uint32)
+    totals = skm_apply.group_sum(ctx, csr, groups, nfam)
+    # postings walked: sum over query entries of the column's document frequency in the totals matrix
+    tcol = totals.colidx.download(totals.nnz)
+    df = np.bincount(tcol, minlength=basis.ncols)
+    walked = int(df[csr.colidx.download(csr.nnz)].sum())
+    out = {"workload": f"{n} queries x {nfam} family totals ({args.alphabet} k={args.k}; the families of the bench workload, 100 members each)",
+           "queries": n, "families": nfam, "query_entries": csr.nnz, "totals_entries": totals.nnz, "basis_columns": basis.ncols,
+           "postings_walked": walked}
+    reps = 5
+
+    def timed(fn):
+        fn()
+        ctx.sync()
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        ctx.sync()
+        wall = (time.perf_counter() - t0) / reps * 1e3
+        prof = {k: v[1] / reps for k, v in ctx.profile_dump().items()}
+        ctx.profile_enable(False)
+        return wall, prof, r
+
+    w, pr, _ = timed(lambda: skm_apply.group_sum(ctx, csr, groups, nfam))
+    out["group_sum"] = {"ms_incl_host": w, "kernel_ms": {k: round(v, 4) for k, v in pr.items() if v > 0.002}, "device_ms": sum(pr.values())}
+    w, pr, r = timed(lambda: skm_apply.apply_top2(ctx, csr, basis.ncols, totals))
+    k_ms = pr.get("k_apply_top2", 0.0)
+    dev_ms = sum(pr.values())
+    out["fused_apply_top2"] = {
+        "ms_incl_host": w, "device_ms": dev_ms, "kernel_ms": {k: round(v, 4) for k, v in pr.items() if v > 0.002},
+        "sequences_per_s_device": n / (dev_ms * 1e-3) if dev_ms > 0 else None,
+        "roofline": {"kernel": "k_apply_top2", "bound": "hbm", "algorithmic_bytes": walked * 8 + csr.nnz * 16 + n * 40,
+                     "bytes_are": "8 B per posting walked + 16 B per query entry (column id, count, column start and end) + 40 B per row written",
+                     "ms": k_ms, "achieved_GBps": (walked * 8 + csr.nnz * 16 + n * 40) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
+                     "frac": (walked * 8 + csr.nnz * 16 + n * 40) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
+                     "note": "latency-bound: three dependent gathers per entry (column start, posting, accumulator)"}}
+    out["top1_is_own_family_frac"] = float(np.mean(r[0][:, 0] == fam))
+
+    def unfused():
+        S, ld = skm_apply.cosine_rows_vs_totals(ctx, csr, basis.ncols, totals)
+        return skm_apply.row_top2(ctx, S, n, nfam, ld)
+
+    w, pr, r2 = timed(unfused)
+    out["materialised_block_then_top2"] = {"ms_incl_host": w, "device_ms": sum(pr.values()), "block_bytes": int(n * ((nfam + 3) // 4 * 4) * 4),
+                                           "kernel_ms": {k: round(v, 4) for k, v in pr.items() if v > 0.002}}
+    out["fused_equals_materialised_top1"] = bool((r2[0][:, 0] == r[0][:, 0]).all())
+    out["parity"] = "tests/test_gpu_parity.py::test_apply_epilogue_matches_reference_rule_golden (delta / Confidence equal to G12)"
+    return out
+
+
+def config4_one_rank_share(ctx, engine, alphabet, args):
+    """BASELINE configs[3] (1 M x 300 aa sharded 8 ways) as far as ONE GPU can measure it: all 1 M sequences vectorized here
+    (a rank of the sharded job vectorizes 1/8 of them and receives the postings of the rest), then one rank's share of the
+    pairwise step: exact neighbour lists of 125 k rows against all 1 M columns and the top-10 per row (the 1 M x 1 M float32
+    matrix would be 4 TB; DESIGN.md section 2, decision 2).  The 8-GPU figure derived from it is an ESTIMATE, labelled so."""
+    from snekmer_amd.synth import BASE_SEED, synth_families
+
+    n, world = 1_000_000, 8
+    block = n // world
+    lut = alphabet.build_lut(args.alphabet)
+    t0 = time.perf_counter()
+    res, off, fam = synth_families(n, args.length, family=100, seed=BASE_SEED + 3)
+    gen_s = time.perf_counter() - t0
+    batch = engine.SeqBatch(ctx, res, off)
+    pipe = engine.Pipeline(ctx, lut, args.k)
+    rec = None
+    for rnd in range(2):
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        ctx.sync()
+        t0 = time.perf_counter()
+        pipe.vectorize(batch)
+        ctx.sync()
+        t_vec = time.perf_counter() - t0
+        b = pipe.basis
+        t0 = time.perf_counter()
+        nb = engine.gram_neighbors(ctx, pipe.csr, pipe.rnorm, n, b.ncols, b.colptr, b.post, pipe.rnorm, row0=0, row1=block,
+                                   cap_entries=block * 6000, post_bits=b.post_bits, postcnt=b.postcnt)
+        ctx.sync()
+        t_nb = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        idx, val = engine.neighbors_topk(ctx, nb, pipe.rnorm, pipe.rnorm, 10, exclude_self=True)
+        t_top = time.perf_counter() - t0
+        prof = ctx.profile_dump()
+        ctx.profile_enable(False)
+        rec = (t_vec, t_nb, t_top, prof, nb.total, nb.overflow_rows)
+        if rnd == 0:
+            del nb
+    t_vec, t_nb, t_top, prof, entries, ovf = rec
+    same = float(np.mean(fam[idx[:, 0].astype(np.int64) % n] == fam[:block]))
+    # a rank of the 8-GPU job: vectorize of its 125 k sequences (1/8 of the vectorize measured here), the exchange (not
+    # measurable on one GPU: DESIGN.md section 7 prices it), then exactly the pairwise share measured here
+    est = t_vec / world + t_nb + t_top
+    return {
+        "workload": f"BASELINE configs[3]: {n} x {args.length}aa, {args.alphabet} k={args.k}; one rank's share on one MI355X",
+        "generator_s": gen_s, "nnz": pipe.csr.nnz, "basis_columns": b.ncols,
+        "vectorize_1m_ms": t_vec * 1e3, "vectorize_sequences_per_s": n / t_vec,
+        "neighbour_lists_125k_x_1m_ms": t_nb * 1e3, "list_entries": int(entries), "entries_per_row": entries / block, "overflow_rows": int(ovf),
+        "top10_ms_incl_download": t_top * 1e3, "top1_same_family_frac": same,
+        "kernel_ms": {k: round(v[1], 3) for k, v in prof.items() if v[1] > 0.05},
+        "ESTIMATE_8_gpu": {"ms_per_job": est * 1e3, "sequences_per_s": n / est,
+                           "how": "vectorize_1m_ms / 8 + neighbour_lists_125k_x_1m_ms + top10_ms: every rank's device work if the postings "
+                                  "exchange (0.38 GB out, 2.2 GB in per rank over xGMI) were free; an estimate from one GPU, NOT a measurement "
+                                  "of 8 GPUs"},
+        "parity": "tests/test_gpu_parity.py::test_config4_one_rank_share_125k_rows_vs_1m, tests/test_gpu_sharded.py (8 thread-ranks, 1 M sequences)",
+    }
+
+
 def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed):
     """Measurements taken after the timed region, on the same GPU in the same run."""
     import ctypes as C
@@ -1058,6 +1187,12 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
     # the 40 GB result is no longer needed: make room for the 210 GB count matrix
     pipe.out = None
     _, _, mem = ctx.device_info()
+
+    line["apply_chain"] = apply_chain(ctx, engine, alphabet, args, seed)
+    note("extras: apply_chain")
+    if mem >= 150 * 2**30:
+        line["config4_one_rank_share"] = config4_one_rank_share(ctx, engine, alphabet, args)
+        note("extras: config4_one_rank_share")
 
     # BASELINE configs[4]: dense count scatter, hydro k=20, uint16 cells
     lut2 = alphabet.build_lut("hydro")

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SKM_ABI_VERSION 4
+#define SKM_ABI_VERSION 5
 
 #define SKM_OK 0
 #define SKM_E_BADARG (-1)
@@ -45,6 +45,7 @@ extern "C" {
 #define SKM_E_OVERFLOW (-4)
 #define SKM_E_UNSUPPORTED (-5)
 #define SKM_E_COMM (-6)
+#define SKM_E_STALE (-7) /* skm_graph_launch: the graph holds a scratch address that has since been reallocated */
 
 typedef struct skm_ctx skm_ctx;
 
@@ -68,6 +69,21 @@ int skm_destroy(skm_ctx *ctx);
 int skm_event_record(skm_ctx *ctx, int slot);
 int skm_stream_wait(skm_ctx *ctx, skm_ctx *src, int slot);
 int skm_sync(skm_ctx *ctx); /* host-synchronous */
+/* Replay of a fixed sequence of calls as one HIP graph (no reference counterpart; the reference's unit of work is one
+ * Snakemake job per FASTA file of 50-3700 records, snekmer/rules/kmerize.smk:57-65, where a vectorize + cosine step is a
+ * few dozen launches of microseconds each and the host's launch cost is the step).  skm_graph_begin opens a capture on
+ * the context's stream; every call made on the context until skm_graph_end is RECORDED, NOT RUN (so only calls that do
+ * not wait for the device may be made: skm_vectorize_csr with max_seq_len > 0, skm_cosine_csr, skm_csr_to_dense_i8,
+ * skm_cosine_dense_i8, skm_cosine_fixup_rows, ...; the same calls must have run once before the capture, so that the
+ * context's scratch has its size: scratch may not grow inside a capture).  skm_graph_launch queues the recorded work: the
+ * same kernels on the same buffers with the same sizes, reading whatever those buffers hold now.  It returns SKM_E_STALE
+ * when a scratch buffer of the context has been reallocated since the capture (capture again).  Choices the library
+ * makes on the host between kernels (which of two exact kernels runs) are frozen into the graph. */
+typedef struct skm_graph skm_graph;
+int skm_graph_begin(skm_ctx *ctx);
+int skm_graph_end(skm_ctx *ctx, skm_graph **out_graph);
+int skm_graph_launch(skm_ctx *ctx, skm_graph *graph);
+int skm_graph_destroy(skm_ctx *ctx, skm_graph *graph);
 int skm_device_info(skm_ctx *ctx, char *h_name, int name_cap, int *h_cus, int64_t *h_mem_bytes);
 
 /* ---- device memory ----------------------------------------------------------------------- */

@@ -17,8 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNEKMER_HIP_LIB") or os.path.join(_HERE, "libsnekmer_hip.so")
 
 SKM_OK = 0
-ABI_VERSION = 4  # SKM_ABI_VERSION of include/snekmer_hip.h
-ERRORS = {-1: "BADARG", -2: "NOMEM", -3: "HIP", -4: "OVERFLOW", -5: "UNSUPPORTED", -6: "COMM"}
+ABI_VERSION = 5  # SKM_ABI_VERSION of include/snekmer_hip.h
+ERRORS = {-1: "BADARG", -2: "NOMEM", -3: "HIP", -4: "OVERFLOW", -5: "UNSUPPORTED", -6: "COMM", -7: "STALE"}
 COMM_ID_BYTES = 128
 
 
@@ -52,6 +52,10 @@ _SIGNATURES = {
     "skm_create_confined": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_p)]),
     "skm_destroy": (C.c_int, [_p]),
     "skm_sync": (C.c_int, [_p]),
+    "skm_graph_begin": (C.c_int, [_p]),
+    "skm_graph_end": (C.c_int, [_p, C.POINTER(_p)]),
+    "skm_graph_launch": (C.c_int, [_p, _p]),
+    "skm_graph_destroy": (C.c_int, [_p, _p]),
     "skm_event_record": (C.c_int, [_p, C.c_int]),
     "skm_stream_wait": (C.c_int, [_p, _p, C.c_int]),
     "skm_device_info": (C.c_int, [_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_i64)]),
@@ -313,6 +317,15 @@ class Context:
     def sync(self):
         _check(self.lib, self.lib.skm_sync(self.handle))
 
+    # -- HIP graphs (skm_graph_*): record a fixed sequence of calls once, replay it with one launch
+    def graph_begin(self):
+        _check(self.lib, self.lib.skm_graph_begin(self.handle))
+
+    def graph_end(self) -> "Graph":
+        g = _p()
+        _check(self.lib, self.lib.skm_graph_end(self.handle, C.byref(g)))
+        return Graph(self, g)
+
     def record_event(self, slot: int):
         """Mark the current end of this context's stream in `slot` (skm_event_record)."""
         _check(self.lib, self.lib.skm_event_record(self.handle, slot))
@@ -331,6 +344,7 @@ class Context:
     # -- profiling
     def profile_enable(self, on: bool = True):
         _check(self.lib, self.lib.skm_profile_enable(self.handle, 1 if on else 0))
+        self.profiling = bool(on)  # (engine.Pipeline runs eagerly while per-kernel timing is on: a graph replay records no events)
 
     def profile_reset(self):
         _check(self.lib, self.lib.skm_profile_reset(self.handle))
@@ -357,6 +371,27 @@ class Context:
         if self.handle is None:
             raise HipError(-1, f"{name}: the context is closed")
         _check(self.lib, getattr(self.lib, name)(self.handle, *args))
+
+
+class Graph:
+    """A captured sequence of calls on one context (skm_graph_begin .. skm_graph_end)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self.handle = ctx, handle
+
+    def launch(self):
+        _check(self.ctx.lib, self.ctx.lib.skm_graph_launch(self.ctx.handle, self.handle))
+
+    def close(self):
+        if self.handle is not None and self.ctx.handle is not None:
+            self.ctx.lib.skm_graph_destroy(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _default_ctx: Optional[Context] = None

@@ -37,6 +37,7 @@ int create_ctx(int device_id, int first_group, int last_group, skm_ctx **out_ctx
     hipDeviceProp_t prop;
     SKM_HIP(hipGetDeviceProperties(&prop, device_id));
     hipStream_t stream = nullptr;
+    int usable = prop.multiProcessorCount;
     if (first_group >= 0) {
         const int ncu = prop.multiProcessorCount;
         SKM_REQUIRE(first_group <= last_group && last_group <= 7, SKM_E_BADARG, "%s: CU groups %d..%d (want 0 <= first <= last <= 7)", who,
@@ -53,6 +54,9 @@ int create_ctx(int device_id, int first_group, int last_group, skm_ctx **out_ctx
         for (int i = 0; i < ncu; ++i)
             if ((i / 8) % 8 >= first_group && (i / 8) % 8 <= last_group)
                 mask[i / 32] |= 1u << (i % 32);
+        usable = 0;
+        for (int i = 0; i < ncu; ++i)
+            usable += (mask[i / 32] >> (i % 32)) & 1u;
         SKM_HIP(hipExtStreamCreateWithCUMask(&stream, (uint32_t)((ncu + 31) / 32), mask));
     } else {
         SKM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -60,6 +64,7 @@ int create_ctx(int device_id, int first_group, int last_group, skm_ctx **out_ctx
     skm_ctx *ctx = new skm_ctx();
     ctx->device = device_id;
     ctx->num_cus = prop.multiProcessorCount;
+    ctx->usable_cus = usable;
     ctx->stream = stream;
     SKM_HIP(hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocDefault));
     memset(ctx->h_pinned, 0, 4096);  // (offset 2048: the previous cosine call's heavy-row count, skm_cosine_csr.hip)
@@ -281,6 +286,12 @@ int skm_ws(skm_ctx *ctx, int slot, size_t bytes, void **out)
     if (bytes < 256)
         bytes = 256;
     if (ctx->ws_bytes[slot] < bytes) {
+        if (ctx->capturing) {
+            skm_set_error("scratch slot %d would grow (%zu -> %zu bytes) inside skm_graph_begin .. skm_graph_end: run the same calls "
+                          "once outside a capture first", slot, ctx->ws_bytes[slot], bytes);
+            return SKM_E_UNSUPPORTED;
+        }
+        ++ctx->ws_generation;
         if (ctx->ws[slot]) {
             SKM_HIP(hipStreamSynchronize(ctx->stream));
             SKM_HIP(hipFree(ctx->ws[slot]));
@@ -295,17 +306,96 @@ int skm_ws(skm_ctx *ctx, int slot, size_t bytes, void **out)
             return SKM_E_NOMEM;
         }
         ctx->ws_bytes[slot] = want;
-        if (slot == WS_COS)  // holds a ticket counter that every user leaves at zero (k_cosine_prologue)
+        if (slot == WS_COS || slot == WS_ZERO)  // hold counters that every user leaves at zero (k_cosine_prologue, k_compact_rows)
             SKM_HIP(hipMemsetAsync(ctx->ws[slot], 0, want, ctx->stream));
     }
     *out = ctx->ws[slot];
     return SKM_OK;
 }
 
+// ---------------------------------------------------------------------------- graphs
+struct skm_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t ws_generation = 0;
+    skm_ctx *owner = nullptr;
+};
+
+extern "C" int skm_graph_begin(skm_ctx *ctx)
+{
+    SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    SKM_REQUIRE(!ctx->capturing, SKM_E_BADARG, "skm_graph_begin: a capture is already open on this context");
+    SKM_HIP(hipSetDevice(ctx->device));
+    // relaxed mode: other threads (and this one) may allocate and free while the capture is open; what is captured is
+    // exactly what the library queues on this context's stream
+    SKM_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+    ctx->capturing = true;
+    return SKM_OK;
+}
+
+extern "C" int skm_graph_end(skm_ctx *ctx, skm_graph **out_graph)
+{
+    SKM_REQUIRE(ctx && out_graph, SKM_E_BADARG, "skm_graph_end: null argument");
+    *out_graph = nullptr;
+    SKM_REQUIRE(ctx->capturing, SKM_E_BADARG, "skm_graph_end: no capture is open on this context");
+    ctx->capturing = false;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+    if (e != hipSuccess || !g) {
+        (void)hipGetLastError();
+        skm_set_error("skm_graph_end: the capture was invalidated (%s): a call inside it waited for the device or used another stream",
+                      hipGetErrorString(e));
+        return SKM_E_HIP;
+    }
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipGraphDestroy(g);
+        skm_set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
+        return SKM_E_HIP;
+    }
+    skm_graph *gr = new skm_graph();
+    gr->graph = g;
+    gr->exec = x;
+    gr->ws_generation = ctx->ws_generation;
+    gr->owner = ctx;
+    *out_graph = gr;
+    return SKM_OK;
+}
+
+extern "C" int skm_graph_launch(skm_ctx *ctx, skm_graph *graph)
+{
+    SKM_REQUIRE(ctx && graph && graph->owner == ctx, SKM_E_BADARG, "skm_graph_launch: the graph was captured on another context");
+    SKM_REQUIRE(!ctx->capturing, SKM_E_BADARG, "skm_graph_launch: a capture is open on this context");
+    if (graph->ws_generation != ctx->ws_generation) {
+        skm_set_error("skm_graph_launch: a scratch buffer of the context was reallocated since the capture; capture again");
+        return SKM_E_STALE;
+    }
+    SKM_HIP(hipSetDevice(ctx->device));
+    SKM_HIP(hipGraphLaunch(graph->exec, ctx->stream));
+    return SKM_OK;
+}
+
+extern "C" int skm_graph_destroy(skm_ctx *ctx, skm_graph *graph)
+{
+    SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    if (!graph)
+        return SKM_OK;
+    SKM_HIP(hipSetDevice(ctx->device));
+    (void)hipStreamSynchronize(ctx->stream);  // a replay may still be running
+    if (graph->exec)
+        (void)hipGraphExecDestroy(graph->exec);
+    if (graph->graph)
+        (void)hipGraphDestroy(graph->graph);
+    delete graph;
+    return SKM_OK;
+}
+
 // ---------------------------------------------------------------------------- profiling
 skm_prof_scope::skm_prof_scope(skm_ctx *c, const char *name, hipStream_t on) : ctx(c), st(on ? on : c->stream)
 {
-    if (!ctx->profiling)
+    if (!ctx->profiling || ctx->capturing)
         return;
     skm_prof_entry ent;
     ent.name = name;
@@ -427,8 +517,6 @@ extern "C" int skm_vectorize_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, 
     void *p;
     SKM_TRY(skm_ws(ctx, WS_K, sizeof(uint64_t) * (size_t)(total_residues + 1), &p));
     uint64_t *rowcount = (uint64_t *)p;
-    SKM_TRY(skm_count_stage_async(ctx, h_rank, nsym, k, code_bits, d_seq, d_off, n, total_residues, max_seq_len, d_rowptr, d_codes, d_counts,
-                                  rowcount, d_rnorm, d_normsq));
     int key_bits = 0;
     {
         unsigned __int128 space = 1;
@@ -442,6 +530,14 @@ extern "C" int skm_vectorize_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, 
         if (key_bits < 1)
             key_bits = 1;
     }
+    // no fill operation between the stages: the count stage's last kernel marks colidx and clears the sort state
+    skm_count_extras extras;
+    extras.colidx_ff = d_colidx;
+    SKM_TRY(skm_basis_sort_state(ctx, total_residues, key_bits, code_bits, &extras.zero, &extras.zero_words, &extras.hist_passes,
+                                 &extras.hist_key_bits));
+    extras.hist = extras.zero != nullptr;  // ... and counts the sort's digit histograms while it writes the codes
+    SKM_TRY(skm_count_stage_async(ctx, h_rank, nsym, k, code_bits, d_seq, d_off, n, total_residues, max_seq_len, d_rowptr, d_codes, d_counts,
+                                  rowcount, d_rnorm, d_normsq, extras));
     return skm_basis_stage_async(ctx, code_bits, key_bits, total_residues, d_rowptr + n, d_codes, rowcount, d_basis, d_colidx,
-                                 d_colptr, d_post, d_ncols);
+                                 d_colptr, d_post, d_ncols, extras);
 }

@@ -1031,9 +1031,32 @@ extern "C" int skm_pair_work(skm_ctx *ctx, int64_t ncols, const uint32_t *d_colp
     return SKM_OK;
 }
 
+// The sort state the basis stage will use for `cap` keys (same slot, same size as skm_basis_stage_async asks for), so that
+// the stage in front can have it cleared: *out_state = nullptr when the stage uses the vendor sort (which clears its own).
+int skm_basis_sort_state(skm_ctx *ctx, int64_t cap, int key_bits, int code_bits, uint32_t **out_state, int64_t *out_words,
+                         int *out_passes, int *out_key_bits)
+{
+    *out_state = nullptr;
+    *out_words = 0;
+    if (key_bits <= 0 || key_bits > code_bits)
+        key_bits = code_bits;
+    if (!skm_use_onesweep(cap))
+        return SKM_OK;
+    const int passes = (key_bits + 7) / 8;
+    void *p;
+    SKM_TRY(skm_ws(ctx, WS_ROCPRIM, skm_onesweep::state_bytes(cap, 8192, passes) + skm_onesweep::state_bytes(cap, 2048, passes), &p));
+    *out_state = (uint32_t *)p;
+    *out_words = (int64_t)((skm_onesweep::sort_state_bytes(cap, key_bits) + 3) / 4);
+    if (out_passes)
+        *out_passes = passes;
+    if (out_key_bits)
+        *out_key_bits = key_bits;
+    return SKM_OK;
+}
+
 int skm_basis_stage_async(skm_ctx *ctx, int code_bits, int key_bits, int64_t cap, const int64_t *d_nnz, const void *d_codes,
                           const uint64_t *d_rowcount, void *d_basis, uint32_t *d_colidx, uint32_t *d_colptr, uint64_t *d_post,
-                          int64_t *d_ncols)
+                          int64_t *d_ncols, const skm_count_extras &prepared)
 {
     hipStream_t st = ctx->stream;
     const size_t kb = (size_t)(code_bits / 8);
@@ -1047,7 +1070,8 @@ int skm_basis_stage_async(skm_ctx *ctx, int code_bits, int key_bits, int64_t cap
     uint32_t *blockheads = (uint32_t *)p;
     if (key_bits <= 0 || key_bits > code_bits)
         key_bits = code_bits;
-    SKM_HIP(hipMemsetAsync(d_colidx, 0xFF, sizeof(uint32_t) * (size_t)cap, st));
+    if (prepared.colidx_ff != d_colidx)  // (a fused call: the count stage wrote the marker beside every entry)
+        SKM_HIP(hipMemsetAsync(d_colidx, 0xFF, sizeof(uint32_t) * (size_t)cap, st));
     if (skm_use_onesweep(cap)) {
         // the library's own sort: sized by the device-side entry count, 2 + (key_bits / 8) launches (skm_onesweep.h)
         const int passes = (key_bits + 7) / 8;
@@ -1056,12 +1080,14 @@ int skm_basis_stage_async(skm_ctx *ctx, int code_bits, int key_bits, int64_t cap
         SKM_TRY(skm_ws(ctx, WS_I, sizeof(uint32_t) * (size_t)cap, &p));
         uint32_t *vtmp = (uint32_t *)p;
         SKM_TRY(skm_ws(ctx, WS_ROCPRIM, skm_onesweep::state_bytes(cap, 8192, passes) + skm_onesweep::state_bytes(cap, 2048, passes), &p));
+        const bool zeroed = prepared.zero == (uint32_t *)p &&
+                            (size_t)prepared.zero_words * 4 >= skm_onesweep::sort_state_bytes(cap, key_bits);
         if (code_bits == 32)
             SKM_TRY(skm_onesweep::sort_pairs_dev<uint32_t>(ctx, d_nnz, cap, (const uint32_t *)d_codes, (uint32_t *)skeys, sidx,
-                                                            (uint32_t *)ktmp, vtmp, p, key_bits, "onesweep_sort_codes"));
+                                                            (uint32_t *)ktmp, vtmp, p, key_bits, "onesweep_sort_codes", zeroed, zeroed && prepared.hist));
         else
             SKM_TRY(skm_onesweep::sort_pairs_dev<uint64_t>(ctx, d_nnz, cap, (const uint64_t *)d_codes, (uint64_t *)skeys, sidx,
-                                                            (uint64_t *)ktmp, vtmp, p, key_bits, "onesweep_sort_codes"));
+                                                            (uint64_t *)ktmp, vtmp, p, key_bits, "onesweep_sort_codes", zeroed, zeroed && prepared.hist));
     } else {
         // rocPRIM sorts the capacity: entries past the device-side count carry the all-ones sentinel
         // (skm_count_stage_async); they are the last ones of the input and the sort is stable, so positions [0, nnz) of

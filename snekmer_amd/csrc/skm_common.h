@@ -26,6 +26,9 @@
 enum skm_ws_slot {
     WS_A = 0, WS_B, WS_C, WS_D, WS_E, WS_F, WS_G, WS_H, WS_I, WS_J, WS_K, WS_L, WS_ROCPRIM, WS_SMALL, WS_LUT,
     WS_COS,  // counters and partial minima of the cosine stage; zero-filled when (re)allocated (skm_ws)
+    WS_ZERO, // words every user leaves at zero (zero-filled when allocated): the size-class counters of the count stage
+    WS_SCAN, // temporary storage of the count stage's row-pointer scan (its own slot: WS_ROCPRIM may hold sort state
+             // that the count stage's last kernel is clearing for the basis stage)
     WS_COUNT
 };
 
@@ -38,6 +41,7 @@ struct skm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 0;
+    int usable_cus = 0;  // compute units the context's stream may use (num_cus unless skm_create_confined masked some out)
     void *ws[WS_COUNT] = {};
     size_t ws_bytes[WS_COUNT] = {};
     void *h_pinned = nullptr;  // small pinned buffer for count read-backs
@@ -47,6 +51,14 @@ struct skm_ctx {
     uint32_t *d_err = nullptr;
     hipEvent_t ev_host = nullptr;  // marks an asynchronous read-back the host waits for while later kernels run
     bool profiling = false;
+    // stream capture (skm_graph_begin .. skm_graph_end): while set, scratch slots must not grow, nothing may wait for the
+    // device and no timing events are recorded.  ws_generation counts scratch reallocations: a captured graph holds scratch
+    // addresses and is refused (SKM_E_STALE) once one of them has moved.
+    // the count stage's size-class counters (WS_ZERO) are cleared by its last kernel; true while a call is between its
+    // first and last launch, i.e. still true at the next entry if a call failed in between: that entry clears them itself
+    bool count_fill_dirty = false;
+    bool capturing = false;
+    uint64_t ws_generation = 0;
     std::vector<skm_prof_entry> prof;
     std::vector<hipEvent_t> event_pool;
     // cosine stage: streams confined to disjoint CU sets (writer 3/4, sparse Gram 1/4) and the events
@@ -130,9 +142,25 @@ static inline bool skm_use_onesweep(int64_t cap)
 
 // Stage functions shared by the fused entry point skm_vectorize_csr (skm_api.hip would be the natural home; they
 // live with their kernels in skm_kmer.hip / skm_basis.hip).  Neither waits for the device.
+// Work the count stage does for the stage behind it, so that a fused call needs no fill operations (and no histogram pass)
+// of its own: colidx_ff[e] = 0xFFFFFFFF for every entry e the last kernel (k_compact_rows) writes; zero_words 32-bit words
+// cleared at `zero`.
+struct skm_count_extras {
+    uint32_t *colidx_ff = nullptr;
+    uint32_t *zero = nullptr;  // cleared by the stage's FIRST count kernel (nothing in the stage reads it) ...
+    int64_t zero_words = 0;
+    // ... so that the last one can already count into it: the digit histograms of the basis stage's sort (8-bit digits of
+    // the low hist_key_bits bits of every code, layout skm_onesweep::state_header::hist at the start of `zero`)
+    bool hist = false;
+    int hist_passes = 0, hist_key_bits = 0;
+};
 int skm_count_stage_async(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits, const uint8_t *d_seq,
                           const int64_t *d_off, int64_t n, int64_t total_residues, int64_t max_seq_len, int64_t *d_rowptr, void *d_codes,
-                          uint32_t *d_counts, uint64_t *d_rowcount, float *d_rnorm, uint64_t *d_normsq);
+                          uint32_t *d_counts, uint64_t *d_rowcount, float *d_rnorm, uint64_t *d_normsq,
+                          const skm_count_extras &extras = skm_count_extras());
+// prepared: what the count stage already did for this call (colidx pre-filled; `zero` = the sort state it cleared)
 int skm_basis_stage_async(skm_ctx *ctx, int code_bits, int key_bits, int64_t cap, const int64_t *d_nnz, const void *d_codes,
                           const uint64_t *d_rowcount, void *d_basis, uint32_t *d_colidx, uint32_t *d_colptr, uint64_t *d_post,
-                          int64_t *d_ncols);
+                          int64_t *d_ncols, const skm_count_extras &prepared = skm_count_extras());
+int skm_basis_sort_state(skm_ctx *ctx, int64_t cap, int key_bits, int code_bits, uint32_t **out_state, int64_t *out_words,
+                         int *out_passes = nullptr, int *out_key_bits = nullptr);

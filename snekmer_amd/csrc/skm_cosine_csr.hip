@@ -171,6 +171,14 @@ __global__ __launch_bounds__(TB) void k_cosine_strip(const int64_t *__restrict__
     __shared__ int s_skip;
     const int tid = threadIdx.x;
     const uint32_t nlist = strip_list ? *strip_count : 0u;
+    if constexpr (WIDE) {
+        // The float64 launch is the last kernel of a list-path call.  Given (wide_list, wide_count) = (the context's pinned
+        // hint words, the call's per-block hand-off counters) its first workgroup copies the 16 counters to the host:
+        // what a hipMemcpyAsync (one more stream operation per call) did before.  Read without waiting by the next call
+        // (heavy_panels_wanted).
+        if (wide_list && wide_count && blockIdx.x == 0 && tid < 16)
+            __hip_atomic_store(wide_list + tid, wide_count[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     for (int z = tid; z < (int)(R * CH * sizeof(acc_t) / 16); z += TB)
         reinterpret_cast<int4 *>(&s_acc[0][0])[z] = make_int4(0, 0, 0, 0);
     for (uint32_t it = blockIdx.x;; it += gridDim.x) {
@@ -1393,9 +1401,11 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
             fb_count, &state->min_yrnorm, wide_list, &state->wide_count);                                            \
         k_cosine_strip<MODE, VEC, 0, PW, true><<<skm_grid_cap(ctx, strips, 2), TB, 0, st>>>(                         \
             d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, d_ypost, d_ypostcnt, d_yrnorm, row0, row1, d_out, ld,          \
-            wide_list, &state->wide_count, nullptr, nullptr, nullptr);                                               \
+            wide_list, &state->wide_count, nullptr, hint_dst, hint_src);                                             \
     } while (0)
 
+    // (set on the list path: the last kernel of the call then copies the hand-off counters to the pinned hint words)
+    uint32_t *hint_dst = nullptr, *hint_src = nullptr;
     void *p;
     SKM_TRY(skm_ws(ctx, WS_COS, sizeof(cos_state), &p));
     cos_state *state = (cos_state *)p;
@@ -1626,7 +1636,13 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     }
     // how many rows this call handed on (one counter per row block): the next call on this context reads them (without
     // waiting) to decide whether the panel pipeline is worth its dozen launches (heavy_panels_wanted)
-    SKM_HIP(hipMemcpyAsync((uint8_t *)ctx->h_pinned + 2048, over_count, sizeof(uint32_t) * MAXB, hipMemcpyDeviceToHost, st));
+    static_assert(MAXB == 16, "k_cosine_strip<WIDE> copies 16 counters");
+    if (ctx->d_err) {  // pinned memory is device-addressable: the last kernel stores the counters itself
+        hint_dst = ctx->d_err - SKM_DEVERR_WORD + 2048 / 4;
+        hint_src = over_count;
+    } else {
+        SKM_HIP(hipMemcpyAsync((uint8_t *)ctx->h_pinned + 2048, over_count, sizeof(uint32_t) * MAXB, hipMemcpyDeviceToHost, st));
+    }
     {
         // strips with a row still flagged; worst-case grid, surplus workgroups exit at once
         SKM_PROF(ctx, "k_cosine_strip");

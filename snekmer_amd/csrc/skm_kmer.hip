@@ -17,6 +17,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "skm_common.h"
+#include "skm_onesweep.h"
 #include "skm_wave_sort.h"
 
 namespace {
@@ -173,8 +174,17 @@ __global__ __launch_bounds__(64) void k_count_short(skm_lut256 lut, int nsym, in
                                                     const uint32_t *__restrict__ list,
                                                     const uint32_t *__restrict__ nlist_ptr,
                                                     K *__restrict__ tmp_codes, uint32_t *__restrict__ tmp_counts,
-                                                    uint32_t *__restrict__ tmp_first, int32_t *__restrict__ row_nnz)
+                                                    uint32_t *__restrict__ tmp_first, int32_t *__restrict__ row_nnz,
+                                                    uint32_t *__restrict__ zero, int64_t zero_words)
 {
+    if (zero) {  // state of the NEXT stage (skm_count_extras): cleared here, by the widest launch of this one
+        uint4 *z4 = reinterpret_cast<uint4 *>(zero);
+        const int64_t n4 = zero_words >> 2, gthreads = (int64_t)gridDim.x * 64;
+        for (int64_t z = (int64_t)blockIdx.x * 64 + threadIdx.x; z < n4; z += gthreads)
+            z4[z] = make_uint4(0u, 0u, 0u, 0u);
+        for (int64_t z = (n4 << 2) + (int64_t)blockIdx.x * 64 + threadIdx.x; z < zero_words; z += gthreads)
+            zero[z] = 0u;
+    }
     // the list length is read on the device: the launch does not wait for the host to learn it
     const uint32_t nlist = *nlist_ptr;
     __shared__ uint8_t s_lut[256];
@@ -674,11 +684,24 @@ __global__ __launch_bounds__(BLK) void k_compact_rows(const int64_t *__restrict_
                                                       const uint32_t *__restrict__ tmp_first,
                                                       K *__restrict__ codes, uint32_t *__restrict__ counts,
                                                       uint32_t *__restrict__ first, uint64_t *__restrict__ rowcount,
-                                                      float *__restrict__ rnorm, uint64_t *__restrict__ normsq)
+                                                      float *__restrict__ rnorm, uint64_t *__restrict__ normsq,
+                                                      uint32_t *__restrict__ bucket_fill, uint32_t *__restrict__ colidx_ff,
+                                                      uint32_t *__restrict__ hist, int hist_passes, int hist_key_bits)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    // the stage's last kernel: every count kernel has read its list length, so the size-class counters go back to zero
+    // for the next call (no fill operation in front of k_classify); and state the next stage wants cleared
+    if (bucket_fill && blockIdx.x == 0 && threadIdx.x < NBUCKET)
+        bucket_fill[threadIdx.x] = 0u;
+    // digit histograms of the next stage's sort, counted while the codes pass through (skm_count_extras::hist)
+    __shared__ uint32_t s_h[skm_onesweep::MAX_PASSES][skm_onesweep::RADIX];
+    if (hist) {
+        for (int z = threadIdx.x; z < hist_passes * skm_onesweep::RADIX; z += BLK)
+            (&s_h[0][0])[z] = 0u;
+        __syncthreads();
+    }
     for (int64_t i = wave; i < n; i += nwaves) {
         const int64_t src = off[i], dst = rowptr[i];
         const int64_t cnt = rowptr[i + 1] - dst;
@@ -691,6 +714,15 @@ __global__ __launch_bounds__(BLK) void k_compact_rows(const int64_t *__restrict_
                 first[dst + t] = tmp_first[src + t];
             if (rowcount)
                 rowcount[dst + t] = (uint64_t)(uint32_t)i | ((uint64_t)c << 32);
+            if (colidx_ff)
+                colidx_ff[dst + t] = 0xFFFFFFFFu;
+            if (hist) {
+                const K code = tmp_codes[src + t];
+                for (int p = 0; p < hist_passes; ++p) {
+                    const int shift = p * skm_onesweep::RADIX_BITS, bits = min(skm_onesweep::RADIX_BITS, hist_key_bits - shift);
+                    atomicAdd(&s_h[p][(uint32_t)(code >> shift) & ((1u << bits) - 1u)], 1u);
+                }
+            }
             sq += (unsigned long long)c * c;
         }
         if (rnorm || normsq) {
@@ -702,6 +734,14 @@ __global__ __launch_bounds__(BLK) void k_compact_rows(const int64_t *__restrict_
                 if (rnorm)
                     rnorm[i] = sq ? (float)(1.0 / sqrt((double)sq)) : 1.0f;
             }
+        }
+    }
+    if (hist) {
+        __syncthreads();
+        for (int z = threadIdx.x; z < hist_passes * skm_onesweep::RADIX; z += BLK) {
+            const uint32_t c = (&s_h[0][0])[z];
+            if (c)
+                atomicAdd(hist + z, c);
         }
     }
 }
@@ -744,7 +784,7 @@ template <typename K, bool WITH_POS>
 int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const uint8_t *d_seq,
                    const int64_t *d_off, int64_t n, int64_t total_residues, int64_t max_seq_len, int64_t *d_rowptr, K *d_codes,
                    uint32_t *d_counts, uint32_t *d_firstpos, int64_t *h_nnz, uint64_t *d_rowcount = nullptr,
-                   float *d_rnorm = nullptr, uint64_t *d_normsq = nullptr)
+                   float *d_rnorm = nullptr, uint64_t *d_normsq = nullptr, const skm_count_extras &extras = skm_count_extras())
 {
     hipStream_t st = ctx->stream;
     void *p;
@@ -754,7 +794,7 @@ int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const u
     int32_t *row_nnz = (int32_t *)p;
     SKM_TRY(skm_ws(ctx, WS_C, sizeof(uint32_t) * (size_t)n * NBUCKET + 64, &p));
     uint32_t *lists = (uint32_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
+    SKM_TRY(skm_ws(ctx, WS_ZERO, 256, &p));
     uint32_t *fill = (uint32_t *)p;
     SKM_TRY(skm_ws(ctx, WS_D, sizeof(K) * (size_t)(total_residues + 1), &p));
     K *tmp_codes = (K *)p;
@@ -766,7 +806,11 @@ int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const u
         tmp_first = (uint32_t *)p;
     }
 
-    SKM_HIP(hipMemsetAsync(fill, 0, sizeof(uint32_t) * NBUCKET, st));
+    // zero when allocated and put back to zero by every call's last kernel (k_compact_rows); a call that failed between
+    // its first and last launch left the flag set
+    if (ctx->count_fill_dirty)
+        SKM_HIP(hipMemsetAsync(fill, 0, sizeof(uint32_t) * 8, st));
+    ctx->count_fill_dirty = true;
     {
         SKM_PROF(ctx, "k_classify");
         const int64_t max_win = max_seq_len > 0 ? (max_seq_len - k + 1 > 0 ? max_seq_len - k + 1 : 0) : -1;
@@ -791,7 +835,7 @@ int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const u
         SKM_PROF(ctx, "k_count_short");
         int grid = skm_grid_cap(ctx, n, 64);
         k_count_short<K, WITH_POS><<<grid, 64, 0, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + 1 * n, fill + 1,
-                                                         tmp_codes, tmp_counts, tmp_first, row_nnz);
+                                                         tmp_codes, tmp_counts, tmp_first, row_nnz, extras.zero, extras.zero_words);
         SKM_TRY(skm_check_launch("k_count_short"));
     }
     if (!bounded || max_seq_len - k + 1 > SHORT_MAX) {
@@ -860,7 +904,7 @@ int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const u
         auto in = rocprim::make_transform_iterator(row_nnz, to_i64());
         SKM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, in, d_rowptr, (int64_t)0, (size_t)(n + 1),
                                         rocprim::plus<int64_t>(), st));
-        SKM_TRY(skm_ws(ctx, WS_ROCPRIM, tmp_bytes, &p));
+        SKM_TRY(skm_ws(ctx, WS_SCAN, tmp_bytes, &p));
         SKM_PROF(ctx, "rocprim_scan_rowptr");
         SKM_HIP(rocprim::exclusive_scan(p, tmp_bytes, in, d_rowptr, (int64_t)0, (size_t)(n + 1),
                                         rocprim::plus<int64_t>(), st));
@@ -869,9 +913,12 @@ int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const u
         SKM_PROF(ctx, "k_compact_rows");
         int grid = skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16);
         k_compact_rows<K><<<grid, BLK, 0, st>>>(d_off, d_rowptr, n, tmp_codes, tmp_counts, tmp_first, d_codes, d_counts,
-                                                 WITH_POS ? d_firstpos : nullptr, d_rowcount, d_rnorm, d_normsq);
+                                                 WITH_POS ? d_firstpos : nullptr, d_rowcount, d_rnorm, d_normsq, fill,
+                                                 extras.colidx_ff, extras.hist ? extras.zero : nullptr, extras.hist_passes,
+                                                 extras.hist_key_bits);
     }
     SKM_TRY(skm_check_launch("k_compact_rows"));
+    ctx->count_fill_dirty = false;
     if (h_nnz) {
         int64_t *h_n = (int64_t *)ctx->h_pinned;
         SKM_HIP(hipMemcpyAsync(h_n, d_rowptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -984,7 +1031,8 @@ extern "C" int skm_count_csr(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int 
 // compaction pass also emits the posting words and the row norms.
 int skm_count_stage_async(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, int code_bits, const uint8_t *d_seq,
                           const int64_t *d_off, int64_t n, int64_t total_residues, int64_t max_seq_len, int64_t *d_rowptr, void *d_codes,
-                          uint32_t *d_counts, uint64_t *d_rowcount, float *d_rnorm, uint64_t *d_normsq)
+                          uint32_t *d_counts, uint64_t *d_rowcount, float *d_rnorm, uint64_t *d_normsq,
+                          const skm_count_extras &extras)
 {
     skm_lut256 lut;
     SKM_TRY(make_lut(h_rank, &lut));
@@ -993,7 +1041,7 @@ int skm_count_stage_async(skm_ctx *ctx, const uint8_t *h_rank, int nsym, int k, 
         SKM_HIP(hipMemsetAsync(d_codes, 0xFF, (size_t)(code_bits / 8) * (size_t)(total_residues + 1), ctx->stream));
     if (code_bits == 32)
         return count_csr_impl<uint32_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, max_seq_len, d_rowptr, (uint32_t *)d_codes,
-                                               d_counts, nullptr, nullptr, d_rowcount, d_rnorm, d_normsq);
+                                               d_counts, nullptr, nullptr, d_rowcount, d_rnorm, d_normsq, extras);
     return count_csr_impl<uint64_t, false>(ctx, lut, nsym, k, d_seq, d_off, n, total_residues, max_seq_len, d_rowptr, (uint64_t *)d_codes,
-                                           d_counts, nullptr, nullptr, d_rowcount, d_rnorm, d_normsq);
+                                           d_counts, nullptr, nullptr, d_rowcount, d_rnorm, d_normsq, extras);
 }

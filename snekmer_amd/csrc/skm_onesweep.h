@@ -18,6 +18,13 @@
 
 #include "skm_common.h"
 
+#ifndef SKM_OS_LB
+#define SKM_OS_LB 8
+#endif
+#ifndef SKM_OS_SMALL_LOG2
+#define SKM_OS_SMALL_LOG2 22
+#endif
+
 namespace skm_onesweep {
 
 constexpr int RADIX_BITS = 8, RADIX = 1 << RADIX_BITS;
@@ -57,7 +64,7 @@ __global__ __launch_bounds__(TB) void k_histogram(const int64_t *__restrict__ d_
     }
 }
 
-template <typename K, int TB, int IPT, bool FIRST>
+template <typename K, int TB, int IPT, bool FIRST, bool TICKET = true>
 __global__ __launch_bounds__(TB) void k_pass(const int64_t *__restrict__ d_n, const K *__restrict__ kin, K *__restrict__ kout,
                                              const uint32_t *__restrict__ vin, uint32_t *__restrict__ vout, state_header *st,
                                              uint32_t *__restrict__ tile_state, int pass, int key_bits)
@@ -73,12 +80,14 @@ __global__ __launch_bounds__(TB) void k_pass(const int64_t *__restrict__ d_n, co
     const int shift = pass * RADIX_BITS;
     const uint32_t mask = (1u << min(RADIX_BITS, key_bits - shift)) - 1u;
     const int64_t n = *d_n;
-    if (tid == 0)
+    // tiles in arrival order (atomic ticket), so that every tile a look-back waits for is already running; a grid small
+    // enough to be resident as a whole (TICKET false) needs no such order and saves the ticket's round trip
+    if (TICKET && tid == 0)
         s_tile = atomicAdd(&st->ticket[pass], 1u);
     for (int z = tid; z < NW * RADIX; z += TB)
         (&s_whist[0][0])[z] = 0u;
     __syncthreads();
-    const int64_t tile = s_tile;
+    const int64_t tile = TICKET ? s_tile : blockIdx.x;
     const int64_t tile_base = tile * TILE;
     if (tile_base >= n)  // uniform; no earlier tile ever waits for this one
         return;
@@ -94,28 +103,39 @@ __global__ __launch_bounds__(TB) void k_pass(const int64_t *__restrict__ d_n, co
         val[r] = FIRST ? (uint32_t)(tile_base + e) : (valid ? vin[tile_base + e] : 0u);
         dig[r] = valid ? ((uint32_t)(key[r] >> shift) & mask) : 0xFFFFFFFFu;
     }
-    // ranks within the wave, in element order: items r = 0.. in turn, lanes of equal digit found with ballots
+    // ranks within the wave, in element order: items r = 0.. in turn, lanes of equal digit found with ballots.  Three
+    // loops instead of one so that the LDS atomics of the IPT items leave back to back (one wave's atomics execute in issue
+    // order, which is what keeps the sort stable) and are waited for ONCE: in a single loop every item waited for its own
+    // returning atomic before the next item's ballots started - IPT LDS round trips in series, most of a small pass's time.
     const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned long long peers[IPT];
 #pragma unroll
     for (int r = 0; r < IPT; ++r) {
         const bool valid = dig[r] != 0xFFFFFFFFu;
-        unsigned long long peers = __ballot(valid);
+        unsigned long long pm = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < RADIX_BITS; ++b) {
             const bool bit = (dig[r] >> b) & 1u;
             const unsigned long long bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
+            pm &= bit ? bal : ~bal;
         }
-        uint32_t base = 0;
-        if (valid) {
-            const int leader = __ffsll((long long)peers) - 1;
-            if (lane == leader)
-                base = atomicAdd(&s_whist[wid][dig[r]], (uint32_t)__popcll(peers));
-            base = __shfl(base, leader);
-            rank[r] = base + (uint32_t)__popcll(peers & lt);
-        } else {
-            rank[r] = 0;
-        }
+        peers[r] = valid ? pm : 0ull;
+    }
+    // every lane issues the atomic, non-leaders (and invalid lanes, on slot 0) with an addend of 0: no branch around it, so
+    // the IPT instructions are issued in a row; the leader's return value is the counter before its own add whatever the
+    // order in which the lanes of one instruction are applied, because nobody else changes the counter in that instruction
+    uint32_t base[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const bool lead = peers[r] && lane == __ffsll((long long)peers[r]) - 1;
+        base[r] = atomicAdd(&s_whist[wid][peers[r] ? dig[r] : 0u], lead ? (uint32_t)__popcll(peers[r]) : 0u);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (the uses below must not be scheduled between the atomics)
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const int leader = peers[r] ? __ffsll((long long)peers[r]) - 1 : lane;
+        const uint32_t b0 = __shfl(base[r], leader);
+        rank[r] = peers[r] ? b0 + (uint32_t)__popcll(peers[r] & lt) : 0u;
     }
     __syncthreads();
     // per digit: exclusive prefix over the waves, tile count, publication, look-back
@@ -185,18 +205,32 @@ __global__ __launch_bounds__(TB) void k_pass(const int64_t *__restrict__ d_n, co
         }
         uint32_t excl = 0;
         if (tile > 0) {
+            // look-back, LB tiles per round trip: the words of the LB nearest predecessors are loaded together and consumed
+            // nearest first up to the first inclusive prefix or the first unpublished word.  One word per round trip made
+            // a chain of dependent agent-scope loads (each a trip past the XCD's L2) as long as the distance to the nearest
+            // finished tile - with every tile of a small input resident at once, most of a pass's time.
+            constexpr int LB = SKM_OS_LB;
             int64_t t = tile - 1;
-            while (true) {
-                const uint32_t w = __hip_atomic_load(tile_state + (size_t)t * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t status = w >> ST_SHIFT;
-                if (status == 0u) {
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
+            bool done = false;
+            while (!done) {
+                uint32_t w[LB];
+#pragma unroll
+                for (int q = 0; q < LB; ++q)
+                    w[q] = t - q >= 0 ? __hip_atomic_load(tile_state + (size_t)(t - q) * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : (ST_PREFIX << ST_SHIFT);
+                int adv = 0;
+#pragma unroll
+                for (int q = 0; q < LB; ++q) {
+                    const uint32_t status = w[q] >> ST_SHIFT;
+                    if (done || adv != q || status == 0u)
+                        continue;
+                    excl += w[q] & ST_MASK;
+                    ++adv;
+                    done = status == ST_PREFIX;
                 }
-                excl += w & ST_MASK;
-                if (status == ST_PREFIX)
-                    break;
-                --t;
+                t -= adv;
+                if (!done && adv == 0)
+                    __builtin_amdgcn_s_sleep(1);
             }
             __hip_atomic_store(tile_state + (size_t)tile * RADIX + tid, (ST_PREFIX << ST_SHIFT) | (excl + tile_cnt), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -230,25 +264,34 @@ static inline size_t state_bytes(int64_t cap, int tile, int passes)
     return sizeof(state_header) + sizeof(uint32_t) * (size_t)ntiles * RADIX * (size_t)passes;
 }
 
+// what sort_pairs_dev clears (or wants cleared) at d_state for `cap` keys
+static inline size_t sort_state_bytes(int64_t cap, int key_bits)
+{
+    const int passes = (key_bits + RADIX_BITS - 1) / RADIX_BITS;
+    return state_bytes(cap, cap <= ((int64_t)1 << SKM_OS_SMALL_LOG2) ? 256 * 8 : 1024 * 8, passes);
+}
+
 // Stable sort of the first *d_n (<= cap < 2^30) keys of `kin` with payload = index; result in kout / vout.  ktmp / vtmp:
 // scratch of cap elements each; d_state: state_bytes().  Nothing waits for the device.
 template <typename K>
 static int sort_pairs_dev(skm_ctx *ctx, const int64_t *d_n, int64_t cap, const K *kin, K *kout, uint32_t *vout, K *ktmp,
-                          uint32_t *vtmp, void *d_state, int key_bits, const char *label)
+                          uint32_t *vtmp, void *d_state, int key_bits, const char *label, bool state_is_zero = false,
+                          bool hist_ready = false)
 {
     hipStream_t s = ctx->stream;
     const int passes = (key_bits + RADIX_BITS - 1) / RADIX_BITS;
     SKM_REQUIRE(passes >= 1 && passes <= MAX_PASSES && cap < ((int64_t)1 << 30), SKM_E_BADARG, "onesweep: bad size");
     // small inputs: 256-thread tiles of 2048 keys (more tiles in flight: the passes are latency-bound there);
     // large ones: 1024 x 8 (the shape rocPRIM's tuning also prefers on this chip)
-    const bool small = cap <= ((int64_t)1 << 22);
+    const bool small = cap <= ((int64_t)1 << SKM_OS_SMALL_LOG2);
     const int tile = small ? 256 * 8 : 1024 * 8;
     const int64_t ntiles = (cap + tile - 1) / tile + 1;
     state_header *st = (state_header *)d_state;
     uint32_t *tile_state = (uint32_t *)((uint8_t *)d_state + sizeof(state_header));
     SKM_PROF(ctx, label);
-    SKM_HIP(hipMemsetAsync(d_state, 0, state_bytes(cap, tile, passes), s));
-    {
+    if (!state_is_zero)  // (a fused call has the previous stage's last kernel clear it: sort_state_bytes() words from d_state)
+        SKM_HIP(hipMemsetAsync(d_state, 0, state_bytes(cap, tile, passes), s));
+    if (!hist_ready) {  // (a fused call: the previous stage's last kernel counted the digits while it wrote the keys)
         const int grid = skm_grid_cap(ctx, skm_ceil_div(cap, 256 * 16), 4);
         k_histogram<K, 256><<<grid, 256, 0, s>>>(d_n, kin, passes, key_bits, st);
     }
@@ -262,7 +305,17 @@ static int sort_pairs_dev(skm_ctx *ctx, const int64_t *d_n, int64_t cap, const K
         uint32_t *ts = tile_state + (size_t)p * (size_t)ntiles * RADIX;
 #define SKM_OS_PASS(TB, FIRST)                                                                                        \
     k_pass<K, TB, 8, FIRST><<<(unsigned)(ntiles - 1), TB, 0, s>>>(d_n, src_k, dst_k, src_v, dst_v, st, ts, p, key_bits)
-        if (small) {
+#define SKM_OS_PASS_NT(TB, FIRST)                                                                                     \
+    k_pass<K, TB, 8, FIRST, false><<<(unsigned)(ntiles - 1), TB, 0, s>>>(d_n, src_k, dst_k, src_v, dst_v, st, ts, p, key_bits)
+        // two 256-thread workgroups of this kernel (26-34 KB of LDS, < 64 registers) fit every CU beside anything else the
+        // library runs on the stream's context: up to 2 per CU the whole grid is resident and tile = blockIdx.x is safe
+        const bool resident = small && ntiles - 1 <= 2 * (int64_t)ctx->usable_cus;
+        if (resident) {
+            if (p == 0)
+                SKM_OS_PASS_NT(256, true);
+            else
+                SKM_OS_PASS_NT(256, false);
+        } else if (small) {
             if (p == 0)
                 SKM_OS_PASS(256, true);
             else
@@ -274,6 +327,7 @@ static int sort_pairs_dev(skm_ctx *ctx, const int64_t *d_n, int64_t cap, const K
                 SKM_OS_PASS(1024, false);
         }
 #undef SKM_OS_PASS
+#undef SKM_OS_PASS_NT
         src_k = dst_k;
         src_v = dst_v;
     }

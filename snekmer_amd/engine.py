@@ -610,7 +610,7 @@ class Pipeline:
     """
 
     def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int, post32: bool = False, fused: bool = True,
-                 dense_route="auto"):
+                 dense_route="auto", graphs=False):
         self.ctx, self.lut, self.k = ctx, lut, k
         self.fused = fused  # skm_vectorize_csr (one call, no result read back) instead of the three-call form
         # 4-byte posting words (batches under 2^24 sequences): half the posting bytes, but measured SLOWER
@@ -626,6 +626,14 @@ class Pipeline:
         self.out = None
         self._dense = self._irr_list = self._irr_count = None
         self._dense_valid = False
+        # HIP-graph replay of whole steps (skm_graph_*): "auto" = batches of at most GRAPH_AUTO_RESIDUES residues, whose step is
+        # a few dozen launches of microseconds each (the reference's job size: one FASTA file per job,
+        # snekmer/rules/kmerize.smk:57-65); True = any size; False (default) = never.  Opt-in because it buys nothing on
+        # the host it was measured on: a 1 000-sequence step is 24 dispatches of >= 5 us each ON THE DEVICE (0.164 ms eager,
+        # 0.172 ms replayed); the host's launches were already hidden behind them.  It pays on a slower or busier host.  See `step`.
+        self.graphs = graphs
+        self._graphs = {}
+        self.graph_replays = 0
 
     @property
     def basis(self) -> Optional[Basis]:
@@ -715,7 +723,7 @@ class Pipeline:
         """Rows the last dense-route step recomputed exactly (a count above 127); reads one word back."""
         return int(self._irr_count.download(1)[0]) if self._dense_valid else 0
 
-    def step(self, batch: SeqBatch):
+    def _step_eager(self, batch: SeqBatch):
         if self.wants_dense(batch):
             self.csr, self.rnorm = vectorize_counts(self.ctx, batch, self.lut, self.k, csr=self.csr, rnorm=self.rnorm)
             self.csr.colidx = None
@@ -723,6 +731,125 @@ class Pipeline:
             return self.cosine()
         self.vectorize(batch)
         return self.cosine()
+
+    # ---- whole steps as HIP graphs
+    GRAPH_AUTO_RESIDUES = 1 << 23  # "auto": up to ~28 k sequences of 300 aa; above, the launches are a percent of the step
+    GRAPH_ENV = ("SKM_COSINE_PATH", "SKM_HEAVY_PANEL", "SKM_COSINE_OVERLAP", "SKM_SORT", "SKM_DENSE_VARIANT", "SKM_OVERLAP_BLOCKS",
+                 "SKM_GRAM_SHAPE")  # host-side switches between exact kernels: a capture freezes them, so they are part of its key
+    GRAPH_SLOTS = 8
+
+    def _graph_key(self, batch: SeqBatch):
+        import os
+
+        if self.graphs is False or getattr(self.ctx, "profiling", False) or batch.ctx is not self.ctx:
+            return None
+        if not self.fused or self.post32 or batch.n < 1 or batch.total < 1 or batch.max_len < 1:
+            return None  # (those forms wait for the device inside the step)
+        if self.graphs == "auto" and batch.total > self.GRAPH_AUTO_RESIDUES:
+            return None
+        return (batch.d_seq.ptr, batch.d_seq.nbytes, batch.d_off.ptr, batch.n, batch.total, batch.max_len,
+                tuple(os.environ.get(v) for v in self.GRAPH_ENV), self.dense_route)
+
+    def _signature(self):
+        """(address, bytes) of every buffer the kernels of the last step touched besides the batch and the context's scratch:
+        a captured step may be replayed only while these are what the pipeline still holds."""
+        csr = self.csr
+        if csr is None or self.out is None or self.rnorm is None:
+            return None
+        bufs = [csr.rowptr, csr.codes, csr.counts, self.rnorm, self.out]
+        if self.route == "dense":
+            bufs += [self._dense, self._irr_list, self._irr_count]
+        else:
+            b = self._basis
+            if b is None:
+                return None
+            bufs += [csr.colidx, b.codes, b.colptr, b.post, b.d_ncols]
+        if any(x is None for x in bufs):
+            return None
+        return (self.route,) + tuple((x.ptr, x.nbytes) for x in bufs)
+
+    def step(self, batch: SeqBatch):
+        """vectorize + cosine of one batch.  A step whose batch (same device buffers, same shape) has been seen before is
+        replayed as ONE HIP graph: the first sight runs eagerly (it also sizes every buffer and the context's scratch), the
+        second is captured (skm_graph_begin .. skm_graph_end record the same library calls instead of running them) and
+        launched, later ones are one launch each.  A replay runs the same kernels on the same buffers and reads whatever the
+        batch's buffers hold now.  It is only used while the pipeline still holds exactly the buffers the capture saw
+        (`_signature`), the library's scratch has not moved (SKM_E_STALE) and per-kernel timing is off; anything else runs
+        eagerly.  Results are the eager step's bit for bit (tests/test_gpu_parity.py)."""
+        key = self._graph_key(batch)
+        if key is None:
+            return self._step_eager(batch)
+        ent = self._graphs.get(key)
+        if ent is not None and ent["graph"] is not None and ent["sig"] is not None and ent["sig"] == self._signature_for(ent):
+            try:
+                ent["graph"].launch()
+            except _hip.HipError as err:
+                if err.code != -7:  # not SKM_E_STALE
+                    raise
+                ent["graph"].close()
+                ent["graph"] = None
+            else:
+                self._restore(ent)
+                self.graph_replays += 1
+                return self.out
+        if ent is None:
+            out = self._step_eager(batch)
+            while len(self._graphs) >= self.GRAPH_SLOTS:
+                old = self._graphs.pop(next(iter(self._graphs)))
+                if old["graph"] is not None:
+                    old["graph"].close()
+            self._graphs[key] = {"graph": None, "sig": self._signature(), "state": self._state()}
+            return out
+        if ent["graph"] is None and ent["sig"] is not None and ent["sig"] == self._signature_for(ent):
+            # second sight, nothing reallocated since the eager run: record the same calls, then launch the recording
+            self.ctx.graph_begin()
+            try:
+                out = self._step_eager(batch)
+            except Exception:
+                try:
+                    self.ctx.graph_end().close()
+                except _hip.HipError:
+                    pass
+                del self._graphs[key]
+                raise
+            graph = self.ctx.graph_end()
+            if self._signature() != ent["sig"]:  # a buffer was replaced inside the capture: the recording is of the new ones
+                ent["sig"] = self._signature()
+            ent["graph"], ent["state"] = graph, self._state()
+            graph.launch()
+            self.graph_replays += 1
+            return out
+        out = self._step_eager(batch)  # buffers changed since this shape was last seen: start over
+        if ent["graph"] is not None:
+            ent["graph"].close()
+        ent.update(graph=None, sig=self._signature(), state=self._state())
+        return out
+
+    def _state(self):
+        return (self.route, self._basis_stale, self._dense_valid, self.csr.n, self.csr.elided)
+
+    def _signature_for(self, ent):
+        """The signature the pipeline's CURRENT buffers would give for the route the entry's step took."""
+        route, self.route = self.route, ent["state"][0]
+        try:
+            return self._signature()
+        finally:
+            self.route = route
+
+    def _restore(self, ent):
+        """Host-side state after a replay: what `_step_eager` leaves behind (sizes that live on the device are fetched lazily)."""
+        self.route, self._basis_stale, self._dense_valid, self.csr.n, self.csr.elided = ent["state"]
+        self.csr.nnz = None
+        if self.route == "dense":
+            self.csr.colidx = None
+        elif self._basis is not None:
+            self._basis.ncols = None
+
+    def drop_graphs(self):
+        for ent in self._graphs.values():
+            if ent["graph"] is not None:
+                ent["graph"].close()
+        self._graphs.clear()
 
 
 class OverlappedPipeline:

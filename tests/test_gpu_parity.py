@@ -215,8 +215,8 @@ def test_vectorize_fasta_writes_reference_formats(ctx, tmp_path):
     assert list(df.columns) == ["filename", "sequence_id", "sequence", "sequence_length", "sequence_vector"]
     n = len(df)
     assert list(df["sequence_id"]) == list(g["ids"][:n]) and list(df["sequence"]) == list(g["seqs"][:n])
-    with open(kmers, "rb") as f:
-        kv = pickle.load(f)
+    kv = skm.io.load_pickle(kmers)  # the file names snekmer.vectorize.KmerVec (what Snekmer's consumers unpickle)
+    assert b"snekmer.vectorize" in open(kmers, "rb").read() and type(kv) is skm.vectorize.KmerVec
     assert sorted(kv.__dict__) == sorted(gjson("g6_basis.json")["kmervec_attrs"])
     assert list(kv.kmer_set.kmers) == list(kmerlist)
     # sparse variant of the same file: CSR counts instead of the dense presence matrix
@@ -1309,6 +1309,75 @@ def test_overlapped_pipeline_equals_pipeline_on_a_stream_of_batches(ctx):
             split.sync()
             got = out.download().reshape(out.shape)[: b.n, : b.n]
             assert (got == want[i]).all(), (fraction, i)
+
+
+@pytest.mark.parametrize("name,k,n", [("red6", 12, 1000), ("standard", 12, 700), ("solvacc", 8, 1500)])
+def test_pipeline_step_replayed_as_a_hip_graph_equals_the_eager_step(ctx, name, k, n):
+    """engine.Pipeline.step replays a step it has seen before as ONE HIP graph (skm_graph_begin / end / launch): sparse route
+    with 32- and 64-bit codes, dense route (int8 GEMM + exact fix-up rows).  Every replay must equal the eager step bit for
+    bit - also after the batch's device buffers were overwritten with other sequences of the same shape (a replay reads what
+    the buffers hold now), after the pipeline lost a buffer (signature mismatch: eager, then a new capture) and after a
+    larger batch moved the context's scratch (SKM_E_STALE: eager, then a new capture)."""
+    from snekmer_amd import _hip
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+
+    lut = A.build_lut(name)
+    own = _hip.Context(ctx.device)  # its own scratch: the test watches it move
+    res, off, _ = synth_families(n, 300, family=25, seed=900 + n)
+    rng = np.random.default_rng(n)  # other sequences of the same lengths: a fifth of the residues replaced
+    hit = (rng.random(res.size) < 0.2) & (res != ord("*"))
+    res2 = np.where(hit, np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)[rng.integers(0, 20, res.size)], res)
+    assert res2.size == res.size and not (res2 == res).all()
+    if name == "solvacc":  # a row with counts above 127: the dense route's exact fix-up runs inside the graph too
+        res = res.copy()
+        res[off[3]:off[3] + 290] = ord("A")
+    batch = engine.SeqBatch(own, res, off)
+    eager = engine.Pipeline(own, lut, k, graphs=False)
+    want = eager.step(batch)
+    want = want.download().reshape(want.shape).copy()
+    w_rowptr, w_codes, w_counts, _ = eager.csr.host()
+    pipe = engine.Pipeline(own, lut, k, graphs="auto")
+    for i in range(5):
+        out = pipe.step(batch)
+        assert (out.download().reshape(out.shape) == want).all(), i
+        rowptr, codes, counts, _ = pipe.csr.host()
+        assert (rowptr == w_rowptr).all() and (codes == w_codes).all() and (counts == w_counts).all()
+        assert pipe.route == eager.route and pipe.basis.ncols == eager.basis.ncols
+    assert pipe.graph_replays == 4  # eager, capture + launch, three launches
+    if pipe.route == "dense":
+        assert pipe.irregular_rows() >= 1
+    # other sequences in the same buffers
+    own._h2d(batch.d_seq.ptr, res2)
+    want2 = eager.step(batch)
+    want2 = want2.download().reshape(want2.shape).copy()
+    assert not (want2 == want).all()
+    out = pipe.step(batch)
+    assert pipe.graph_replays == 5 and (out.download().reshape(out.shape) == want2).all()
+    assert pipe.csr.nnz == eager.csr.nnz and pipe.basis.ncols == eager.basis.ncols
+    # the pipeline loses its result buffer: no replay into freed memory
+    pipe.out = None
+    for i in range(3):
+        out = pipe.step(batch)
+        assert (out.download().reshape(out.shape) == want2).all()
+    assert pipe.graph_replays == 7  # eager (new buffer), capture + launch, launch
+    # a larger batch moves the context's scratch: the old capture is refused and made again
+    big = engine.SeqBatch(own, *synth_families(3 * n, 300, family=25, seed=77)[:2])
+    engine.Pipeline(own, lut, k, graphs=False).step(big)
+    for i in range(3):
+        out = pipe.step(batch)
+        assert (out.download().reshape(out.shape)[:n, :n] == want2[:n, :n]).all()
+    assert pipe.graph_replays >= 8
+    # per-kernel timing on: eager, and the events are there
+    own.profile_enable(True)
+    own.profile_reset()
+    before = pipe.graph_replays
+    pipe.step(batch)
+    assert pipe.graph_replays == before and len(own.profile_dump()) >= 5
+    own.profile_enable(False)
+    pipe.drop_graphs()
+    own.close()
 
 
 def test_confined_context_is_an_ordinary_context_on_fewer_compute_units(ctx):

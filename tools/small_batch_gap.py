@@ -15,14 +15,18 @@ def measure(ctx, lut, k, res, off, reps=200, pipeline=None):
 
     batch = engine.SeqBatch(ctx, res, off)
     p = (pipeline or engine.Pipeline)(ctx, lut, k)
-    for _ in range(5):
-        p.step(batch)
-    ctx.sync()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        p.step(batch)
-    ctx.sync()
-    wall = (time.perf_counter() - t0) / reps * 1e3
+    walls = {}
+    for mode in (False, "auto"):  # eager launches, then whole-step HIP-graph replay (the default)
+        p.graphs = mode
+        for _ in range(5):
+            p.step(batch)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            p.step(batch)
+        ctx.sync()
+        walls[mode] = (time.perf_counter() - t0) / reps * 1e3
+    wall = walls[False]
     ctx.profile_enable(True)
     ctx.profile_reset()
     for _ in range(50):
@@ -32,7 +36,7 @@ def measure(ctx, lut, k, res, off, reps=200, pipeline=None):
     n = batch.n
     ld = (n + 3) // 4 * 4
     floor_ms = 4.0 * n * ld / 8e12 * 1e3
-    return {"n": n, "wall_ms_per_step": wall, "kernel_sum_ms": sum(v[1] for v in prof.values()) / 50,
+    return {"n": n, "wall_ms_per_step": wall, "wall_ms_per_step_graph_replay": walls["auto"], "graph_replays": p.graph_replays, "kernel_sum_ms": sum(v[1] for v in prof.values()) / 50,
             "launches_per_step": sum(v[0] for v in prof.values()) / 50, "hbm_floor_ms": floor_ms, "frac": floor_ms / wall,
             "stages": {kk: round(v[1] / 50, 4) for kk, v in prof.items()}}
 
