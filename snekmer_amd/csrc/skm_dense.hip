@@ -702,20 +702,32 @@ __global__ __launch_bounds__(256) void k_retile_b_i8(int64_t rows, int64_t kdim,
     }
 }
 
-template <int MODE, bool SYM, int DA = 3>
+// SPLIT (small problems: fewer tiles than compute units): the K stages of a tile are shared by `nsplit` workgroups
+// (grid = tile slots x nsplit, split-major; `sps` stages each, a multiple of 4).  Every workgroup of a tile stores its int32
+// partial tile to its slab (the accumulator registers as they stand: 1 KiB per wave instruction), takes a ticket, and the
+// LAST to arrive adds the others' slabs to its own registers and runs the epilogue (no workgroup ever waits for another:
+// any grid size is safe).  Hand-off per MI355X_MICROARCH.md / G16: stores drained, workgroup barrier, one lane's agent-scope
+// acq_rel ticket (release of the slab, acquire of the others'), barrier, plain loads.  The last arriver puts the ticket
+// back to zero for the next launch.
+template <int MODE, bool SYM, int DA = 3, bool SPLIT = false>
 __global__ __launch_bounds__(512) void k_cosine_dense_i8_v5(int64_t n, int64_t m, int64_t kdim,
                                                             const int8_t *__restrict__ X,   // A image (k_retile_i8)
                                                             const int8_t *__restrict__ YB,  // B image (k_retile_b_i8)
                                                             const float *__restrict__ xr,
                                                             const float *__restrict__ yr, float *__restrict__ out,
-                                                            int64_t ld)
+                                                            int64_t ld, int nsplit = 1, int64_t sps = 0,
+                                                            int32_t *__restrict__ slabs = nullptr,
+                                                            uint32_t *__restrict__ tickets = nullptr)
 {
     __shared__ __attribute__((aligned(16))) int8_t s_t[NSLOT5 * SLOT5_BYTES];  // the ONLY shared object (128 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t nty = (n + BM3 - 1) / BM3, ntx = (m + BN3 - 1) / BN3;
     const int64_t nsx = (ntx + 7) / 8;
-    const int64_t nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
-    const int64_t seq = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+    const int64_t nwg = SPLIT ? gridDim.x / nsplit : gridDim.x;  // tile slots (a multiple of 32)
+    const int64_t bid = SPLIT ? blockIdx.x % nwg : blockIdx.x;
+    const int split = SPLIT ? (int)(blockIdx.x / nwg) : 0;
+    const int64_t q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+    const int64_t seq = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
     int64_t st = seq / 32;
     const int64_t within = seq % 32;
     int64_t sy, sx;
@@ -744,7 +756,10 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v5(int64_t n, int64_t m
         for (int r = 0; r < 16; ++r)
             acc[a][r] = 0;
 
-    const int64_t nst = kdim / BK4;  // a multiple of 4 (the launcher's condition)
+    const int64_t nst_all = kdim / BK4;  // a multiple of 4 (the launcher's condition)
+    // this workgroup's K stages [s_lo, nst): both ends multiples of 4 (the launcher makes every split non-empty)
+    const int64_t s_lo = SPLIT ? (int64_t)split * sps : 0;
+    const int64_t nst = SPLIT ? min(nst_all, s_lo + sps) : nst_all;
     const int64_t nrbx = nty * (BM3 / 16);
     // A staging: wave w lands rows [32 w, 32 w + 32) of the stage, two instructions of 16 rows x 64 B
     auto stage_a = [&](int64_t slot_of, int64_t sidx, int q) {  // stage sidx into the slot of stage slot_of
@@ -763,15 +778,15 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v5(int64_t n, int64_t m
     };
 #pragma unroll
     for (int s0 = 0; s0 < DA; ++s0) {
-        stage_a(s0, s0, 0);
-        stage_a(s0, s0, 1);
+        stage_a(s_lo + s0, s_lo + s0, 0);
+        stage_a(s_lo + s0, s_lo + s0, 1);
     }
-    load_b(std::integral_constant<int, 0>{}, 0, 0);
-    load_b(std::integral_constant<int, 0>{}, 0, 1);
-    load_b(std::integral_constant<int, 1>{}, 1, 0);
-    load_b(std::integral_constant<int, 1>{}, 1, 1);
-    load_b(std::integral_constant<int, 2>{}, 2, 0);
-    load_b(std::integral_constant<int, 2>{}, 2, 1);
+    load_b(std::integral_constant<int, 0>{}, s_lo + 0, 0);
+    load_b(std::integral_constant<int, 0>{}, s_lo + 0, 1);
+    load_b(std::integral_constant<int, 1>{}, s_lo + 1, 0);
+    load_b(std::integral_constant<int, 1>{}, s_lo + 1, 1);
+    load_b(std::integral_constant<int, 2>{}, s_lo + 2, 0);
+    load_b(std::integral_constant<int, 2>{}, s_lo + 2, 1);
     // builtin waits (0x0F70 = vmcnt(0), 0x0F78 = vmcnt(8); the other counters untouched), not asm: the compiler's own
     // wait-count model must see them, or it waits for everything before the first MFMA of a stage
     __builtin_amdgcn_s_waitcnt(0x0F70);  // once per tile
@@ -817,7 +832,7 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v5(int64_t n, int64_t m
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     };
-    for (int64_t s = 0; s < nst; s += 4) {
+    for (int64_t s = s_lo; s < nst; s += 4) {
         body(std::integral_constant<int, 0>{}, s);
         body(std::integral_constant<int, 1>{}, s + 1);
         body(std::integral_constant<int, 2>{}, s + 2);
@@ -828,15 +843,86 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v5(int64_t n, int64_t m
     __builtin_amdgcn_s_waitcnt(0x0F70);  // the dead re-fetches have landed before the epilogue reuses the LDS
     __builtin_amdgcn_s_barrier();
 
-    // epilogue (as v4's, for this wave's 8 sub-tiles of 32 x 32)
+    if (SPLIT) {
+        // Hand-off.  A workgroup takes the tile's ticket as soon as its K stages are done.  Not the last one: it stores its
+        // partial tile to its slab ([wave][a][q][lane] int4 = this lane's registers 4q .. 4q+3 of sub-tile a: 1 KiB per
+        // wave instruction), drains the stores and counts itself in `done`.  The last one keeps its registers, waits until
+        // `done` shows every other slab complete - it only ever waits for workgroups that hold a ticket, i.e. that are
+        // running and wait for nobody: no residency assumption - adds them and runs the epilogue.  The slab bytes travel
+        // with write-through (sc1) stores and sc1 loads instead of a release / acquire pair: those write back / invalidate
+        // the XCD's whole L2, which at this point holds the other workgroups' freshly stored output tiles.
+        constexpr int64_t SLAB = (int64_t)BM3 * BN3;  // int32 words
+        uint32_t *s_ticket = reinterpret_cast<uint32_t *>(s_t);
+        if (tid == 0)
+            *s_ticket = __hip_atomic_fetch_add(tickets + 2 * bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const uint32_t arrived = *s_ticket;
+        __syncthreads();  // (the epilogue reuses the LDS)
+        if (arrived != (uint32_t)nsplit - 1u) {
+            i32x4 *mine = reinterpret_cast<i32x4 *>(slabs + (bid * (nsplit - 1) + arrived) * SLAB) + (wid * 32) * 64 + lane;
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    i32x4 v;
+                    v[0] = acc[a][4 * q];
+                    v[1] = acc[a][4 * q + 1];
+                    v[2] = acc[a][4 * q + 2];
+                    v[3] = acc[a][4 * q + 3];
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + (a * 4 + q) * 64), "v"(v) : "memory");
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores ...
+            __syncthreads();                                   // ... before one lane reports the slab complete
+            if (tid == 0)
+                __hip_atomic_fetch_add(tickets + 2 * bid + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) {
+            while (__hip_atomic_load(tickets + 2 * bid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (uint32_t)nsplit - 1u)
+                __builtin_amdgcn_s_sleep(2);
+            // both counters back to zero for the next launch: every workgroup of this tile is past its last atomic
+            __hip_atomic_store(tickets + 2 * bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tickets + 2 * bid + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        for (int o = 0; o + 1 < nsplit; ++o) {
+            const i32x4 *theirs = reinterpret_cast<const i32x4 *>(slabs + (bid * (nsplit - 1) + o) * SLAB) + (wid * 32) * 64 + lane;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // 16 loads of 1 KiB in flight per wave (the operand registers of the K loop are free)
+                i32x4 v[16];
+#pragma unroll
+                for (int z = 0; z < 16; ++z)
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[z]) : "v"(theirs + (h * 16 + z) * 64) : "memory");
+                // (the loaded registers are operands of the wait, so that no use of them can be scheduled above it)
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                               "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])::"memory");
+#pragma unroll
+                for (int z = 0; z < 16; ++z) {
+                    const int a = (h * 16 + z) >> 2, q = (h * 16 + z) & 3;
+                    acc[a][4 * q] += v[z][0];
+                    acc[a][4 * q + 1] += v[z][1];
+                    acc[a][4 * q + 2] += v[z][2];
+                    acc[a][4 * q + 3] += v[z][3];
+                }
+            }
+        }
+    }
+
+    // epilogue for this wave's 8 sub-tiles of 32 x 32.  A lane holds one COLUMN of a sub-tile (16 rows of it), so storing
+    // the registers as they stand is 16 dword stores per sub-tile (two 128-byte row pieces per instruction) and the
+    // epilogue was store-ISSUE-bound: ~35 us per tile, a fifth of a large launch's time per tile and most of a small
+    // launch's.  Both images now go through LDS (free after the K loop; 2 x 4.5 KiB per wave) and leave as 16-byte
+    // stores, 1 KiB per instruction: the tile itself row-major (8 rows x 128 B per instruction), its mirror transposed.
     const int ccol = lane & 31, chalf = lane >> 5;
     const bool mirror = SYM && ty < tx;
-    constexpr int TROW = 36;
-    float *tbuf = reinterpret_cast<float *>(s_t) + wid * (32 * TROW);
+    constexpr int TROW = 36;  // floats per buffered row: 16-byte aligned, spreads the banks
+    float *tdir = reinterpret_cast<float *>(s_t) + wid * (2 * 32 * TROW), *tmir = tdir + 32 * TROW;
     const bool vec_ok = (ld & 3) == 0 && ((uintptr_t)out & 15) == 0;
     const int64_t jbase = col0 + wid * 32;
     const int64_t j = jbase + ccol;
     const float rj = j < m ? yr[j] : 0.0f;
+    const int prow = lane >> 3, pc4 = (lane & 7) * 4;  // a 16-byte store: row 8 * pass + prow, columns pc4 .. pc4 + 3
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
         const int64_t ibase = row0 + a * 32;
@@ -855,19 +941,38 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v5(int64_t n, int64_t m
                         if (i == j)
                             v = 0.0f;
                     }
-                    out[i * ld + j] = v;
                 }
                 o[u] = v;
+                tdir[(li + u) * TROW + ccol] = v;
             }
             if (mirror)
-                *reinterpret_cast<float4 *>(tbuf + ccol * TROW + li) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4 *>(tmir + ccol * TROW + li) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        // (one wave: its LDS operations complete in order, no barrier needed between the writes above and these reads)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 8 + prow;
+            const float4 v = *reinterpret_cast<const float4 *>(tdir + r * TROW + pc4);
+            const int64_t ii = ibase + r, jj = jbase + pc4;
+            if (ii < n) {
+                float *dst = out + ii * ld + jj;
+                if (vec_ok && jj + 3 < m) {
+                    *reinterpret_cast<float4 *>(dst) = v;
+                } else {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (jj + u < m)
+                            dst[u] = e[u];
+                }
+            }
         }
         if (mirror) {
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
-                const int c = pass * 8 + (lane >> 3), i4 = (lane & 7) * 4;
-                const float4 v = *reinterpret_cast<const float4 *>(tbuf + c * TROW + i4);
-                const int64_t jj = jbase + c, ii = ibase + i4;
+                const int c = pass * 8 + prow;
+                const float4 v = *reinterpret_cast<const float4 *>(tmir + c * TROW + pc4);
+                const int64_t jj = jbase + c, ii = ibase + pc4;
                 if (jj < m) {
                     float *dst = out + jj * ld + ii;
                     if (vec_ok && ii + 3 < n) {
@@ -1161,6 +1266,57 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
             k_retile_i8<<<skm_grid_cap(ctx, skm_ceil_div(nrbx * 16 * kdim / 16, 256), 8), 256, 0, ctx->stream>>>(n, kdim, d_x, nrbx, xt);
             k_retile_b_i8<<<skm_grid_cap(ctx, skm_ceil_div(ncb * 32 * kdim / 16, 256), 8), 256, 0, ctx->stream>>>(m, kdim, d_y, ncb, ybt);
             SKM_TRY(skm_check_launch("k_retile_i8"));
+            // Far fewer real tiles than compute units (the reference's own job size: one FASTA file of up to a few thousand
+            // records, snekmer/rules/kmerize.smk:57-65): the K loop of a tile is shared by 2-4 workgroups while tiles x
+            // splits fill at most HALF of the chip.  Measured (tools/bench_dense_small.py, K = 6656): N = 1500 (21 tiles)
+            // 0.099 -> 0.069 ms with 4 splits; N = 3383 (105 tiles: the CI proteome) 0.109 -> 0.119 with 2, N = 8000 0.307 ->
+            // 0.329: from ~100 tiles on the launch is bound by what all tiles share (75 % L2 hits, waves waiting half of
+            // their cycles on operands from beyond L2), and more workgroups per tile only add the slab traffic.
+            const int64_t nty5 = skm_ceil_div(n, BM3), ntx5 = skm_ceil_div(m, BN3);
+            const int64_t real_tiles = sym ? nty5 * (nty5 + 1) / 2 : nty5 * ntx5;
+            const int64_t nst5 = kdim / BK4;
+            int nsplit = 1;
+            int64_t sps = nst5;
+            for (int cand = 4; cand >= 2 && nsplit == 1; --cand) {
+                const int64_t per = skm_ceil_div(skm_ceil_div(nst5, cand), 4) * 4;  // stages per split: a multiple of 4
+                if (real_tiles * cand <= (int64_t)ctx->usable_cus / 2 && per >= 8 && skm_ceil_div(nst5, per) == cand) {
+                    nsplit = cand;
+                    sps = per;
+                }
+            }
+#ifdef SKM_DIAG
+            if (const char *fs = getenv("SKM_DENSE_SPLIT")) {  // A/B timing: force the split count (1 = off)
+                const int cand = atoi(fs);
+                const int64_t per = skm_ceil_div(skm_ceil_div(nst5, cand > 0 ? cand : 1), 4) * 4;
+                if (cand >= 1 && cand <= 8 && per >= 4 && skm_ceil_div(nst5, per) == cand) {
+                    nsplit = cand;
+                    sps = per;
+                }
+            }
+#endif
+            if (nsplit > 1) {
+                const int64_t slots = supertiles * 32;
+                SKM_TRY(skm_ws(ctx, WS_J, sizeof(int32_t) * (size_t)slots * (size_t)(nsplit - 1) * BM3 * BN3, &p));
+                int32_t *slabs = (int32_t *)p;
+                SKM_TRY(skm_ws(ctx, WS_ZERO, 256 + sizeof(uint32_t) * 2 * (size_t)slots, &p));  // (ticket, done) per slot: left at zero by every launch
+                uint32_t *tickets = (uint32_t *)p + 64;
+                dim3 grid5((unsigned)(slots * nsplit));
+#define SKM_V5S(MODE, SYM) \
+    k_cosine_dense_i8_v5<MODE, SYM, 3, true><<<grid5, 512, 0, ctx->stream>>>(n, m, kdim, xt, ybt, d_xrnorm, d_yrnorm, d_out, ld, nsplit, sps, slabs, tickets)
+                if (mode == 0) {
+                    if (sym)
+                        SKM_V5S(0, true);
+                    else
+                        SKM_V5S(0, false);
+                } else {
+                    if (sym)
+                        SKM_V5S(1, true);
+                    else
+                        SKM_V5S(1, false);
+                }
+#undef SKM_V5S
+                return skm_check_launch("k_cosine_dense_i8");
+            }
 #define SKM_V5(MODE, SYM) k_cosine_dense_i8_v5<MODE, SYM><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, xt, ybt, d_xrnorm, d_yrnorm, d_out, ld)
             if (mode == 0) {
                 if (sym)
