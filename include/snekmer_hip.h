@@ -495,10 +495,12 @@ int skm_allgatherv_multi(skm_ctx *ctx, int narrays, const void *const *d_send, v
  * entry count is read on the device (d_rowptr[n] <= cap_entries < 2^30), so the call does not wait for it:
  * d_out_counts[nbuckets] (device int64) = entries per owner, which the exchange can gather device to device
  * (one host round trip for the whole [src, dst] matrix).  h_counts (optional): the same on the host; passing it makes
- * the call host-synchronous. */
+ * the call host-synchronous.
+ * d_out_index (optional, capacity cap_entries): grouped position -> entry of the CSR it came from, for
+ * skm_colidx_from_owners. */
 int skm_bucket_partition(skm_ctx *ctx, int code_bits, int nbuckets, int64_t n, int64_t cap_entries, const int64_t *d_rowptr,
                          const void *d_codes, const uint32_t *d_counts, int64_t row_base, void *d_out_codes,
-                         uint64_t *d_out_rowcount, int64_t *d_out_counts, int64_t *h_counts);
+                         uint64_t *d_out_rowcount, int64_t *d_out_counts, int64_t *h_counts, uint32_t *d_out_index);
 /* Owner side: from the nrecv (code, row | count << 32) entries an owner received (ascending rows
  * within equal codes once stably sorted, which holds when sources are concatenated in rank order)
  * build d_post[npost] (postings of k-mers found in >= 2 rows, column after column, rows ascending),
@@ -507,11 +509,14 @@ int skm_bucket_partition(skm_ctx *ctx, int code_bits, int nbuckets, int64_t n, i
  * power of two >= 2 * ncols.  d_out4 (device int64[4]) = {distinct k-mers incl. single-row ones, ncols, npost, tsize};
  * the call does not wait for them (gather them device to device with the other owners' sizes).  h_out4 (optional):
  * the same on the host, which makes the call host-synchronous.  d_cols_start / d_post need room for nrecv elements, the
- * table for skm_bucket_table_capacity(nrecv) slots (all of its value words are cleared). */
+ * table for skm_bucket_table_capacity(nrecv) slots (all of its value words are cleared).
+ * d_ret (optional, nrecv words): the owner's ANSWER to every entry it received, in the order received: the owner-local
+ * column of the entry's k-mer, 0xFFFFFFFF for a k-mer of one row.  Sent back through the reverse of the all-to-all it
+ * replaces the table (d_tab_keys = d_tab_vals = NULL is then allowed): skm_colidx_from_owners. */
 int64_t skm_bucket_table_capacity(int64_t nrecv);
 int skm_bucket_postings(skm_ctx *ctx, int code_bits, int key_bits, int64_t nrecv, const void *d_codes,
                         const uint64_t *d_rowcount, int64_t *d_out4, int64_t *h_out4, uint32_t *d_cols_start, uint64_t *d_post,
-                        void *d_tab_keys, uint32_t *d_tab_vals);
+                        void *d_tab_keys, uint32_t *d_tab_vals, uint32_t *d_ret);
 /* Global column starts from the gathered per-owner arrays: d_starts holds the owners' d_cols_start
  * arrays back to back (h_ncols[p] entries each); d_colptr[sum(h_ncols) + 1] gets them rebased by
  * the owners' posting offsets (prefix sums of h_npost), closed by the total. */
@@ -523,6 +528,12 @@ int skm_concat_colptr(skm_ctx *ctx, int nparts, const int64_t *h_ncols, const in
 int skm_colidx_lookup(skm_ctx *ctx, int code_bits, int nbuckets, int64_t nnz, const void *d_codes,
                       const int64_t *h_tab_sizes, const int64_t *h_ncols, const void *d_tab_keys,
                       const uint32_t *d_tab_vals, uint32_t *d_colidx);
+/* Column id of every entry of a CSR shard from the owners' answers: d_back[nnz] = what came back through the reverse
+ * all-to-all, i.e. in the grouped order skm_bucket_partition produced (h_group_counts[b] entries for owner b, back to
+ * back); d_index = that call's d_out_index; owner b's columns start at global id sum(h_ncols[:b]).
+ * d_colidx[d_index[g]] = d_back[g] + that base, 0xFFFFFFFF kept. */
+int skm_colidx_from_owners(skm_ctx *ctx, int nbuckets, int64_t nnz, const uint32_t *d_back, const uint32_t *d_index,
+                           const int64_t *h_group_counts, const int64_t *h_ncols, uint32_t *d_colidx);
 /* d_rowptr[n_total + 1] of an n_total-row matrix that is empty except rows [lo, lo + nloc), which
  * are the local shard (d_local[nloc + 1]): lets skm_cosine_csr / skm_gram_neighbors run on a shard
  * with global row numbers. */

@@ -139,9 +139,10 @@ _SIGNATURES = {
     "skm_alltoallv_multi": (C.c_int, [_p, C.c_int, _p, _p, _p, _p, _p]),
     "skm_plan_allgatherv": (C.c_int, [C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "skm_allgatherv_multi": (C.c_int, [_p, C.c_int, _p, _p, _p, _p]),
-    "skm_bucket_partition": (C.c_int, [_p, C.c_int, C.c_int, _i64, _i64, _p, _p, _p, _i64, _p, _p, _p, _p]),
+    "skm_bucket_partition": (C.c_int, [_p, C.c_int, C.c_int, _i64, _i64, _p, _p, _p, _i64, _p, _p, _p, _p, _p]),
     "skm_bucket_table_capacity": (_i64, [_i64]),
-    "skm_bucket_postings": (C.c_int, [_p, C.c_int, C.c_int, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "skm_bucket_postings": (C.c_int, [_p, C.c_int, C.c_int, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "skm_colidx_from_owners": (C.c_int, [_p, C.c_int, _i64, _p, _p, _p, _p, _p]),
     "skm_concat_colptr": (C.c_int, [_p, C.c_int, _p, _p, _p, _p]),
     "skm_colidx_lookup": (C.c_int, [_p, C.c_int, C.c_int, _i64, _p, _p, _p, _p, _p, _p]),
     "skm_embed_rowptr": (C.c_int, [_p, _i64, _i64, _i64, _p, _p]),

@@ -26,11 +26,15 @@
 
 constexpr int PB_ROWS = 256;       // heavy rows per block
 constexpr int PB_KMAX = 1024;      // panel columns per block
-constexpr int PB_DICT = 2048;      // hash slots of a block's column dictionary
+constexpr int PB_DICT = 8192;      // hash slots of a block's column dictionary (round 4: 2048, and a tenth of the long entries of
+                                   // synth_skewed's heavy rows found no room: mixed blocks hold thousands of distinct long columns)
 constexpr int PB_JMAX = 16384;     // rows of Y a block's panel may touch
 constexpr uint32_t PB_DF_LONG = 64, PB_DF_MAX = 8192;  // a column is panel material when DF_LONG < df <= DF_MAX
 constexpr uint32_t PB_NOSLOT = 0xFFFFFFFFu;
-constexpr uint32_t PB_MIN_ROWS = 8;  // rows of a block that must share a column for it to get a slot
+#ifndef SKM_PB_MIN_ROWS
+#define SKM_PB_MIN_ROWS 24  // (bench.py skewed_workload, ms per step: 2 30.2, 4 29.0, 8 23.5, 16 23.2, 24 22.7, 32 23.0, 48 23.8)
+#endif
+constexpr uint32_t PB_MIN_ROWS = SKM_PB_MIN_ROWS;  // rows of a block that must share a column for it to get a slot
 constexpr int PB_STEP_COLS = 32768; // columns per step of the PANEL form of k_cosine_heavy
 constexpr int PB_STEPS = 32;       // such steps over at most 2^20 rows of Y
 constexpr int PB_MAXBLOCKS = 512;  // at most 131072 heavy rows get panels; the rest are walked
@@ -53,7 +57,8 @@ struct panel_bufs {
     int nb;               // blocks the buffers hold
 };
 
-__device__ __forceinline__ uint32_t panel_hash(uint32_t c) { return (c * 2654435761u) >> (32 - 11); }  // PB_DICT = 2^11
+__device__ __forceinline__ uint32_t panel_hash(uint32_t c) { return (c * 2654435761u) >> (32 - 13); }  // PB_DICT = 2^13
+static_assert(PB_DICT == 1 << 13, "panel_hash");
 
 // slot of column c in block b's dictionary, PB_NOSLOT when absent / not given a slot / bad
 __device__ __forceinline__ uint32_t panel_lookup(const panel_bufs &pb, uint32_t b, uint32_t c)

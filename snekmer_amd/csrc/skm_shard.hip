@@ -15,8 +15,11 @@
 //                          code -> column
 //        ... all-gather of postings and tables ...   (skm_allgatherv)
 //   skm_concat_colptr      global column starts from the per-owner tables
-//   skm_colidx_lookup      each rank: column id of its own CSR entries from the owner's hash
-//                          table (one probe as a rule); a k-mer of one row only gets 0xFFFFFFFF
+//   skm_colidx_from_owners (round 5) each rank: column id of its own CSR entries from the owners' ANSWERS - the owner of an
+//                          entry knows its column once it has sorted its share, and sends one uint32 per entry back
+//                          through the reverse of the all-to-all (0xFFFFFFFF: a k-mer of one row only); no hash table is
+//                          built, gathered or probed (round 4: skm_colidx_lookup, kept: 1.0 ms of probes per rank + the
+//                          tables in the all-gather)
 //   skm_embed_rowptr       the local rows as rows [lo, hi) of an otherwise empty N-row matrix, so
 //                          that the cosine kernels see global row numbers
 //
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(BLK) void k_partition_gather(const int64_t *__restr
                                                           const uint64_t *__restrict__ rowcount,
                                                           K *__restrict__ out_codes, uint64_t *__restrict__ out_rowcount,
                                                           const unsigned int *__restrict__ hist, int nbuckets,
-                                                          int64_t *__restrict__ out_counts)
+                                                          int64_t *__restrict__ out_counts, uint32_t *__restrict__ out_index)
 {
     const int64_t nnz = *d_nnz;
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,6 +109,8 @@ __global__ __launch_bounds__(BLK) void k_partition_gather(const int64_t *__restr
         const uint32_t e = idx[t];
         out_codes[t] = codes[e];
         out_rowcount[t] = rowcount[e];
+        if (out_index)
+            out_index[t] = e;  // grouped position -> entry of the shard's CSR (what the owners' answers are scattered by)
     }
 }
 
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(BLK) void k_bucket_emit(int64_t n, const K *__restr
                                                      const uint64_t *__restrict__ rowcount,
                                                      uint32_t *__restrict__ cols_start, uint64_t *__restrict__ post,
                                                      const int64_t *__restrict__ out4, K *__restrict__ tab_keys,
-                                                     uint32_t *__restrict__ tab_vals)
+                                                     uint32_t *__restrict__ tab_vals, uint32_t *__restrict__ ret)
 {
     const uint32_t tsize = (uint32_t)out4[3];  // power of two >= 2 x shared columns (k_owner_sizes)
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -160,14 +165,23 @@ __global__ __launch_bounds__(BLK) void k_bucket_emit(int64_t n, const K *__restr
         const K k = skeys[t];
         const bool head = t == 0 || skeys[t - 1] != k;
         const bool more = t + 1 < n && skeys[t + 1] == k;
-        if (head && !more)
-            continue;  // k-mer of one row only: no posting, no column
+        if (head && !more) {  // k-mer of one row only: no posting, no column
+            if (ret)
+                ret[sidx[t]] = TAB_EMPTY;
+            continue;
+        }
         const uint64_t sc = incl[t];
         const uint32_t pos = (uint32_t)sc - 1u;  // inclusive scan: this entry is counted
         post[pos] = rowcount[sidx[t]];
+        // the answer to whoever sent this entry: the owner-local column of its k-mer (heads counted up to here, this
+        // k-mer's included), in the order the entries were received
+        if (ret)
+            ret[sidx[t]] = (uint32_t)(sc >> 32) - 1u;
         if (head) {
             const uint32_t ci = (uint32_t)(sc >> 32) - 1u;
             cols_start[ci] = pos;
+            if (!tab_vals)
+                continue;
             // every column is inserted once, so claiming the value word is enough; the key word is
             // only read by later kernels
             for (uint32_t h = table_slot(k, tsize);; h = (h + 1u) & (tsize - 1u)) {
@@ -233,7 +247,7 @@ __global__ void k_embed_rowptr(int64_t n_total, int64_t lo, int64_t nloc, const 
 template <typename K>
 int partition_impl(skm_ctx *ctx, int nbuckets, int64_t n, int64_t cap, const int64_t *d_rowptr, const K *d_codes,
                    const uint32_t *d_counts, int64_t row_base, K *d_out_codes, uint64_t *d_out_rowcount,
-                   int64_t *d_out_counts, int64_t *h_counts)
+                   int64_t *d_out_counts, int64_t *h_counts, uint32_t *d_out_index)
 {
     // Nothing here waits for the device unless the caller asks for the counts on the host: the entry count is
     // d_rowptr[n], the launches cover the capacity, the stable grouping by owner is one digit of the library's own
@@ -266,7 +280,7 @@ int partition_impl(skm_ctx *ctx, int nbuckets, int64_t n, int64_t cap, const int
     {
         SKM_PROF(ctx, "k_partition_gather");
         k_partition_gather<K><<<skm_grid_cap(ctx, skm_ceil_div(cap, BLK), 16), BLK, 0, st>>>(
-            d_rowptr + n, idx, d_codes, rowcount, d_out_codes, d_out_rowcount, hist, nbuckets, d_out_counts);
+            d_rowptr + n, idx, d_codes, rowcount, d_out_codes, d_out_rowcount, hist, nbuckets, d_out_counts, d_out_index);
     }
     SKM_TRY(skm_check_launch("k_partition_gather"));
     if (h_counts) {
@@ -287,7 +301,7 @@ static uint32_t table_size_for(int64_t ncols)
 
 template <typename K>
 int postings_impl(skm_ctx *ctx, int key_bits, int64_t n, const K *d_codes, const uint64_t *d_rowcount, int64_t *d_out4,
-                  int64_t *h_out4, uint32_t *d_cols_start, uint64_t *d_post, K *d_tab_keys, uint32_t *d_tab_vals)
+                  int64_t *h_out4, uint32_t *d_cols_start, uint64_t *d_post, K *d_tab_keys, uint32_t *d_tab_vals, uint32_t *d_ret)
 {
     hipStream_t st = ctx->stream;
     void *p;
@@ -309,12 +323,13 @@ int postings_impl(skm_ctx *ctx, int key_bits, int64_t n, const K *d_codes, const
     // sizes stay on the device (d_out4); the table's value words are cleared over their whole capacity because the
     // size actually used (a power of two >= 2 x shared columns) is only known there
     k_owner_sizes<<<1, 1, 0, st>>>(n, incl, d_out4);
-    SKM_HIP(hipMemsetAsync(d_tab_vals, 0xFF, sizeof(uint32_t) * (size_t)table_size_for(n / 2), st));
+    if (d_tab_vals)
+        SKM_HIP(hipMemsetAsync(d_tab_vals, 0xFF, sizeof(uint32_t) * (size_t)table_size_for(n / 2), st));
     {
         SKM_PROF(ctx, "k_bucket_emit");
         k_bucket_emit<K><<<skm_grid_cap(ctx, skm_ceil_div(n, BLK), 16), BLK, 0, st>>>(n, skeys, sidx, incl, d_rowcount,
                                                                                    d_cols_start, d_post, d_out4, d_tab_keys,
-                                                                                   d_tab_vals);
+                                                                                   d_tab_vals, d_ret);
     }
     SKM_TRY(skm_check_launch("k_bucket_emit"));
     if (h_out4) {
@@ -330,7 +345,7 @@ int postings_impl(skm_ctx *ctx, int key_bits, int64_t n, const K *d_codes, const
 extern "C" int skm_bucket_partition(skm_ctx *ctx, int code_bits, int nbuckets, int64_t n, int64_t cap_entries,
                                     const int64_t *d_rowptr, const void *d_codes, const uint32_t *d_counts,
                                     int64_t row_base, void *d_out_codes, uint64_t *d_out_rowcount, int64_t *d_out_counts,
-                                    int64_t *h_counts)
+                                    int64_t *h_counts, uint32_t *d_out_index)
 {
     SKM_REQUIRE(ctx && d_out_counts && n >= 0 && cap_entries >= 0 && row_base >= 0, SKM_E_BADARG, "skm_bucket_partition: bad argument");
     SKM_REQUIRE(code_bits == 32 || code_bits == 64, SKM_E_BADARG, "skm_bucket_partition: code_bits must be 32 or 64");
@@ -350,9 +365,9 @@ extern "C" int skm_bucket_partition(skm_ctx *ctx, int code_bits, int nbuckets, i
                 "skm_bucket_partition: null array");
     if (code_bits == 32)
         return partition_impl<uint32_t>(ctx, nbuckets, n, cap_entries, d_rowptr, (const uint32_t *)d_codes, d_counts, row_base,
-                                        (uint32_t *)d_out_codes, d_out_rowcount, d_out_counts, h_counts);
+                                        (uint32_t *)d_out_codes, d_out_rowcount, d_out_counts, h_counts, d_out_index);
     return partition_impl<uint64_t>(ctx, nbuckets, n, cap_entries, d_rowptr, (const uint64_t *)d_codes, d_counts, row_base,
-                                    (uint64_t *)d_out_codes, d_out_rowcount, d_out_counts, h_counts);
+                                    (uint64_t *)d_out_codes, d_out_rowcount, d_out_counts, h_counts, d_out_index);
 }
 
 extern "C" int64_t skm_bucket_table_capacity(int64_t nrecv)
@@ -365,18 +380,40 @@ __global__ void k_empty_owner(int64_t *out4, uint32_t *tab_vals)
 {
     out4[0] = out4[1] = out4[2] = 0;
     out4[3] = 2;  // an empty table of the minimum size, so that every owner contributes one
-    tab_vals[0] = tab_vals[1] = 0xFFFFFFFFu;
+    if (tab_vals)
+        tab_vals[0] = tab_vals[1] = 0xFFFFFFFFu;
+}
+
+// colidx[index[g]] = the owner's answer for grouped position g, moved into the global column numbering (owners'
+// columns back to back in rank order); group of g = the owner its entry went to
+struct owner_groups {
+    int64_t first[SKM_MAX_RANKS + 1];  // first grouped position of every owner's group
+    uint32_t col[SKM_MAX_RANKS + 1];   // first global column id of every owner
+};
+__global__ __launch_bounds__(BLK) void k_colidx_from_owners(int64_t nnz, int nb, owner_groups grp, const uint32_t *__restrict__ back,
+                                                            const uint32_t *__restrict__ index, uint32_t *__restrict__ colidx)
+{
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; g < nnz; g += stride) {
+        int b = 0;
+        while (b + 1 < nb && g >= grp.first[b + 1])
+            ++b;
+        const uint32_t v = back[g];
+        colidx[index[g]] = v == TAB_EMPTY ? TAB_EMPTY : grp.col[b] + v;
+    }
 }
 }  // namespace
 
 extern "C" int skm_bucket_postings(skm_ctx *ctx, int code_bits, int key_bits, int64_t nrecv, const void *d_codes,
                                    const uint64_t *d_rowcount, int64_t *d_out4, int64_t *h_out4, uint32_t *d_cols_start,
-                                   uint64_t *d_post, void *d_tab_keys, uint32_t *d_tab_vals)
+                                   uint64_t *d_post, void *d_tab_keys, uint32_t *d_tab_vals, uint32_t *d_ret)
 {
     SKM_REQUIRE(ctx && d_out4 && nrecv >= 0, SKM_E_BADARG, "skm_bucket_postings: bad argument");
     SKM_REQUIRE(code_bits == 32 || code_bits == 64, SKM_E_BADARG, "skm_bucket_postings: code_bits must be 32 or 64");
     SKM_REQUIRE(nrecv < ((int64_t)1 << 31), SKM_E_OVERFLOW, "skm_bucket_postings: more than 2^31 entries for one owner");
-    SKM_REQUIRE(d_tab_keys && d_tab_vals, SKM_E_BADARG, "skm_bucket_postings: null table");
+    SKM_REQUIRE((d_tab_keys && d_tab_vals) || (!d_tab_keys && !d_tab_vals && d_ret), SKM_E_BADARG,
+                "skm_bucket_postings: give the table (keys and values), the answer array d_ret, or both");
     SKM_HIP(hipSetDevice(ctx->device));
     if (nrecv == 0) {
         k_empty_owner<<<1, 1, 0, ctx->stream>>>(d_out4, d_tab_vals);
@@ -392,9 +429,9 @@ extern "C" int skm_bucket_postings(skm_ctx *ctx, int code_bits, int key_bits, in
         key_bits = code_bits;
     if (code_bits == 32)
         return postings_impl<uint32_t>(ctx, key_bits, nrecv, (const uint32_t *)d_codes, d_rowcount, d_out4, h_out4, d_cols_start,
-                                       d_post, (uint32_t *)d_tab_keys, d_tab_vals);
+                                       d_post, (uint32_t *)d_tab_keys, d_tab_vals, d_ret);
     return postings_impl<uint64_t>(ctx, key_bits, nrecv, (const uint64_t *)d_codes, d_rowcount, d_out4, h_out4, d_cols_start,
-                                   d_post, (uint64_t *)d_tab_keys, d_tab_vals);
+                                   d_post, (uint64_t *)d_tab_keys, d_tab_vals, d_ret);
 }
 
 extern "C" int skm_concat_colptr(skm_ctx *ctx, int nparts, const int64_t *h_ncols, const int64_t *h_npost,
@@ -455,6 +492,34 @@ extern "C" int skm_colidx_lookup(skm_ctx *ctx, int code_bits, int nbuckets, int6
         k_colidx_lookup<uint64_t><<<grid, BLK, 0, ctx->stream>>>(nnz, (const uint64_t *)d_codes, (uint32_t)nbuckets, seg,
                                                                  (const uint64_t *)d_tab_keys, d_tab_vals, d_colidx);
     return skm_check_launch("k_colidx_lookup");
+}
+
+extern "C" int skm_colidx_from_owners(skm_ctx *ctx, int nbuckets, int64_t nnz, const uint32_t *d_back, const uint32_t *d_index,
+                                      const int64_t *h_group_counts, const int64_t *h_ncols, uint32_t *d_colidx)
+{
+    SKM_REQUIRE(ctx && nnz >= 0 && h_group_counts && h_ncols, SKM_E_BADARG, "skm_colidx_from_owners: bad argument");
+    SKM_REQUIRE(nbuckets >= 1 && nbuckets <= SKM_MAX_RANKS, SKM_E_BADARG, "skm_colidx_from_owners: 1 <= nbuckets <= %d", SKM_MAX_RANKS);
+    owner_groups grp = {};
+    int64_t first = 0, col = 0;
+    for (int b = 0; b < nbuckets; ++b) {
+        SKM_REQUIRE(h_group_counts[b] >= 0 && h_ncols[b] >= 0, SKM_E_BADARG, "skm_colidx_from_owners: negative size");
+        grp.first[b] = first;
+        grp.col[b] = (uint32_t)col;
+        first += h_group_counts[b];
+        col += h_ncols[b];
+    }
+    grp.first[nbuckets] = first;
+    SKM_REQUIRE(first == nnz, SKM_E_BADARG, "skm_colidx_from_owners: the groups hold %lld entries, nnz is %lld", (long long)first,
+                (long long)nnz);
+    SKM_REQUIRE(col < ((int64_t)1 << 32) - 1, SKM_E_OVERFLOW, "skm_colidx_from_owners: >= 2^32 columns");
+    if (nnz == 0)
+        return SKM_OK;
+    SKM_REQUIRE(d_back && d_index && d_colidx, SKM_E_BADARG, "skm_colidx_from_owners: null array");
+    SKM_HIP(hipSetDevice(ctx->device));
+    SKM_PROF(ctx, "k_colidx_from_owners");
+    k_colidx_from_owners<<<skm_grid_cap(ctx, skm_ceil_div(nnz, BLK), 16), BLK, 0, ctx->stream>>>(nnz, nbuckets, grp, d_back, d_index,
+                                                                                                 d_colidx);
+    return skm_check_launch("k_colidx_from_owners");
 }
 
 extern "C" int skm_embed_rowptr(skm_ctx *ctx, int64_t n_total, int64_t lo, int64_t nloc, const int64_t *d_local,

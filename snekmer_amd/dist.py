@@ -133,6 +133,16 @@ def postings_host(codes: np.ndarray, rowcount: np.ndarray):
     return int(head.sum()), sk[col_head], starts.astype(np.uint32), post
 
 
+def owner_answers_host(codes: np.ndarray) -> np.ndarray:
+    """Host statement of skm_bucket_postings' d_ret: for every entry an owner received (in the order received) the
+    owner-local column of its k-mer - columns are the owner's k-mers found in >= 2 rows, in ascending code order -,
+    0xFFFFFFFF for a k-mer of one row."""
+    codes = np.asarray(codes)
+    uniq, inv, cnt = np.unique(codes, return_inverse=True, return_counts=True)
+    col_of_uniq = np.where(cnt >= 2, np.cumsum(cnt >= 2) - 1, 0xFFFFFFFF).astype(np.uint32)
+    return col_of_uniq[inv] if len(codes) else np.zeros(0, np.uint32)
+
+
 def concat_rowptr_host(local_rowptrs: Sequence[np.ndarray]) -> np.ndarray:
     """Host statement of skm_csr_concat_rowptr (used by the CPU tests to check the plan)."""
     out, base = [], 0
@@ -228,7 +238,7 @@ class ShardedPipeline:
     """vectorize the local shard, exchange, then cosine (or top-k) for the local row block."""
 
     def __init__(self, ctx, lut, k: int, exchange, bounds: Sequence[Tuple[int, int]], total_residues: int,
-                 basis: Optional[str] = None):
+                 basis: Optional[str] = None, columns: Optional[str] = None):
         import os
 
         from . import engine
@@ -240,6 +250,12 @@ class ShardedPipeline:
         self.engine = engine
         self.ctx, self.lut, self.k, self.ex = ctx, lut, k, exchange
         self.mode = basis
+        # how a rank learns the column ids of its own entries (distributed basis): "owners" = every owner answers the entries
+        # it received with one uint32 each through the reverse of the all-to-all (no hash table is built, gathered or
+        # probed); "tables" = round 4's form: owners' hash tables all-gathered, one probe per entry
+        self.columns = columns or os.environ.get("SKM_DIST_COLUMNS", "owners")
+        if self.columns not in ("owners", "tables"):
+            raise ValueError("columns must be 'owners' or 'tables'")
         self.bounds = list(bounds)
         self.rank = exchange.rank
         self.world = len(self.bounds)
@@ -315,10 +331,13 @@ class ShardedPipeline:
         # residues (3.5 M sequences of 300 aa on ONE rank; include/snekmer_hip.h, skm_bucket_partition)
         if cap >= 1 << 30:
             raise ValueError(f"rank {me}: a shard of {cap - 1} residues; ShardedPipeline holds at most 2^30 - 1 per rank: use more ranks")
+        owners = self.columns == "owners"
         p_codes = self._need("p_codes", cap, self.code_dtype)
         p_rc = self._need("p_rc", cap, np.uint64)
+        p_index = self._need("p_index", cap, np.uint32) if owners else None
         ctx.call("skm_bucket_partition", self.code_bits, G, _i64(loc.n), _i64(cap), _p(loc.rowptr.ptr),
-                 _p(loc.codes.ptr), _p(loc.counts.ptr), _i64(lo), _p(p_codes.ptr), _p(p_rc.ptr), _p(d_counts.ptr), _p(None))
+                 _p(loc.codes.ptr), _p(loc.counts.ptr), _i64(lo), _p(p_codes.ptr), _p(p_rc.ptr), _p(d_counts.ptr), _p(None),
+                 _p(p_index.ptr if owners else None))
         cmat = self._gather_sizes(d_counts, G)  # collective 1 + round trip 1: [src, dst] entry counts
         loc.nnz = int(cmat[me, :].sum())
         self.nnz_total = int(cmat.sum())
@@ -328,44 +347,67 @@ class ShardedPipeline:
         r_codes = self._need("r_codes", nrecv, self.code_dtype)
         r_rc = self._need("r_rc", nrecv, np.uint64)
         ex.alltoallv_multi([p_codes, p_rc], [r_codes, r_rc], [cb, 8], cmat[me, :], cmat[:, me])  # collective 2
-        # 3. owner: sort its share by code, compact postings, column starts, hash table code -> column
+        # 3. owner: sort its share by code, compact postings, column starts, and either its answers (the owner-local column of
+        # every entry it received, in the order received) or a hash table code -> column
         o_start = self._need("o_start", nrecv, np.uint32)
         o_post = self._need("o_post", nrecv, np.uint64)
-        tcap = int(ctx.lib.skm_bucket_table_capacity(nrecv))
-        o_tkeys = self._need("o_tkeys", tcap, self.code_dtype)
-        o_tvals = self._need("o_tvals", tcap, np.uint32)
         d_out4 = self._need("d_out4", 4, np.int64)
+        if owners:
+            o_ret = self._need("o_ret", nrecv, np.uint32)
+            o_tkeys = o_tvals = None
+        else:
+            tcap = int(ctx.lib.skm_bucket_table_capacity(nrecv))
+            o_tkeys = self._need("o_tkeys", tcap, self.code_dtype)
+            o_tvals = self._need("o_tvals", tcap, np.uint32)
+            o_ret = None
         ctx.call("skm_bucket_postings", self.code_bits, e.key_bits(self.lut.nsym, self.k), _i64(nrecv), _p(r_codes.ptr),
-                 _p(r_rc.ptr), _p(d_out4.ptr), _p(None), _p(o_start.ptr), _p(o_post.ptr), _p(o_tkeys.ptr), _p(o_tvals.ptr))
+                 _p(r_rc.ptr), _p(d_out4.ptr), _p(None), _p(o_start.ptr), _p(o_post.ptr), _p(o_tkeys.ptr if o_tkeys else None),
+                 _p(o_tvals.ptr if o_tvals else None), _p(o_ret.ptr if owners else None))
         # collective 3 + round trip 2: [rank, (distinct, shared columns, postings, table slots)]
         meta = self._gather_sizes(d_out4, 4)
         ncols, npost, tsize = meta[:, 1].copy(), meta[:, 2].copy(), meta[:, 3].copy()
-        tot_cols, tot_post, tot_slots = int(ncols.sum()), int(npost.sum()), int(tsize.sum())
-        # 4. one grouped all-gather: every rank gets all postings, column starts, tables and row norms
+        tot_cols, tot_post, tot_slots = int(ncols.sum()), int(npost.sum()), int(tsize.sum()) if not owners else 0
+        # 4. one grouped all-gather: every rank gets all postings, column starts and row norms (and the tables); with
+        # answers, the reverse of collective 2 carries one uint32 per entry back to where the entry came from (queued right
+        # behind the all-gather: RCCL runs them back to back on the context's stream)
         b = self.basis or _ColumnMajor()
         b.ncols, b.ncols_shared = int(meta[:, 0].sum()), tot_cols
         b.post = self._need("post", tot_post, np.uint64)
         b.colptr = self._need("colptr", tot_cols + 1, np.uint32)
         a_start = self._need("a_start", tot_cols, np.uint32)
-        a_tkeys = self._need("a_tkeys", tot_slots, self.code_dtype)
-        a_tvals = self._need("a_tvals", tot_slots, np.uint32)
-        ex.allgatherv_multi([o_post, o_start, o_tkeys, o_tvals, rn], [b.post, a_start, a_tkeys, a_tvals, self.rnorm],
-                            [8, 4, cb, 4, 4], [npost, ncols, tsize, tsize, np.asarray(self.rows, dtype=np.int64)])  # collective 4
+        rows64 = np.asarray(self.rows, dtype=np.int64)
+        if owners:
+            back = self._need("back", loc.nnz, np.uint32)
+            ex.alltoallv_multi([o_ret], [back], [4], cmat[:, me], cmat[me, :])  # collective 4a: the answers
+            ex.allgatherv_multi([o_post, o_start, rn], [b.post, a_start, self.rnorm], [8, 4, 4], [npost, ncols, rows64])  # 4b
+        else:
+            a_tkeys = self._need("a_tkeys", tot_slots, self.code_dtype)
+            a_tvals = self._need("a_tvals", tot_slots, np.uint32)
+            ex.allgatherv_multi([o_post, o_start, o_tkeys, o_tvals, rn], [b.post, a_start, a_tkeys, a_tvals, self.rnorm],
+                                [8, 4, cb, 4, 4], [npost, ncols, tsize, tsize, rows64])  # collective 4
         ctx.call("skm_concat_colptr", G, ncols.ctypes.data_as(_p), npost.ctypes.data_as(_p), _p(a_start.ptr),
                  _p(b.colptr.ptr))
         self.basis = b
         # sizes of this step, for reporting (bench.py's per-stage rooflines)
         self.sizes = {"local_entries": int(loc.nnz), "owned_entries": nrecv, "owned_columns": int(ncols[me]),
-                      "owned_postings": int(npost[me]), "owned_table_slots": int(tsize[me]), "columns": tot_cols,
+                      "owned_postings": int(npost[me]), "owned_table_slots": 0 if owners else int(tsize[me]), "columns": tot_cols,
                       "postings": tot_post, "table_slots": tot_slots,
                       "alltoall_bytes_out": int((cmat[me, :].sum() - cmat[me, me]) * (cb + 8)),
                       "alltoall_bytes_in": int((cmat[:, me].sum() - cmat[me, me]) * (cb + 8)),
+                      "answers_bytes_out": int((cmat[:, me].sum() - cmat[me, me]) * 4) if owners else 0,
+                      "answers_bytes_in": int((cmat[me, :].sum() - cmat[me, me]) * 4) if owners else 0,
                       "allgather_bytes_in": int((tot_post - npost[me]) * 8 + (tot_cols - ncols[me]) * 4
-                                                + (tot_slots - tsize[me]) * (cb + 4) + (self.n_total - nloc) * 4)}
+                                                + (0 if owners else (tot_slots - tsize[me]) * (cb + 4)) + (self.n_total - nloc) * 4),
+                      "column_ids": self.columns}
         # 5. columns of the local rows; the shard as rows [lo, hi) of an N-row matrix
         colidx = self._need("colidx", loc.nnz, np.uint32)
-        ctx.call("skm_colidx_lookup", self.code_bits, G, _i64(loc.nnz), _p(loc.codes.ptr), tsize.ctypes.data_as(_p),
-                 ncols.ctypes.data_as(_p), _p(a_tkeys.ptr), _p(a_tvals.ptr), _p(colidx.ptr))
+        if owners:
+            groups = np.ascontiguousarray(cmat[me, :], dtype=np.int64)
+            ctx.call("skm_colidx_from_owners", G, _i64(loc.nnz), _p(back.ptr), _p(p_index.ptr), groups.ctypes.data_as(_p),
+                     ncols.ctypes.data_as(_p), _p(colidx.ptr))
+        else:
+            ctx.call("skm_colidx_lookup", self.code_bits, G, _i64(loc.nnz), _p(loc.codes.ptr), tsize.ctypes.data_as(_p),
+                     ncols.ctypes.data_as(_p), _p(a_tkeys.ptr), _p(a_tvals.ptr), _p(colidx.ptr))
         ctx.call("skm_embed_rowptr", _i64(self.n_total), _i64(lo), _i64(nloc), _p(loc.rowptr.ptr), _p(self.rowptr_g.ptr))
         x = e.CountsCSR(ctx, self.n_total, loc.nnz, self.code_bits, self.rowptr_g, loc.codes, loc.counts, None)
         x.colidx = colidx

@@ -104,7 +104,7 @@ def _worker_owner(rank, world, port, outdir):
 
     from oracle import c_oracle
     from snekmer_amd import alphabet as A
-    from snekmer_amd.dist import owner_host, plan_alltoall, postings_host, shard_bounds
+    from snekmer_amd.dist import owner_answers_host, owner_host, plan_alltoall, postings_host, shard_bounds
     from snekmer_amd.synth import synth_families
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -166,6 +166,17 @@ def _worker_owner(rank, world, port, outdir):
         for p in parts:
             for c in p[1]:
                 table[int(c)] = len(table)
+        # the column ids as ShardedPipeline learns them (round 5): every owner answers the entries it received, one uint32
+        # each in the order received, through the REVERSE of the all-to-all; the sender adds the owner's first global column
+        sb, rb = plan_alltoall(cmat.T, rank, 4)
+        back = alltoallv(owner_answers_host(r_codes), sb, rb).view(np.uint32)
+        assert len(back) == len(codes)
+        colbase = np.cumsum([0] + [len(p[1]) for p in parts])
+        grp_owner = np.repeat(np.arange(world), cmat[rank, :])  # owner of every grouped position
+        colidx = np.full(len(codes), 0xFFFFFFFF, dtype=np.int64)
+        colidx[order] = np.where(back == 0xFFFFFFFF, 0xFFFFFFFF, back.astype(np.int64) + colbase[grp_owner])
+        want = np.asarray([table.get(int(c), 0xFFFFFFFF) for c in codes], dtype=np.int64)
+        assert (colidx == want).all()
         # 5. own rows against the postings; norms all-gathered
         norms = np.concatenate(allgather_obj(np.sqrt(np.add.reduceat(counts.astype(np.float64) ** 2, rp[:-1]))
                                              if len(counts) else np.zeros(hi - lo)))

@@ -825,6 +825,15 @@ def test_sharded_pipeline_over_rccl_single_rank_equals_pipeline(ctx, mode):
         assert sp.nnz_total == ref.csr.nnz and sp.basis.ncols == ref.basis.ncols
         out = sp.step(batch)  # buffers are reused on the second step
         assert (out.download().reshape(out.shape)[:n, :n] == S).all()
+        if mode == "distributed":
+            # both ways of learning the column ids (the owners' answers through the reverse all-to-all - the default - and
+            # round 4's gathered hash tables) give the same column ids and the same matrix
+            assert sp.columns == "owners" and sp.sizes["column_ids"] == "owners" and sp.sizes["owned_table_slots"] == 0
+            col_owners = sp.x.colidx.download(sp.x.nnz)
+            st = ShardedPipeline(ctx, lut, 12, ex, shard_bounds(n, 1), int(off[-1]), basis=mode, columns="tables")
+            out = st.step(batch)
+            assert (out.download().reshape(out.shape)[:n, :n] == S).all()
+            assert (st.x.colidx.download(st.x.nnz) == col_owners).all() and st.sizes["owned_table_slots"] > 0
     finally:
         ctx.call("skm_comm_destroy")
 
@@ -837,7 +846,7 @@ def test_owner_partition_postings_lookup_match_host_statements(ctx, name):
 
     from snekmer_amd import alphabet as A
     from snekmer_amd import engine
-    from snekmer_amd.dist import owner_host, postings_host
+    from snekmer_amd.dist import owner_answers_host, owner_host, postings_host
     from snekmer_amd.synth import synth_families
 
     lut = A.build_lut(name)
@@ -852,11 +861,13 @@ def test_owner_partition_postings_lookup_match_host_statements(ctx, name):
     d_cnt = ctx.empty(nb, np.int64)
     # capacity larger than the entry count: the count is read on the device (d_rowptr[n])
     d_codes, d_rc = ctx.empty(nnz + 1000, dt), ctx.empty(nnz + 1000, np.uint64)
+    d_index = ctx.empty(nnz + 1000, np.uint32)
     ctx.call("skm_bucket_partition", csr.code_bits, nb, C.c_int64(csr.n), C.c_int64(nnz + 1000), p(csr.rowptr.ptr), p(csr.codes.ptr),
-             p(csr.counts.ptr), C.c_int64(base), p(d_codes.ptr), p(d_rc.ptr), p(d_cnt.ptr), h_counts.ctypes.data_as(p))
+             p(csr.counts.ptr), C.c_int64(base), p(d_codes.ptr), p(d_rc.ptr), p(d_cnt.ptr), h_counts.ctypes.data_as(p), p(d_index.ptr))
     assert (d_cnt.download(nb) == h_counts).all()
     own = owner_host(codes, nb)
     order = np.argsort(own, kind="stable")
+    assert (d_index.download(nnz) == order).all()  # grouped position -> entry of the CSR
     rows = np.repeat(np.arange(csr.n, dtype=np.uint64) + np.uint64(base), np.diff(rowptr))
     rc = rows | (counts.astype(np.uint64) << np.uint64(32))
     assert (h_counts == np.bincount(own, minlength=nb)).all()
@@ -871,9 +882,18 @@ def test_owner_partition_postings_lookup_match_host_statements(ctx, name):
     t_keys, t_vals = ctx.empty(cap, dt), ctx.empty(cap, np.uint32)
     out4 = np.zeros(4, dtype=np.int64)
     d_out4 = ctx.empty(4, np.int64)
+    d_ret = ctx.empty(nrecv, np.uint32)
     ctx.call("skm_bucket_postings", csr.code_bits, 0, C.c_int64(nrecv), p(r_codes.ptr), p(r_rc.ptr), p(d_out4.ptr), out4.ctypes.data_as(p),
-             p(o_start.ptr), p(o_post.ptr), p(t_keys.ptr), p(t_vals.ptr))
+             p(o_start.ptr), p(o_post.ptr), p(t_keys.ptr), p(t_vals.ptr), p(d_ret.ptr))
     assert (d_out4.download(4) == out4).all()
+    # the owner's answers (one uint32 per received entry, in the order received) against their host statement; and the
+    # same call without a table (what ShardedPipeline runs): same postings, same answers
+    answers = owner_answers_host(codes[order][seg])
+    assert (d_ret.download(nrecv) == answers).all()
+    o_start2, o_post2, d_ret2 = ctx.empty(nrecv, np.uint32), ctx.empty(nrecv, np.uint64), ctx.empty(nrecv, np.uint32)
+    ctx.call("skm_bucket_postings", csr.code_bits, 0, C.c_int64(nrecv), p(r_codes.ptr), p(r_rc.ptr), p(d_out4.ptr), None,
+             p(o_start2.ptr), p(o_post2.ptr), None, None, p(d_ret2.ptr))
+    assert (d_ret2.download(nrecv) == answers).all() and (d_out4.download(3) == out4[:3]).all()
     distinct, h_code, h_start, h_post = postings_host(codes[order][seg], rc[order][seg])
     assert out4[:3].tolist() == [distinct, len(h_code), len(h_post)] and out4[3] >= 2 * len(h_code)
     assert (o_start.download(len(h_code)) == h_start).all() and (o_post.download(len(h_post)) == h_post).all()
@@ -891,6 +911,16 @@ def test_owner_partition_postings_lookup_match_host_statements(ctx, name):
     hit = (pos < len(h_code)) & (h_code[np.minimum(pos, len(h_code) - 1)] == codes) if len(h_code) else np.zeros(nnz, bool)
     want = np.where(hit, pos, 0xFFFFFFFF).astype(np.uint32)
     assert (colidx.download(nnz) == want).all()
+    # the same column ids from the owners' answers: what comes back through the reverse all-to-all is, per owner, the
+    # answers to the entries of that owner's group in grouped order (here: owner 1 answers, owners 0 and 2 own nothing shared)
+    back = np.full(nnz, 0xFFFFFFFF, dtype=np.uint32)
+    back[seg] = answers
+    colidx2 = ctx.empty(nnz, np.uint32)
+    ctx.call("skm_memset", p(colidx2.ptr), 0x5A, C.c_size_t(4 * nnz))
+    ctx.call("skm_colidx_from_owners", nb, C.c_int64(nnz), p(ctx.to_device(back).ptr), p(d_index.ptr), h_counts.ctypes.data_as(p),
+             ncols.ctypes.data_as(p), p(colidx2.ptr))
+    assert (colidx2.download(nnz) == want).all()
+    assert (len(h_code) == 0) or (answers[answers != 0xFFFFFFFF].max() == len(h_code) - 1)
 
 
 # ------------------------------------------------------------------ sharded step, two ranks on one GPU
