@@ -840,9 +840,10 @@ def real_proteome(ctx, engine, alphabet):
 def small_batches(ctx, engine, alphabet, args):
     """The launch-bound regime: BASELINE configs[1] (10 k sequences) and the reference's real job sizes (one FASTA file
     of 50-3 700 records per Snakemake job, snekmer/rules/kmerize.smk:57-65).  Per N: wall time per step (host running
-    ahead, no synchronisation inside the loop), the sum of the per-stage HIP-event times, launches per step (profiled
-    scopes: a library sort counts as one) and `frac` = the step's HBM floor (4 bytes per result cell at the 8 TB/s spec)
-    over the wall time."""
+    ahead, no synchronisation inside the loop), the same with whole steps replayed as HIP graphs (engine.Pipeline(graphs=
+    "auto")), the sum of the per-stage HIP-event times, `gpu_operations_per_step` = every kernel, fill and copy of a step
+    (the node count of the step captured as a HIP graph: what rocprofv3 lists as dispatches), the profiled scopes per step
+    (a library sort counts as one) and `frac` = the step's HBM floor (4 bytes per result cell at the 8 TB/s spec) over the wall time."""
     from snekmer_amd.synth import BASE_SEED, synth_families
 
     lut = alphabet.build_lut(args.alphabet)
@@ -851,15 +852,22 @@ def small_batches(ctx, engine, alphabet, args):
         res, off, _ = synth_families(n, args.length, family=100, seed=BASE_SEED + 1)
         b = engine.SeqBatch(ctx, res, off)
         p = engine.Pipeline(ctx, lut, args.k)
-        for _ in range(5):
-            p.step(b)
-        ctx.sync()
-        reps = 200
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            p.step(b)
-        ctx.sync()
-        wall = (time.perf_counter() - t1) / reps * 1e3
+        walls = {}
+        for mode in (False, "auto"):
+            p.graphs = mode
+            for _ in range(5):
+                p.step(b)
+            ctx.sync()
+            reps = 200
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                p.step(b)
+            ctx.sync()
+            walls[mode] = (time.perf_counter() - t1) / reps * 1e3
+        nodes = [ent["graph"].nodes for ent in p._graphs.values() if ent["graph"] is not None]
+        p.graphs = False
+        p.drop_graphs()
+        wall = walls[False]
         ctx.profile_enable(True)
         ctx.profile_reset()
         for _ in range(50):
@@ -868,8 +876,9 @@ def small_batches(ctx, engine, alphabet, args):
         ctx.profile_enable(False)
         ld = (n + 3) // 4 * 4
         floor_ms = 4.0 * n * ld / (HBM_PEAK_GBS * 1e9) * 1e3
-        out.append({"n": n, "wall_ms": wall, "kernel_sum_ms": sum(v[1] for v in prof.values()) / 50,
-                    "launches_per_step": sum(v[0] for v in prof.values()) / 50, "hbm_floor_ms": floor_ms, "frac": floor_ms / wall,
+        out.append({"n": n, "wall_ms": wall, "wall_ms_graph_replay": walls["auto"], "kernel_sum_ms": sum(v[1] for v in prof.values()) / 50,
+                    "gpu_operations_per_step": nodes[0] if nodes else None,
+                    "profiled_scopes_per_step": sum(v[0] for v in prof.values()) / 50, "hbm_floor_ms": floor_ms, "frac": floor_ms / wall,
                     "sequences_per_s": n / (wall * 1e-3), "stage_ms": {kk: round(v[1] / 50, 4) for kk, v in prof.items()}})
         del p, b
     return out

@@ -83,6 +83,7 @@ typedef struct skm_graph skm_graph;
 int skm_graph_begin(skm_ctx *ctx);
 int skm_graph_end(skm_ctx *ctx, skm_graph **out_graph);
 int skm_graph_launch(skm_ctx *ctx, skm_graph *graph);
+int skm_graph_nodes(skm_graph *graph, int64_t *h_nodes); /* kernels + fills + copies in the capture: the GPU operations of a replay */
 int skm_graph_destroy(skm_ctx *ctx, skm_graph *graph);
 int skm_device_info(skm_ctx *ctx, char *h_name, int name_cap, int *h_cus, int64_t *h_mem_bytes);
 

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "skm_graph_begin": (C.c_int, [_p]),
     "skm_graph_end": (C.c_int, [_p, C.POINTER(_p)]),
     "skm_graph_launch": (C.c_int, [_p, _p]),
+    "skm_graph_nodes": (C.c_int, [_p, C.POINTER(_i64)]),
     "skm_graph_destroy": (C.c_int, [_p, _p]),
     "skm_event_record": (C.c_int, [_p, C.c_int]),
     "skm_stream_wait": (C.c_int, [_p, _p, C.c_int]),
@@ -382,6 +383,13 @@ class Graph:
 
     def launch(self):
         _check(self.ctx.lib, self.ctx.lib.skm_graph_launch(self.ctx.handle, self.handle))
+
+    @property
+    def nodes(self) -> int:
+        """Kernels, fills and copies in the capture: the GPU operations one replay (= one eager run of the same calls) issues."""
+        n = _i64(0)
+        _check(self.ctx.lib, self.ctx.lib.skm_graph_nodes(self.handle, C.byref(n)))
+        return int(n.value)
 
     def close(self):
         if self.handle is not None and self.ctx.handle is not None:

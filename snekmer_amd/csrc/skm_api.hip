@@ -319,6 +319,7 @@ struct skm_graph {
     hipGraphExec_t exec = nullptr;
     uint64_t ws_generation = 0;
     skm_ctx *owner = nullptr;
+    size_t nodes = 0;  // kernels, fills and copies the capture holds: the GPU operations of one replay
 };
 
 extern "C" int skm_graph_begin(skm_ctx *ctx)
@@ -360,7 +361,15 @@ extern "C" int skm_graph_end(skm_ctx *ctx, skm_graph **out_graph)
     gr->exec = x;
     gr->ws_generation = ctx->ws_generation;
     gr->owner = ctx;
+    (void)hipGraphGetNodes(g, nullptr, &gr->nodes);
     *out_graph = gr;
+    return SKM_OK;
+}
+
+extern "C" int skm_graph_nodes(skm_graph *graph, int64_t *h_nodes)
+{
+    SKM_REQUIRE(graph && h_nodes, SKM_E_BADARG, "skm_graph_nodes: null argument");
+    *h_nodes = (int64_t)graph->nodes;
     return SKM_OK;
 }
 

@@ -16,6 +16,9 @@ enum metric_id {
     M_CANBERRA = 4,     // sum |x - y| / (|x| + |y|), 0/0 terms skipped
     M_BRAYCURTIS = 5,   // sum |x - y| / sum |x + y|
     M_MINKOWSKI = 6,    // (sum |x - y|^p)^(1/p)
+    M_NAN_EUCLIDEAN = 7,  // sklearn.metrics.pairwise.nan_euclidean_distances: sqrt(k / present * sum over the columns where
+                          // neither value is NaN of (x - y)^2), NaN when no column is present in both rows
+    M_HAVERSINE = 8,    // two columns (latitude, longitude in radians): 2 asin(sqrt(sin^2(dlat / 2) + cos cos sin^2(dlon / 2)))
     M_DICE = 10,        // the boolean family: x, y read as x != 0, y != 0 (scipy's definitions, 0/0 -> nan as scipy's C)
     M_ROGERSTANIMOTO = 11,
     M_RUSSELLRAO = 12,
@@ -77,6 +80,19 @@ __global__ __launch_bounds__(256) void k_pairwise_f64(int64_t n, int64_t m, int6
                             a[u][v] += d;
                         else if constexpr (M == M_SQEUCLIDEAN || M == M_EUCLIDEAN)
                             a[u][v] += d * d;
+                        else if constexpr (M == M_NAN_EUCLIDEAN) {
+                            if (x == x && y == y) {  // neither is NaN
+                                a[u][v] += d * d;
+                                b[u][v] += 1.0;
+                            }
+                        } else if constexpr (M == M_HAVERSINE) {  // k == 2 (checked by the launcher): k0 == 0, kk = 0, 1
+                            const double sh = sin(0.5 * (x - y));
+                            if (kk == 0) {
+                                a[u][v] = sh * sh;
+                                c[u][v] = cos(x) * cos(y);
+                            } else
+                                b[u][v] = sh * sh;
+                        }
                         else if constexpr (M == M_CHEBYSHEV)
                             a[u][v] = fmax(a[u][v], d);
                         else if constexpr (M == M_CANBERRA) {
@@ -117,6 +133,10 @@ __global__ __launch_bounds__(256) void k_pairwise_f64(int64_t n, int64_t m, int6
                 }
             } else if constexpr (M == M_EUCLIDEAN)
                 o = sqrt(a[u][v]);
+            else if constexpr (M == M_NAN_EUCLIDEAN)
+                o = b[u][v] > 0.0 ? sqrt(a[u][v] / b[u][v] * (double)k) : nan("");
+            else if constexpr (M == M_HAVERSINE)
+                o = 2.0 * asin(sqrt(a[u][v] + c[u][v] * b[u][v]));
             else if constexpr (M == M_BRAYCURTIS)
                 o = a[u][v] / b[u][v];
             else if constexpr (M == M_MINKOWSKI)
@@ -124,7 +144,7 @@ __global__ __launch_bounds__(256) void k_pairwise_f64(int64_t n, int64_t m, int6
             else
                 o = a[u][v];
             if (square && i == j)  // squareform(pdist(X)) / euclidean_distances(X): an exact-zero diagonal
-                o = 0.0;
+                o = (M == M_NAN_EUCLIDEAN && !(b[u][v] > 0.0)) ? nan("") : 0.0;  // (sklearn: a row without a value stays NaN)
             out[i * ld + j] = o;
         }
 }
@@ -136,6 +156,7 @@ extern "C" int skm_pairwise_f64(skm_ctx *ctx, int metric, double p, int64_t n, i
 {
     SKM_REQUIRE(ctx && n >= 0 && m >= 0 && k >= 1 && ldx >= k && ldy >= k && ld >= m, SKM_E_BADARG, "skm_pairwise_f64: bad argument");
     SKM_REQUIRE(metric != M_MINKOWSKI || p > 0.0, SKM_E_BADARG, "skm_pairwise_f64: minkowski needs p > 0");
+    SKM_REQUIRE(metric != M_HAVERSINE || k == 2, SKM_E_BADARG, "skm_pairwise_f64: haversine needs exactly two columns");
     if (n == 0 || m == 0)
         return SKM_OK;
     SKM_REQUIRE(d_x && d_y && d_out, SKM_E_BADARG, "skm_pairwise_f64: null array");
@@ -155,6 +176,8 @@ extern "C" int skm_pairwise_f64(skm_ctx *ctx, int metric, double p, int64_t n, i
         SKM_PW(M_CANBERRA);
         SKM_PW(M_BRAYCURTIS);
         SKM_PW(M_MINKOWSKI);
+        SKM_PW(M_NAN_EUCLIDEAN);
+        SKM_PW(M_HAVERSINE);
         SKM_PW(M_DICE);
         SKM_PW(M_ROGERSTANIMOTO);
         SKM_PW(M_RUSSELLRAO);

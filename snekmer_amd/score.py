@@ -245,7 +245,7 @@ SKLEARN_METRICS = ("braycurtis", "canberra", "chebyshev", "cityblock", "correlat
 
 # metric name -> id of skm_pairwise_f64 (include/snekmer_hip.h)
 PAIRWISE_METRICS = {"cityblock": 0, "manhattan": 0, "l1": 0, "sqeuclidean": 1, "euclidean": 2, "l2": 2, "chebyshev": 3, "canberra": 4,
-                    "braycurtis": 5, "minkowski": 6, "dice": 10, "rogerstanimoto": 11, "russellrao": 12, "sokalmichener": 13,
+                    "braycurtis": 5, "minkowski": 6, "nan_euclidean": 7, "haversine": 8, "dice": 10, "rogerstanimoto": 11, "russellrao": 12, "sokalmichener": 13,
                     "sokalsneath": 14, "yule": 15}
 
 
@@ -261,13 +261,34 @@ def pairwise_distances(X, metric: str = "euclidean", p: float = 2.0, ctx=None) -
     device kernel on the transformed rows (`_whole_matrix_metric`): "correlation" = cosine distance of the row-centred
     matrix, "seuclidean" = euclidean after dividing every column by its standard deviation (V = var(X, ddof=1), what
     sklearn passes to scipy), "mahalanobis" = euclidean after X -> X L with L L^T = VI = inv(cov(X^T))^T.  The rest of
-    scikit-learn's names ("haversine", "nan_euclidean", "precomputed", "wminkowski", the true "jaccard" through this
-    function) raise NotImplementedError - no Snekmer rule passes them -, a name scikit-learn does not know raises its
-    ValueError."""
+    scikit-learn's names raise NotImplementedError - no Snekmer rule passes them -, a name scikit-learn does not know raises
+    its ValueError.
+
+    Round 5: "nan_euclidean" (NaN entries allowed: sklearn's nan_euclidean_distances, the squared distance over the columns
+    present in both rows scaled to all columns, NaN where no column is), "haversine" (exactly two columns, radians) and
+    "precomputed" (the matrix itself after scikit-learn's checks: square, no negative value) are implemented too; what
+    still raises NotImplementedError is "wminkowski" (gone from scipy), the true "jaccard" through this function, and
+    callables (a Python function per pair of rows has no device form)."""
     import ctypes as C
 
     from . import _hip
 
+    if callable(metric):
+        raise NotImplementedError("a callable metric is a Python function per pair of rows: it has no device form; "
+                                  "call sklearn.metrics.pairwise_distances for it")
+    if metric == "precomputed":
+        # sklearn: check_pairwise_arrays(precomputed=True) + check_non_negative, then the matrix itself
+        A = _plain(X)
+        if hasattr(A, "toarray"):
+            A = A.toarray()
+        A = np.asarray(A, dtype=np.float64)
+        if A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError(f"Precomputed metric requires shape (n_queries, n_indexed). Got {A.shape} for {A.shape[0] if A.ndim else 0} indexed.")
+        if not np.all(np.isfinite(A)):
+            raise ValueError("Input contains NaN or infinity.")
+        if A.size and A.min() < 0:
+            raise ValueError("Negative values in data passed to `pairwise_distances`. Precomputed distance  need to have non-negative values.")
+        return A.copy()
     if metric == "cosine":
         return cosine_similarity(X, None, mode=1, ctx=ctx)
     if metric in ("hamming", "matching"):
@@ -290,11 +311,16 @@ def pairwise_distances(X, metric: str = "euclidean", p: float = 2.0, ctx=None) -
     A = np.ascontiguousarray(np.asarray(A), dtype=np.float64)
     if A.ndim != 2:
         raise ValueError("expected a 2-D feature matrix")
-    if not np.all(np.isfinite(A)):
+    if metric == "nan_euclidean":
+        if np.any(np.isinf(A)):
+            raise ValueError("Input contains infinity or a value too large for dtype('float64').")
+    elif not np.all(np.isfinite(A)):
         raise ValueError("Input contains NaN or infinity.")
     n, k = A.shape
     if k == 0:
         raise ValueError("feature matrix has no columns")
+    if metric == "haversine" and k != 2:
+        raise ValueError("Haversine distance only valid in 2 dimensions")
     if n == 0:
         return np.zeros((0, 0), dtype=np.float64)
     dx = ctx.to_device(A)

@@ -318,6 +318,13 @@ def score_round(ctx, seed):
 
     metric = sorted(PAIRWISE_METRICS)[int(rng.integers(0, len(PAIRWISE_METRICS)))]
     Xm = Xf if rng.random() < 0.5 else X.astype(np.float64)
+    if metric == "haversine":  # two columns of radians
+        Xm = np.stack([rng.uniform(-np.pi / 2, np.pi / 2, len(Xm)), rng.uniform(-np.pi, np.pi, len(Xm))], axis=1)
+    elif metric == "nan_euclidean":  # missing values, now and then a row without any
+        Xm = Xm.copy()
+        Xm[rng.random(Xm.shape) < 0.25] = np.nan
+        if len(Xm) and rng.random() < 0.3:
+            Xm[int(rng.integers(0, len(Xm)))] = np.nan
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         want = pairwise_distances(Xm, metric=metric)

@@ -606,7 +606,7 @@ def test_connection_matrix_other_sklearn_metrics_match_sklearn(ctx):
     counts[9] = counts[8]
     real = rng.normal(size=(130, 37)) * (rng.random((130, 37)) < 0.7)
     for X in (counts, real, counts[:1], real[:, :1]):
-        for metric in sorted(PAIRWISE_METRICS) + ["hamming", "matching", "cosine"]:
+        for metric in sorted(set(PAIRWISE_METRICS) - {"haversine"}) + ["hamming", "matching", "cosine"]:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")  # sklearn's bool-conversion notice, scipy's 0/0
                 want = pairwise_distances(X, metric=metric)
@@ -639,8 +639,36 @@ def test_connection_matrix_other_sklearn_metrics_match_sklearn(ctx):
             assert np.nanmax(np.abs(got - want), initial=0.0) <= 1e-10 * max(1.0, float(np.nanmax(np.abs(want), initial=0.0))), (metric, X.shape)
     with pytest.raises(np.linalg.LinAlgError):
         skm.score.connection_matrix_from_features(np.hstack([tall, tall[:, :1]]), metric="mahalanobis")  # singular covariance
+    # round 5: the rest of scikit-learn's names.  nan_euclidean with missing values (a row without any, a pair of rows with no
+    # column in common -> NaN), haversine (two columns of radians; anything else is scikit-learn's ValueError), precomputed
+    holes = real.copy()
+    holes[rng.random(holes.shape) < 0.3] = np.nan
+    holes[5] = np.nan
+    holes[6, ::2] = np.nan
+    holes[7] = 1.0
+    holes[7, 1::2] = np.nan
+    want = pairwise_distances(holes, metric="nan_euclidean")
+    got = skm.score.connection_matrix_from_features(holes, metric="nan_euclidean")
+    assert (np.isnan(got) == np.isnan(want)).all() and np.isnan(want).any() and np.nanmax(np.abs(got - want)) <= 1e-12 * np.nanmax(want)
+    geo = np.stack([rng.uniform(-np.pi / 2, np.pi / 2, 97), rng.uniform(-np.pi, np.pi, 97)], axis=1)
+    geo[3] = geo[2]
+    want = pairwise_distances(geo, metric="haversine")
+    got = skm.score.connection_matrix_from_features(geo, metric="haversine")
+    assert np.abs(got - want).max() <= 1e-12 and (np.diag(got) == 0).all()
+    for bad in (real, real[:, :1]):
+        with pytest.raises(ValueError):
+            skm.score.connection_matrix_from_features(bad, metric="haversine")
+        with pytest.raises(ValueError):
+            pairwise_distances(bad, metric="haversine")
+    D = pairwise_distances(real[:40], metric="euclidean")
+    assert (skm.score.connection_matrix_from_features(D, metric="precomputed") == pairwise_distances(D, metric="precomputed")).all()
+    for bad in (real, -D):  # not square; negative values
+        with pytest.raises(ValueError):
+            skm.score.connection_matrix_from_features(bad, metric="precomputed")
+        with pytest.raises(ValueError):
+            pairwise_distances(bad, metric="precomputed")
     with pytest.raises(NotImplementedError):
-        skm.score.connection_matrix_from_features(counts, metric="nan_euclidean")
+        skm.score.connection_matrix_from_features(counts, metric=lambda a, b: 0.0)
     with pytest.raises(ValueError):
         skm.score.connection_matrix_from_features(counts, metric="jensenshannon")
     with pytest.raises(ValueError):
