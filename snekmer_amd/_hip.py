@@ -29,6 +29,13 @@ class P2POp(C.Structure):
                 ("recv_off", C.c_int64), ("recv_bytes", C.c_int64)]
 
 
+def under_profiler() -> bool:
+    """True when a rocprofiler tool library is loaded into this process (rocprofv3 ... -- python3 ...).  Replaying a HIP graph
+    under rocprofv3 --kernel-trace crashed inside the tool on ROCm 7.2 (hipGraphLaunch -> segmentation fault in the
+    profiler's callback), so engine.Pipeline does not capture or replay graphs there."""
+    return any("rocprof" in os.environ.get(v, "") for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+
+
 class HipUnavailable(RuntimeError):
     """The HIP extension (or a GPU) is not available; there is no CPU fallback."""
 

@@ -21,6 +21,9 @@
 #ifndef SKM_OS_LB
 #define SKM_OS_LB 8
 #endif
+#ifndef SKM_OS_LARGE_TB
+#define SKM_OS_LARGE_TB 512  // (29 M pairs, 4 passes: 1024 x 8 0.99 ms, 512 x 8 0.89, 256 x 8 1.13; rocPRIM 0.85)
+#endif
 #ifndef SKM_OS_SMALL_LOG2
 #define SKM_OS_SMALL_LOG2 22
 #endif
@@ -268,7 +271,7 @@ static inline size_t state_bytes(int64_t cap, int tile, int passes)
 static inline size_t sort_state_bytes(int64_t cap, int key_bits)
 {
     const int passes = (key_bits + RADIX_BITS - 1) / RADIX_BITS;
-    return state_bytes(cap, cap <= ((int64_t)1 << SKM_OS_SMALL_LOG2) ? 256 * 8 : 1024 * 8, passes);
+    return state_bytes(cap, cap <= ((int64_t)1 << SKM_OS_SMALL_LOG2) ? 256 * 8 : SKM_OS_LARGE_TB * 8, passes);
 }
 
 // Stable sort of the first *d_n (<= cap < 2^30) keys of `kin` with payload = index; result in kout / vout.  ktmp / vtmp:
@@ -284,7 +287,7 @@ static int sort_pairs_dev(skm_ctx *ctx, const int64_t *d_n, int64_t cap, const K
     // small inputs: 256-thread tiles of 2048 keys (more tiles in flight: the passes are latency-bound there);
     // large ones: 1024 x 8 (the shape rocPRIM's tuning also prefers on this chip)
     const bool small = cap <= ((int64_t)1 << SKM_OS_SMALL_LOG2);
-    const int tile = small ? 256 * 8 : 1024 * 8;
+    const int tile = small ? 256 * 8 : SKM_OS_LARGE_TB * 8;
     const int64_t ntiles = (cap + tile - 1) / tile + 1;
     state_header *st = (state_header *)d_state;
     uint32_t *tile_state = (uint32_t *)((uint8_t *)d_state + sizeof(state_header));
@@ -322,9 +325,9 @@ static int sort_pairs_dev(skm_ctx *ctx, const int64_t *d_n, int64_t cap, const K
                 SKM_OS_PASS(256, false);
         } else {
             if (p == 0)
-                SKM_OS_PASS(1024, true);
+                SKM_OS_PASS(SKM_OS_LARGE_TB, true);
             else
-                SKM_OS_PASS(1024, false);
+                SKM_OS_PASS(SKM_OS_LARGE_TB, false);
         }
 #undef SKM_OS_PASS
 #undef SKM_OS_PASS_NT

@@ -741,7 +741,7 @@ class Pipeline:
     def _graph_key(self, batch: SeqBatch):
         import os
 
-        if self.graphs is False or getattr(self.ctx, "profiling", False) or batch.ctx is not self.ctx:
+        if self.graphs is False or getattr(self.ctx, "profiling", False) or batch.ctx is not self.ctx or _hip.under_profiler():
             return None
         if not self.fused or self.post32 or batch.n < 1 or batch.total < 1 or batch.max_len < 1:
             return None  # (those forms wait for the device inside the step)
