@@ -128,7 +128,7 @@ static inline int skm_grid_cap(const skm_ctx *ctx, int64_t want, int per_cu = 8)
 // (tools/small_batch_gap.py, red6 k=12, 4 digits): the library's own one-sweep sort (skm_onesweep.h: 6 launches, sized
 // by the device-side entry count) takes 0.078 / 0.122 ms for 0.3 / 1.0 M pairs where rocPRIM's Onesweep (~17 stream
 // operations) takes 0.119 / 0.160; from 3 M pairs on rocPRIM's passes are faster (0.16 vs 0.24 ms at 3 M, 0.85 vs 1.12 ms
-// at 29 M: its tuned ranking moves 2.6 TB/s per pass, ours 1.7).  So: ours up to 2^21 pairs - every single-file job of
+// at 29 M: its tuned ranking moves 2.6 TB/s per pass, ours 1.7).  So: ours up to 1.3 M pairs (round 5; 2^21 in round 4) - every single-file job of
 // the reference, snekmer/rules/kmerize.smk:57-65 - rocPRIM above.  SKM_SORT=rocprim / onesweep force one (A/B timing).
 static inline bool skm_use_onesweep(int64_t cap)
 {
@@ -137,7 +137,8 @@ static inline bool skm_use_onesweep(int64_t cap)
         return false;
     if (e && strcmp(e, "onesweep") == 0)
         return cap < ((int64_t)1 << 30);
-    return cap <= ((int64_t)1 << 21);
+    return cap <= ((int64_t)5 << 18);  // 1.3 M pairs (round 5, ms per sort, own / rocPRIM: 0.3 M 0.058 / 0.120, 0.6 M 0.081 / 0.144,
+                                       // 1.05 M 0.096 / 0.162, 1.45 M 0.136 / 0.118, 2.0 M 0.170 / 0.129)
 }
 
 // Stage functions shared by the fused entry point skm_vectorize_csr (skm_api.hip would be the natural home; they
