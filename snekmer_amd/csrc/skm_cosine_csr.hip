@@ -60,6 +60,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SKM_FIRST_GH
 #define SKM_FIRST_GH 2048
 #endif
+#ifndef SKM_WRITER_CH
+#define SKM_WRITER_CH 32768
+#endif
+#ifndef SKM_WRITER_TB
+#define SKM_WRITER_TB 1024
+#endif
 constexpr uint32_t G_DONE_ROW = 0xFFFFFFFEu;  // g_len of a row k_cosine_heavy has already written
 constexpr uint32_t G_WIDE_ROW = 0xFFFFFFFDu;  // g_len of a row whose dot products may exceed int32 (skm_row_is_wide)
 
@@ -1615,7 +1621,7 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
 #define SKM_WRITE(MODE, VEC)                                                                                         \
     do {                                                                                                             \
         if (m >= 65536) /* wide rows: 128 KiB per step (fewer barriers, longer bursts: 6.9 vs 7.2 ms at m = 100k) */ \
-            k_cosine_write<MODE, VEC, 32768, 1024><<<(unsigned)bn, 1024, 0, s_w>>>(                                  \
+            k_cosine_write<MODE, VEC, SKM_WRITER_CH, SKM_WRITER_TB><<<(unsigned)bn, SKM_WRITER_TB, 0, s_w>>>(        \
                 g_ent, g_start, g_len, d_xrnorm, d_yrnorm, m, row0, b0, d_out, ld, fb_list, fb_count, fb_flag,       \
                 wide_list, &state->wide_count);                                                                      \
         else                                                                                                         \

@@ -275,126 +275,10 @@ __global__ __launch_bounds__(256) void k_cosine_dense_i8_v2(int64_t n, int64_t m
 }
 
 
-// ------------------------------------------------------------------------------- i8 MFMA cosine, v3
-// 256 x 256 output tile, 8 waves (2 x 4, 128 x 64 per wave = 4 x 2 MFMA tiles), otherwise the v2
-// structure (LDS-DMA, 2 stages of 64 KiB, swizzled 128-byte rows).  A 128 x 128 tile moves
-// 32 KiB through L2 per 4.2 Mop, which at the i8 MFMA rate is ~39 TB/s chip-wide, above what L2
-// delivers; the 256 x 256 tile halves that and is the shape that can approach the matrix-core rate.
+// ------------------------------------------------------------------------------- 256 x 256 tiles
+// (round 1's lock-step 256 x 256 kernel, "v3", and the row-major staging of v4 were removed in round 5: v5 / v4 from tiled
+// operand copies cover every shape they served; their A/B numbers are in profiles/r02_dense_mfma.json and r04_dense_mfma.json)
 constexpr int BM3 = 256, BN3 = 256;
-constexpr int STAGE3_BYTES = (BM3 + BN3) * BK2;  // 64 KiB
-
-template <int MODE, int ABL = 0>  // ABL (SKM_DIAG only, results invalid): 3 no MFMA
-__global__ __launch_bounds__(512) void k_cosine_dense_i8_v3(int64_t n, int64_t m, int64_t kdim,
-                                                            const int8_t *__restrict__ X,
-                                                            const int8_t *__restrict__ Y,
-                                                            const float *__restrict__ xr,
-                                                            const float *__restrict__ yr, float *__restrict__ out,
-                                                            int64_t ld)
-{
-    __shared__ __attribute__((aligned(16))) int8_t s_t[2 * STAGE3_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid >> 2, wc = wid & 3;
-    // XCD-aware tile order (speed only).  Workgroups b, b+8, ... share an XCD and its L2; give each
-    // XCD a contiguous run of tiles ordered by 4 x 8 "supertiles", so that the ~32 workgroups
-    // resident on an XCD stream the same 4 row panels and 8 column panels in K lock-step.
-    const int64_t nty = (n + BM3 - 1) / BM3, ntx = (m + BN3 - 1) / BN3;
-    const int64_t nsx = (ntx + 7) / 8;
-    const int64_t nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
-    const int64_t seq = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
-    const int64_t st = seq / 32, within = seq % 32;
-    const int64_t ty = (st / nsx) * 4 + within / 8, tx = (st % nsx) * 8 + within % 8;
-    if (ty >= nty || tx >= ntx)
-        return;
-    const int64_t row0 = ty * BM3, col0 = tx * BN3;
-
-    i32x16 acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[a][b][r] = 0;
-
-    const int srow = lane >> 3, schunk = lane & 7;
-    auto stage = [&](int buf, int64_t k0) {
-        int8_t *sa = s_t + buf * STAGE3_BYTES, *sb = sa + BM3 * BK2;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = wid * 32 + q * 8 + srow;
-            const int src_chunk = schunk ^ ((r >> 1) & 7);
-            const int64_t gi = min(row0 + r, n - 1), gj = min(col0 + r, m - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(X + gi * kdim + k0 + src_chunk * 16),
-                                             (__attribute__((address_space(3))) void *)(sa + (wid * 32 + q * 8) * BK2), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Y + gj * kdim + k0 + src_chunk * 16),
-                                             (__attribute__((address_space(3))) void *)(sb + (wid * 32 + q * 8) * BK2), 16, 0, 0);
-        }
-    };
-
-    const int fr = lane & 31, fh = lane >> 5;
-    const int64_t nsteps = kdim / BK2;
-    stage(0, 0);
-    for (int64_t s = 0; s < nsteps; ++s) {
-        const int buf = (int)(s & 1);
-        __builtin_amdgcn_s_barrier();
-        if (s + 1 < nsteps) {
-            stage(buf ^ 1, (s + 1) * BK2);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        const int8_t *sa = s_t + buf * STAGE3_BYTES, *sb = sa + BM3 * BK2;
-#pragma unroll
-        for (int ks = 0; ks < BK2 / 32; ++ks) {
-            i32x4 fa[4], fb[2];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int ra = wr * 128 + t * 32 + fr;
-                fa[t] = *reinterpret_cast<const i32x4 *>(sa + ra * BK2 + (((ks * 2 + fh) ^ ((ra >> 1) & 7)) * 16));
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int rb = wc * 64 + t * 32 + fr;
-                fb[t] = *reinterpret_cast<const i32x4 *>(sb + rb * BK2 + (((ks * 2 + fh) ^ ((rb >> 1) & 7)) * 16));
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    if (ABL != 3)
-                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
-                    else
-                        asm volatile("" ::"v"(fa[a]), "v"(fb[b]));
-                }
-        }
-    }
-
-    const int ccol = lane & 31, chalf = lane >> 5;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int64_t j = col0 + wc * 64 + b * 32 + ccol;
-            const float rj = j < m ? yr[j] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t i = row0 + wr * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * chalf;
-                if (i < n && j < m) {
-                    float o = (float)acc[a][b][r] * xr[i] * rj;
-                    if (MODE == 1) {
-                        o = fminf(fmaxf(1.0f - o, 0.0f), 2.0f);
-                        if (i == j)
-                            o = 0.0f;
-                    }
-                    out[i * ld + j] = o;
-                }
-            }
-        }
-    }
-}
-
-
 
 // Row-major int8 [rows x kdim] -> the tiled image k_cosine_dense_i8_v4<.., TILED> stages from (see there).
 // One thread per 16 bytes; rows are padded with zeros to a multiple of 256.
@@ -436,13 +320,12 @@ constexpr int BK4 = 64;
 constexpr int NSLOT4 = 4;
 constexpr int SLOT4_BYTES = (BM3 + BN3) * BK4;  // 32 KiB
 
-// TILED: the operands were re-laid out by k_retile_i8 so that the 16 rows x 64 B one LDS-DMA instruction lands are
+// The operands were re-laid out by k_retile_i8 so that the 16 rows x 64 B one LDS-DMA instruction lands are
 // 1 KiB of CONTIGUOUS global memory in exactly the LDS image (swizzle included), K stage major: piece (stage s, row
 // block rb) at ((s * nrb + rb) * 1024).  From row-major operands the same instruction touches 16 half lines (one
 // 64-byte L2 request each, 2.1e9 per launch at N = 32 768, K = 16 384: the kernel's bound, section 5.2 of
 // DESIGN.md); from the tiled image it reads 8 whole lines.  Rows past n / m are zero in the image (no clamping).
-// ABL (SKM_DIAG builds only; results invalid): 1 no staging inside the K loop, 2 fragments read once, 3 no MFMA
-template <int MODE, bool SYM, int ABL = 0, bool TILED = false>
+template <int MODE, bool SYM>
 __global__ __launch_bounds__(512) void k_cosine_dense_i8_v4(int64_t n, int64_t m, int64_t kdim,
                                                             const int8_t *__restrict__ X,
                                                             const int8_t *__restrict__ Y,
@@ -492,33 +375,18 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v4(int64_t n, int64_t m
     // staging: one LDS-DMA instruction lands 16 rows x 64 B linearly (lane l -> row l / 4, 16-byte chunk l % 4);
     // the XOR swizzle lives on the SOURCE chunk and on the fragment reads (same involution).  A wave stages
     // rows [32 w, 32 w + 32) of both operands: four instructions per stage, piece p = 0..3 (A q0, B q0, A q1, B q1).
-    const int srow = lane >> 2, schunk = lane & 3;
     auto stage_piece = [&](int slot, int64_t k0, int p) {
         int8_t *sa = s_t + slot * SLOT4_BYTES, *sb = sa + BM3 * BK4;
         const int q = p >> 1;
-        if (TILED) {
-            const int64_t nrbx = (n + BM3 - 1) / BM3 * (BM3 / 16), nrby = (m + BN3 - 1) / BN3 * (BN3 / 16);
-            const int64_t sidx = k0 / BK4;
-            if ((p & 1) == 0) {
-                const int64_t rb = row0 / 16 + wid * 2 + q;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(X + ((sidx * nrbx + rb) * 64 + lane) * 16),
-                                                 (__attribute__((address_space(3))) void *)(sa + (wid * 32 + q * 16) * BK4), 16, 0, 0);
-            } else {
-                const int64_t rb = col0 / 16 + wid * 2 + q;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Y + ((sidx * nrby + rb) * 64 + lane) * 16),
-                                                 (__attribute__((address_space(3))) void *)(sb + (wid * 32 + q * 16) * BK4), 16, 0, 0);
-            }
-            return;
-        }
-        const int r = wid * 32 + q * 16 + srow;
-        const int src_chunk = schunk ^ ((r >> 2) & 3);
+        const int64_t nrbx = (n + BM3 - 1) / BM3 * (BM3 / 16), nrby = (m + BN3 - 1) / BN3 * (BN3 / 16);
+        const int64_t sidx = k0 / BK4;
         if ((p & 1) == 0) {
-            const int64_t gi = min(row0 + r, n - 1);  // clamp: masked in the epilogue
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(X + gi * kdim + k0 + src_chunk * 16),
+            const int64_t rb = row0 / 16 + wid * 2 + q;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(X + ((sidx * nrbx + rb) * 64 + lane) * 16),
                                              (__attribute__((address_space(3))) void *)(sa + (wid * 32 + q * 16) * BK4), 16, 0, 0);
         } else {
-            const int64_t gj = min(col0 + r, m - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Y + gj * kdim + k0 + src_chunk * 16),
+            const int64_t rb = col0 / 16 + wid * 2 + q;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Y + ((sidx * nrby + rb) * 64 + lane) * 16),
                                              (__attribute__((address_space(3))) void *)(sb + (wid * 32 + q * 16) * BK4), 16, 0, 0);
         }
     };
@@ -542,7 +410,7 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v4(int64_t n, int64_t m
     for (int64_t s = 0; s < nst; ++s) {
         // ---- LOAD interval: fragments of stage s into registers
         const int8_t *sa = s_t + (int)(s & 3) * SLOT4_BYTES, *sb = sa + BM3 * BK4;
-        if (ABL != 2 || s == 0) {
+        {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -569,7 +437,7 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v4(int64_t n, int64_t m
         // ---- COMPUTE interval: 16 MFMAs on registers, the four staging instructions of stage s+3 (into the
         // slot of stage s-1) issued between them: an LDS-DMA instruction costs ~60 cycles among MFMAs and
         // 100-185 next to fragment reads, and the LOAD interval is the longer one
-        const bool more = ABL != 1 && s + 3 < nst;
+        const bool more = s + 3 < nst;
         const int nslot = (int)((s + 3) & 3);
         const int64_t nk0 = (s + 3) * BK4;
         __builtin_amdgcn_s_setprio(1);
@@ -579,10 +447,7 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v4(int64_t n, int64_t m
             for (int a = 0; a < 4; ++a) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    if (ABL != 3)
-                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a][ks], fb[b][ks], acc[a][b], 0, 0, 0);
-                    else
-                        asm volatile("" ::"v"(fa[a][ks]), "v"(fb[b][ks]));
+                    acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a][ks], fb[b][ks], acc[a][b], 0, 0, 0);
                 }
                 if ((a & 1) == 1) {  // after every fourth MFMA
                     __builtin_amdgcn_sched_barrier(0);
@@ -1218,20 +1083,17 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
                     1.0 / h[0], 1.0 / h[1]);
     }
     dim3 grid((unsigned)skm_ceil_div(m, BN), (unsigned)skm_ceil_div(n, BM));
-    // SKM_DENSE_VARIANT (all variants exact; for A/B timing): 1 register-staged kernel, 2 128x128 LDS-DMA kernel,
-    // 3 the 256x256 lock-step kernel, 4 the staggered kernel (default where it applies), 5 staggered without symmetry
+    // SKM_DENSE_VARIANT (all variants exact; A/B timing and the tests of the kernels the default route does not pick at a
+    // shape): 1 the register-staged 128 x 128 kernel, 2 the 128 x 128 LDS-DMA kernel, 6 / 7 v4 (256 x 256, staggered wave
+    // groups, both operands through LDS from tiled copies) with / without the symmetric form, 10 / 11 v5 (A through LDS, B
+    // straight into registers; the default where K % 256 == 0) with / without it.  Round 5 removed 3 (round 1's lock-step
+    // 256 x 256 kernel) and 4 / 5 (v4 staging from row-major operands).
     const char *v_env = getenv("SKM_DENSE_VARIANT");
     const int forced0 = v_env ? atoi(v_env) : 0;
-    const int forced = forced0 == 5 ? 4 : forced0;
-    const bool v2 = kdim % BK2 == 0 && forced != 1;
-    const bool v3 = v2 && forced != 2 && n >= 1024 && m >= 1024;
-    // v4 (staggered wave groups, 64-byte K stages; symmetric form when X is Y): the default for large problems
-    // 6: v4 staging from tiled operand copies, 7: the same without symmetry
-    // 10: v5 (1 x 8 waves, B straight into registers from a lane-order image; the default where K % 256 == 0), 11: the
-    // same without symmetry
+    const bool v2 = kdim % BK2 == 0 && forced0 != 1;
     const bool v4 = kdim % BK4 == 0 && kdim >= 4 * BK4 && n >= 1024 && m >= 1024 &&
-                    (forced == 0 || forced == 4 || forced0 == 6 || forced0 == 7 || forced0 == 10 || forced0 == 11);
-    const bool sym = d_x == d_y && n == m && d_xrnorm == d_yrnorm && forced0 != 5 && forced0 != 7 && forced0 != 11;
+                    (forced0 == 0 || forced0 == 6 || forced0 == 7 || forced0 == 10 || forced0 == 11);
+    const bool sym = d_x == d_y && n == m && d_xrnorm == d_yrnorm && forced0 != 7 && forced0 != 11;
     SKM_PROF(ctx, "k_cosine_dense_i8");
     if (v4) {
         const int64_t nsy4 = skm_ceil_div(skm_ceil_div(n, BM3), 4), nsx4 = skm_ceil_div(skm_ceil_div(m, BN3), 8);
@@ -1243,18 +1105,6 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
         }
         SKM_REQUIRE(supertiles * 32 < ((int64_t)1 << 31), SKM_E_OVERFLOW, "skm_cosine_dense_i8: too many tiles");
         dim3 grid4((unsigned)(supertiles * 32));
-#ifdef SKM_DIAG
-        const char *ab_env = getenv("SKM_DENSE_ABLATE");  // timing-only builds, results NOT valid
-        const int dabl = ab_env ? atoi(ab_env) : 0;
-        if (dabl == 1)
-            k_cosine_dense_i8_v4<0, false, 1><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
-        else if (dabl == 2)
-            k_cosine_dense_i8_v4<0, false, 2><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
-        else if (dabl == 3)
-            k_cosine_dense_i8_v4<0, false, 3><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
-        if (dabl >= 1 && dabl <= 3)
-            return skm_check_launch("k_cosine_dense_i8");
-#endif
         // default where K is a multiple of 256: v5 (SKM_DENSE_VARIANT=10; 11 the same without symmetry)
         if ((forced0 == 0 || forced0 == 10 || forced0 == 11) && kdim % (4 * BK4) == 0) {
             const int64_t nrbx = skm_ceil_div(n, BM3) * (BM3 / 16), ncb = skm_ceil_div(m, BN3) * (BN3 / 32);
@@ -1332,9 +1182,8 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
 #undef SKM_V5
             return skm_check_launch("k_cosine_dense_i8");
         }
-        // otherwise v4 staging from a tiled copy of the operands (SKM_DENSE_VARIANT=4 / 5 keep the row-major form, for A/B)
-        if (forced0 == 0 || forced0 == 6 || forced0 == 7 || forced0 == 10 || forced0 == 11) {
-            const bool sym6 = sym;
+        // otherwise (K a multiple of 64 only, or forced): v4 staging from tiled copies of the operands
+        {
             const int64_t nrbx = skm_ceil_div(n, BM3) * (BM3 / 16), nrby = skm_ceil_div(m, BN3) * (BN3 / 16);
             void *p;
             SKM_TRY(skm_ws(ctx, WS_K, (size_t)nrbx * 16 * (size_t)kdim, &p));
@@ -1347,14 +1196,14 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
             }
             SKM_TRY(skm_check_launch("k_retile_i8"));
 #define SKM_V4T(MODE, SYM) \
-    k_cosine_dense_i8_v4<MODE, SYM, 0, true><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, xt, yt, d_xrnorm, d_yrnorm, d_out, ld)
+    k_cosine_dense_i8_v4<MODE, SYM><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, xt, yt, d_xrnorm, d_yrnorm, d_out, ld)
             if (mode == 0) {
-                if (sym6)
+                if (sym)
                     SKM_V4T(0, true);
                 else
                     SKM_V4T(0, false);
             } else {
-                if (sym6)
+                if (sym)
                     SKM_V4T(1, true);
                 else
                     SKM_V4T(1, false);
@@ -1362,35 +1211,6 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
 #undef SKM_V4T
             return skm_check_launch("k_cosine_dense_i8");
         }
-#define SKM_V4(MODE, SYM) \
-    k_cosine_dense_i8_v4<MODE, SYM><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld)
-        if (mode == 0) {
-            if (sym)
-                SKM_V4(0, true);
-            else
-                SKM_V4(0, false);
-        } else {
-            if (sym)
-                SKM_V4(1, true);
-            else
-                SKM_V4(1, false);
-        }
-#undef SKM_V4
-    } else if (v3) {
-        // padded to whole 4 x 8 supertiles; workgroups that fall outside the matrix exit at once
-        const int64_t nsy3 = skm_ceil_div(skm_ceil_div(n, BM3), 4), nsx3 = skm_ceil_div(skm_ceil_div(m, BN3), 8);
-        SKM_REQUIRE(nsy3 * nsx3 * 32 < ((int64_t)1 << 31), SKM_E_OVERFLOW, "skm_cosine_dense_i8: too many tiles");
-        dim3 grid3((unsigned)(nsy3 * nsx3 * 32));
-#ifdef SKM_DIAG
-        if (getenv("SKM_DENSE_ABLATE") && atoi(getenv("SKM_DENSE_ABLATE")) == 3) {
-            k_cosine_dense_i8_v3<0, 3><<<grid3, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
-            return skm_check_launch("k_cosine_dense_i8");
-        }
-#endif
-        if (mode == 0)
-            k_cosine_dense_i8_v3<0><<<grid3, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
-        else
-            k_cosine_dense_i8_v3<1><<<grid3, 512, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
     } else if (v2) {
         if (mode == 0)
             k_cosine_dense_i8_v2<0><<<grid, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the dense i8 MFMA cosine variants (SKM_DENSE_VARIANT) in one process, interleaved rounds.
-usage: ab_dense.py [alphabet k n]   also checks every variant against variant 3 bit for bit"""
+usage: ab_dense.py [alphabet k n]   also checks every variant against the first one bit for bit"""
 import os
 import sys
 
@@ -15,17 +15,12 @@ k = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 32768
 lut = alphabet.build_lut(name)
 res, off, _ = synth_families(n, 300, family=100, seed=BASE_SEED + 6)
-variants = {"3 lock-step": "3", "5 staggered, full": "5", "4 staggered, symmetric": "4",
-            "7 staggered, tiled operands, full": "7", "6 staggered, tiled operands, symmetric": "6",
+# (round 5 removed variants 3 - the lock-step kernel -, 4 / 5 - v4 from row-major operands - and the timing-only ablations
+# of v4 / v3 from the library: their numbers are in profiles/r02_dense_mfma.json and profiles/r04_dense_mfma.json)
+variants = {"7 v4 staggered, tiled operands, full": "7", "6 v4 staggered, tiled operands, symmetric": "6",
             "11 v5 1x8 waves, B in registers, full": "11", "10 v5 1x8 waves, B in registers, symmetric": "10"}
-SYMMETRIC = ("4", "6", "10")
+SYMMETRIC = ("6", "10")
 ABL = {}
-if os.environ.get("SKM_AB_DIAG") == "1":  # needs libsnekmer_hip_diag.so (make diag); ablated runs give invalid results
-    _hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "libsnekmer_hip_diag.so")
-    variants.update({"5 ablate: no staging in loop": "5", "5 ablate: fragments read once": "5", "5 ablate: no MFMA": "5",
-                     "3 ablate: no MFMA": "3"})
-    ABL = {"5 ablate: no staging in loop": "1", "5 ablate: fragments read once": "2", "5 ablate: no MFMA": "3",
-           "3 ablate: no MFMA": "3"}
 ctx = _hip.Context(0)
 batch = engine.SeqBatch(ctx, res, off)
 pipe = engine.DensePipeline(ctx, lut, k)
