@@ -1271,7 +1271,20 @@ int heavy_panels_run(skm_ctx *ctx, const int64_t *d_xrowptr, const uint32_t *d_x
                      hipStream_t st)
 {
     panel_bufs pb = {};
-    pb.nb = (int)std::min<int64_t>(skm_ceil_div(nrows, PB_ROWS), PB_MAXBLOCKS);
+    // Blocks: sized from the number of rows the PREVIOUS call on this context handed on (the same stale hint that switched
+    // the panels on: pinned memory, never waited for) plus a quarter, not from the call's row count - G alone is 16 MiB per
+    // block, and a 100 k-row call whose 4 096 heavy rows need 16 blocks reserved 391 of them (6.1 GiB per context, three
+    // contexts in engine.OverlappedPipeline).  Heavy rows beyond the blocks are walked in full: exact either way.
+    int64_t want_rows = nrows;
+    {
+        const volatile uint32_t *last = (const volatile uint32_t *)((uint8_t *)ctx->h_pinned + 2048);
+        uint64_t heavy = 0;
+        for (int b = 0; b < 16; ++b)
+            heavy += last[b];
+        if (heavy >= 4096u)  // (forced on without a hint - SKM_HEAVY_PANEL=1 on a first call -: the call's row count)
+            want_rows = std::min<int64_t>(nrows, (int64_t)(heavy + heavy / 4 + PB_ROWS));
+    }
+    pb.nb = (int)std::min<int64_t>(skm_ceil_div(want_rows, PB_ROWS), PB_MAXBLOCKS);
     pb.mwords = (uint32_t)((m + 31) / 32);
     const size_t hcap = (size_t)nrows + 8, nb = (size_t)pb.nb;
     // one scratch slot, carved up (every piece 256-byte aligned)
@@ -1288,7 +1301,14 @@ int heavy_panels_run(skm_ctx *ctx, const int64_t *d_xrowptr, const uint32_t *d_x
                  o_G = take(4 * nb * (size_t)PB_ROWS * PB_JMAX),
                  o_state = take(skm_onesweep::state_bytes((int64_t)hcap, 8192, 4) + skm_onesweep::state_bytes((int64_t)hcap, 2048, 4));
     void *p;
-    SKM_TRY(skm_ws(ctx, WS_G, off, &p));
+    {
+        const int rc_ws = skm_ws(ctx, WS_G, off, &p);
+        if (rc_ws == SKM_E_NOMEM) {  // the panels are an optimisation: without room for them every heavy row is walked
+            *out = panel_bufs{};
+            return SKM_E_NOMEM;
+        }
+        SKM_TRY(rc_ws);
+    }
     uint8_t *base = (uint8_t *)p;
     pb.key = (uint32_t *)(base + o_key);
     pb.skey = (uint32_t *)(base + o_skey);
@@ -1592,9 +1612,11 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
         bool use_panels = false;
         if constexpr (sizeof(PW) == 8) {
             if (nblk == 1 && panels_first) {
-                SKM_TRY(heavy_panels_run<PW>(ctx, d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, m, row0, b0, bn,
-                                             b_over_list, b_over_count, &pnl, s_w));
-                use_panels = true;
+                const int prc = heavy_panels_run<PW>(ctx, d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, m, row0, b0, bn,
+                                                     b_over_list, b_over_count, &pnl, s_w);
+                if (prc != SKM_E_NOMEM)  // (no room for the panels: every heavy row is walked, as exact as with them)
+                    SKM_TRY(prc);
+                use_panels = prc == SKM_OK;
             }
         }
         {
