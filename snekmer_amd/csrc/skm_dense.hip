@@ -279,6 +279,9 @@ __global__ __launch_bounds__(256) void k_cosine_dense_i8_v2(int64_t n, int64_t m
 // (round 1's lock-step 256 x 256 kernel, "v3", and the row-major staging of v4 were removed in round 5: v5 / v4 from tiled
 // operand copies cover every shape they served; their A/B numbers are in profiles/r02_dense_mfma.json and r04_dense_mfma.json)
 constexpr int BM3 = 256, BN3 = 256;
+#ifndef SKM_ST_W
+#define SKM_ST_W 8  // tiles per row of a supertile (4 rows x SKM_ST_W columns of tiles go to consecutive workgroups of one XCD)
+#endif
 
 // Row-major int8 [rows x kdim] -> the tiled image k_cosine_dense_i8_v4<.., TILED> stages from (see there).
 // One thread per 16 bytes; rows are padded with zeros to a multiple of 256.
@@ -337,28 +340,28 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v4(int64_t n, int64_t m
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 2, wc = wid & 3;
     const int64_t nty = (n + BM3 - 1) / BM3, ntx = (m + BN3 - 1) / BN3;
-    const int64_t nsx = (ntx + 7) / 8;
+    const int64_t nsx = (ntx + SKM_ST_W - 1) / SKM_ST_W;
     const int64_t nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
     const int64_t seq = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
-    int64_t st = seq / 32;
-    const int64_t within = seq % 32;
+    int64_t st = seq / (4 * SKM_ST_W);
+    const int64_t within = seq % (4 * SKM_ST_W);
     int64_t sy, sx;
     if (SYM) {
         // only the 4 x 8 supertiles that reach the diagonal or lie above it are enumerated (row sy keeps
         // columns sx >= sy / 2), so that every XCD's contiguous share of the grid holds the same amount of work
         sy = 0;
         for (;; ++sy) {
-            const int64_t cnt = nsx - sy / 2;
+            const int64_t cnt = nsx - sy / (SKM_ST_W / 4);
             if (st < cnt)
                 break;
             st -= cnt;
         }
-        sx = sy / 2 + st;
+        sx = sy / (SKM_ST_W / 4) + st;
     } else {
         sy = st / nsx;
         sx = st % nsx;
     }
-    const int64_t ty = sy * 4 + within / 8, tx = sx * 8 + within % 8;
+    const int64_t ty = sy * 4 + within / SKM_ST_W, tx = sx * SKM_ST_W + within % SKM_ST_W;
     if (ty >= nty || tx >= ntx || (SYM && ty > tx))
         return;
     const int64_t row0 = ty * BM3, col0 = tx * BN3;
@@ -587,29 +590,29 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v5(int64_t n, int64_t m
     __shared__ __attribute__((aligned(16))) int8_t s_t[NSLOT5 * SLOT5_BYTES];  // the ONLY shared object (128 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t nty = (n + BM3 - 1) / BM3, ntx = (m + BN3 - 1) / BN3;
-    const int64_t nsx = (ntx + 7) / 8;
+    const int64_t nsx = (ntx + SKM_ST_W - 1) / SKM_ST_W;
     const int64_t nwg = SPLIT ? gridDim.x / nsplit : gridDim.x;  // tile slots (a multiple of 32)
     const int64_t bid = SPLIT ? blockIdx.x % nwg : blockIdx.x;
     const int split = SPLIT ? (int)(blockIdx.x / nwg) : 0;
     const int64_t q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
     const int64_t seq = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
-    int64_t st = seq / 32;
-    const int64_t within = seq % 32;
+    int64_t st = seq / (4 * SKM_ST_W);
+    const int64_t within = seq % (4 * SKM_ST_W);
     int64_t sy, sx;
     if (SYM) {  // as v4: only the supertiles that reach the diagonal or lie above it
         sy = 0;
         for (;; ++sy) {
-            const int64_t cnt = nsx - sy / 2;
+            const int64_t cnt = nsx - sy / (SKM_ST_W / 4);
             if (st < cnt)
                 break;
             st -= cnt;
         }
-        sx = sy / 2 + st;
+        sx = sy / (SKM_ST_W / 4) + st;
     } else {
         sy = st / nsx;
         sx = st % nsx;
     }
-    const int64_t ty = sy * 4 + within / 8, tx = sx * 8 + within % 8;
+    const int64_t ty = sy * 4 + within / SKM_ST_W, tx = sx * SKM_ST_W + within % SKM_ST_W;
     if (ty >= nty || tx >= ntx || (SYM && ty > tx))
         return;
     const int64_t row0 = ty * BM3, col0 = tx * BN3;
@@ -1096,15 +1099,15 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
     const bool sym = d_x == d_y && n == m && d_xrnorm == d_yrnorm && forced0 != 7 && forced0 != 11;
     SKM_PROF(ctx, "k_cosine_dense_i8");
     if (v4) {
-        const int64_t nsy4 = skm_ceil_div(skm_ceil_div(n, BM3), 4), nsx4 = skm_ceil_div(skm_ceil_div(m, BN3), 8);
+        const int64_t nsy4 = skm_ceil_div(skm_ceil_div(n, BM3), 4), nsx4 = skm_ceil_div(skm_ceil_div(m, BN3), SKM_ST_W);
         int64_t supertiles = nsy4 * nsx4;
         if (sym) {  // rows of supertiles shrink towards the bottom: row sy keeps columns sx >= sy / 2 (see the kernel)
             supertiles = 0;
             for (int64_t sy = 0; sy < nsy4; ++sy)
-                supertiles += nsx4 - sy / 2 > 0 ? nsx4 - sy / 2 : 0;
+                supertiles += nsx4 - sy / (SKM_ST_W / 4) > 0 ? nsx4 - sy / (SKM_ST_W / 4) : 0;
         }
-        SKM_REQUIRE(supertiles * 32 < ((int64_t)1 << 31), SKM_E_OVERFLOW, "skm_cosine_dense_i8: too many tiles");
-        dim3 grid4((unsigned)(supertiles * 32));
+        SKM_REQUIRE(supertiles * (4 * SKM_ST_W) < ((int64_t)1 << 31), SKM_E_OVERFLOW, "skm_cosine_dense_i8: too many tiles");
+        dim3 grid4((unsigned)(supertiles * (4 * SKM_ST_W)));
         // default where K is a multiple of 256: v5 (SKM_DENSE_VARIANT=10; 11 the same without symmetry)
         if ((forced0 == 0 || forced0 == 10 || forced0 == 11) && kdim % (4 * BK4) == 0) {
             const int64_t nrbx = skm_ceil_div(n, BM3) * (BM3 / 16), ncb = skm_ceil_div(m, BN3) * (BN3 / 32);
@@ -1145,7 +1148,7 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
             }
 #endif
             if (nsplit > 1) {
-                const int64_t slots = supertiles * 32;
+                const int64_t slots = supertiles * (4 * SKM_ST_W);
                 SKM_TRY(skm_ws(ctx, WS_J, sizeof(int32_t) * (size_t)slots * (size_t)(nsplit - 1) * BM3 * BN3, &p));
                 int32_t *slabs = (int32_t *)p;
                 SKM_TRY(skm_ws(ctx, WS_ZERO, 256 + sizeof(uint32_t) * 2 * (size_t)slots, &p));  // (ticket, done) per slot: left at zero by every launch
@@ -1167,7 +1170,10 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
 #undef SKM_V5S
                 return skm_check_launch("k_cosine_dense_i8");
             }
-#define SKM_V5(MODE, SYM) k_cosine_dense_i8_v5<MODE, SYM><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, xt, ybt, d_xrnorm, d_yrnorm, d_out, ld)
+#ifndef SKM_V5_DA
+#define SKM_V5_DA 3
+#endif
+#define SKM_V5(MODE, SYM) k_cosine_dense_i8_v5<MODE, SYM, SKM_V5_DA><<<grid4, 512, 0, ctx->stream>>>(n, m, kdim, xt, ybt, d_xrnorm, d_yrnorm, d_out, ld)
             if (mode == 0) {
                 if (sym)
                     SKM_V5(0, true);

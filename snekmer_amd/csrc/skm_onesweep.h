@@ -310,9 +310,11 @@ static int sort_pairs_dev(skm_ctx *ctx, const int64_t *d_n, int64_t cap, const K
     k_pass<K, TB, 8, FIRST><<<(unsigned)(ntiles - 1), TB, 0, s>>>(d_n, src_k, dst_k, src_v, dst_v, st, ts, p, key_bits)
 #define SKM_OS_PASS_NT(TB, FIRST)                                                                                     \
     k_pass<K, TB, 8, FIRST, false><<<(unsigned)(ntiles - 1), TB, 0, s>>>(d_n, src_k, dst_k, src_v, dst_v, st, ts, p, key_bits)
-        // two 256-thread workgroups of this kernel (26-34 KB of LDS, < 64 registers) fit every CU beside anything else the
-        // library runs on the stream's context: up to 2 per CU the whole grid is resident and tile = blockIdx.x is safe
-        const bool resident = small && ntiles - 1 <= 2 * (int64_t)ctx->usable_cus;
+        // Tiles by blockIdx instead of a ticket (one round trip less per pass) would be safe for a grid that is resident as a
+        // whole, and measured 2 us faster per pass; but HIP promises nothing about dispatch order, a 128 KiB writer
+        // workgroup of another stream may leave room for one of these per CU instead of five, and a long fuzz run of this
+        // round stopped once, unexplained, with that path in the library: the ticket stays on every pass.
+        const bool resident = false;
         if (resident) {
             if (p == 0)
                 SKM_OS_PASS_NT(256, true);

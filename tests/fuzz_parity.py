@@ -331,7 +331,13 @@ def score_round(ctx, seed):
     got = skm.score.connection_matrix_from_features(Xm, metric=metric)
     assert (np.isnan(got) == np.isnan(want)).all(), f"{tag}: {metric} nan pattern"
     scale = max(1.0, float(np.nanmax(np.abs(want), initial=0.0)))
-    if metric in ("euclidean", "l2"):
+    if metric == "nan_euclidean":
+        # sklearn expands (x - y)^2 = xx + yy - 2 xy here too (with the missing columns zeroed), then scales by K / present:
+        # the same cancellation error, absolute in the squared distance, times that scale (at most K)
+        Z = np.nan_to_num(Xm)
+        bound = 1e-12 * max(1.0, 2.0 * float((Z * Z).sum(axis=1).max(initial=0.0))) * Xm.shape[1]
+        assert np.nanmax(np.abs(got * got - want * want), initial=0.0) <= bound, f"{tag}: {metric}"
+    elif metric in ("euclidean", "l2"):
         # sklearn takes sqrt(xx + yy - 2 xy), which cancels for close rows; the kernel sums (x - y)^2 directly.  The two
         # agree to the expansion's own rounding error, which is absolute in the SQUARED distance: eps * (xx + yy)
         assert np.nanmax(np.abs(got * got - want * want), initial=0.0) <= 1e-12 * max(1.0, 2.0 * float((Xm * Xm).sum(axis=1).max())), \

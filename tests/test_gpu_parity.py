@@ -649,7 +649,10 @@ def test_connection_matrix_other_sklearn_metrics_match_sklearn(ctx):
     holes[7, 1::2] = np.nan
     want = pairwise_distances(holes, metric="nan_euclidean")
     got = skm.score.connection_matrix_from_features(holes, metric="nan_euclidean")
-    assert (np.isnan(got) == np.isnan(want)).all() and np.isnan(want).any() and np.nanmax(np.abs(got - want)) <= 1e-12 * np.nanmax(want)
+    # (sklearn expands (x - y)^2 = xx + yy - 2 xy on the zero-filled matrix: agreement to that expansion's rounding error, absolute
+    # in the squared distance, times the K / present scale)
+    assert (np.isnan(got) == np.isnan(want)).all() and np.isnan(want).any()
+    assert np.nanmax(np.abs(got * got - want * want)) <= 1e-12 * 2.0 * float(np.nansum(holes * holes, axis=1).max()) * holes.shape[1]
     geo = np.stack([rng.uniform(-np.pi / 2, np.pi / 2, 97), rng.uniform(-np.pi, np.pi, 97)], axis=1)
     geo[3] = geo[2]
     want = pairwise_distances(geo, metric="haversine")
