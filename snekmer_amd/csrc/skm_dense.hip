@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void k_cosine_dense_i8_v2(int64_t n, int64_t m
 // operand copies cover every shape they served; their A/B numbers are in profiles/r02_dense_mfma.json and r04_dense_mfma.json)
 constexpr int BM3 = 256, BN3 = 256;
 #ifndef SKM_ST_W
-#define SKM_ST_W 8  // tiles per row of a supertile (4 rows x SKM_ST_W columns of tiles go to consecutive workgroups of one XCD)
+#define SKM_ST_W 4  // tiles per row of a supertile (4 rows x SKM_ST_W columns of tiles go to consecutive workgroups of one XCD)
 #endif
 
 // Row-major int8 [rows x kdim] -> the tiled image k_cosine_dense_i8_v4<.., TILED> stages from (see there).

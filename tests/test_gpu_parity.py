@@ -555,6 +555,8 @@ def test_connection_matrix_and_feature_matrix_goldens(ctx):
     for key, M in (("jaccard_x", g["X"]), ("jaccard_demo_counts", counts), ("jaccard_float", g15["F"])):
         assert (skm.score.jaccard_distance(M) == g15[key]).all(), key
     with pytest.raises(NotImplementedError):
+        skm.score.connection_matrix_from_features(g["X"], metric="wminkowski")
+    with pytest.raises(ValueError):  # scikit-learn: haversine is defined for two columns (latitude, longitude)
         skm.score.connection_matrix_from_features(g["X"], metric="haversine")
     with pytest.raises(ValueError):  # a name scikit-learn itself refuses
         skm.score.connection_matrix_from_features(g["X"], metric="jensenshannon")
