@@ -770,7 +770,9 @@ def skewed_workload(ctx, engine, alphabet, args, pipe, line):
         "pipeline_ms": sum(v for kk, v in stages.items() if kk.startswith("k_panel_") or kk == "onesweep_sort_heavy_rows"),
     }
     # the same batch with the panels off (every posting list walked): what they buy
-    os.environ["SKM_HEAVY_PANEL"] = "0"
+    from snekmer_amd import _hip
+
+    _hip.set_option("SKM_HEAVY_PANEL", 0)
     try:
         p.step(batch)
         ctx.sync()
@@ -780,7 +782,7 @@ def skewed_workload(ctx, engine, alphabet, args, pipe, line):
         ctx.sync()
         out["ms_per_step_without_panels"] = (time.perf_counter() - t1) / 3 * 1e3
     finally:
-        del os.environ["SKM_HEAVY_PANEL"]
+        _hip.set_option("SKM_HEAVY_PANEL", None)
     p.out = None
     return out
 
@@ -1107,7 +1109,9 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
 
     # the opt-in two-stream schedule of skm_cosine_csr (neighbour lists of block b+1 built while block b is written):
     # faster as a whole, but both kernels slow each other down, so the per-kernel rooflines above are taken without it
-    os.environ["SKM_COSINE_OVERLAP"] = "1"
+    from snekmer_amd import _hip
+
+    _hip.set_option("SKM_COSINE_OVERLAP", 1)
     try:
         pipe.step(batch)
         ctx.sync()
@@ -1117,7 +1121,7 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
         ctx.sync()
         ov_ms = (time.perf_counter() - t1) / 5 * 1e3
     finally:
-        os.environ.pop("SKM_COSINE_OVERLAP", None)
+        _hip.set_option("SKM_COSINE_OVERLAP", None)
     note("extras: overlap_schedule")
     line["overlap_schedule"] = {"ms_per_step": ov_ms, "sequences_per_s": n_total / (ov_ms * 1e-3),
                                 "what": "SKM_COSINE_OVERLAP=1: same step in 8 row blocks, the Gram of block b+1 on a stream confined to half of the "
@@ -1250,12 +1254,14 @@ def extras(ctx, engine, alphabet, args, line, pipe, batch, prof, res, off, seed)
     pm = ctx.profile_dump()
     ms_sym = pm["k_cosine_dense_i8"][1] / pm["k_cosine_dense_i8"][0]
     # the same kernel without the X-is-Y shortcut (what a rectangular X, Y call runs): every tile computed
-    os.environ["SKM_DENSE_VARIANT"] = "11"
+    from snekmer_amd import _hip
+
+    _hip.set_option("SKM_DENSE_VARIANT", 11)
     ctx.profile_reset()
     for _ in range(3):
         engine.cosine_dense_i8(ctx, nm, nm, dp.kdim, dp.dense, dp.dense, dp.rnorm, dp.rnorm, out=dp.out)
     ms_full = ctx.profile_read("k_cosine_dense_i8")[1] / 3
-    os.environ.pop("SKM_DENSE_VARIANT")
+    _hip.set_option("SKM_DENSE_VARIANT", None)
     ctx.profile_enable(False)
     ops_full = 2.0 * nm * nm * dp.kdim
     nt = -(-nm // 256)

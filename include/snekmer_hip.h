@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SKM_ABI_VERSION 5
+#define SKM_ABI_VERSION 6
 
 #define SKM_OK 0
 #define SKM_E_BADARG (-1)
@@ -53,6 +53,19 @@ typedef struct skm_ctx skm_ctx;
 int skm_abi_version(void);
 const char *skm_last_error(void);
 int skm_device_count(int *h_count);
+/* Switches between EXACT kernels, for tests and A/B timing; process-wide.  Each starts from the environment variable of the
+ * same name, read ONCE when the library is first used (round 5: no getenv on any call path), and can be set afterwards:
+ *   SKM_SORT            "rocprim" | "onesweep": the basis stage's sort whatever the size (default: by size)
+ *   SKM_COSINE_PATH     "lists" | "cursor": skm_cosine_csr's routing (default: by shape)
+ *   SKM_HEAVY_PANEL     "0" | "1": heavy-row panels off / on (default: by the previous call's heavy-row count)
+ *   SKM_COSINE_OVERLAP  "1": the blocked two-stream schedule inside skm_cosine_csr
+ *   SKM_GRAM_SHAPE      "1".."4": lane-group shape of k_gram_sparse
+ *   SKM_DENSE_VARIANT   "1" | "2" | "6" | "7" | "10" | "11": the int8 GEMM kernel (see skm_cosine_dense_i8)
+ * value NULL: back to what the environment said.  An unknown name or a value outside the list: SKM_E_BADARG.
+ * skm_get_option copies the current value ("" when unset) into buf.  No reference counterpart (the reference has one
+ * code path per stage). */
+int skm_set_option(const char *name, const char *value);
+int skm_get_option(const char *name, char *buf, int cap);
 int skm_create(int device_id, skm_ctx **out_ctx);
 /* A context whose stream may only use the compute-unit groups first..last of 0..7 (group of CU i: (i / 8) % 8, i.e. eight
  * CUs of every XCD per group).  For a SIDE context: engine.OverlappedPipeline vectorizes the next batch on one confined

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNEKMER_HIP_LIB") or os.path.join(_HERE, "libsnekmer_hip.so")
 
 SKM_OK = 0
-ABI_VERSION = 5  # SKM_ABI_VERSION of include/snekmer_hip.h
+ABI_VERSION = 6  # SKM_ABI_VERSION of include/snekmer_hip.h
 ERRORS = {-1: "BADARG", -2: "NOMEM", -3: "HIP", -4: "OVERFLOW", -5: "UNSUPPORTED", -6: "COMM", -7: "STALE"}
 COMM_ID_BYTES = 128
 
@@ -55,6 +55,8 @@ _SIGNATURES = {
     "skm_abi_version": (C.c_int, []),
     "skm_last_error": (C.c_char_p, []),
     "skm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "skm_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "skm_get_option": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
     "skm_create": (C.c_int, [C.c_int, C.POINTER(_p)]),
     "skm_create_confined": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_p)]),
     "skm_destroy": (C.c_int, [_p]),
@@ -193,6 +195,45 @@ def load_library():
 def _check(lib, status: int):
     if status != SKM_OK:
         raise HipError(status, lib.skm_last_error().decode("utf-8", "replace"))
+
+
+OPTION_NAMES = ("SKM_SORT", "SKM_COSINE_PATH", "SKM_HEAVY_PANEL", "SKM_COSINE_OVERLAP", "SKM_GRAM_SHAPE", "SKM_DENSE_VARIANT")
+
+
+def set_option(name: str, value) -> None:
+    """skm_set_option: a process-wide switch between exact kernels (include/snekmer_hip.h lists them).  The library reads
+    the environment variable of the same name once, when it is first used; afterwards this is the way to change one.
+    value None: back to what the environment said.  Unknown names and values raise HipError (SKM_E_BADARG)."""
+    lib = load_library()
+    _check(lib, lib.skm_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(name: str):
+    """Current value of an option as a string, None when unset."""
+    lib = load_library()
+    buf = C.create_string_buffer(64)
+    _check(lib, lib.skm_get_option(name.encode(), buf, 64))
+    return buf.value.decode() or None
+
+
+class options:
+    """`with _hip.options(SKM_SORT="rocprim"): ...`: set for the block, previous values back afterwards."""
+
+    def __init__(self, **values):
+        self.values, self.before = values, {}
+
+    def __enter__(self):
+        for name, value in self.values.items():
+            self.before[name] = get_option(name)
+            set_option(name, value)
+        return self
+
+    def __exit__(self, *exc):
+        for name, value in self.before.items():
+            set_option(name, None)  # the environment's value ...
+            if value is not None and get_option(name) != value:
+                set_option(name, value)  # ... or whatever an enclosing block had set
+        return False
 
 
 def device_count() -> int:

@@ -8,6 +8,116 @@
 
 extern "C" int skm_abi_version(void) { return SKM_ABI_VERSION; }
 
+// ---- options: the environment is read once; skm_set_option changes a value afterwards (include/snekmer_hip.h)
+namespace {
+struct option_desc {
+    const char *name;
+    int skm_options::*field;
+    int unset;                 // the field's value when the option is not set
+    const char *const *words;  // named values (their index + 1 is the field's value), or nullptr: an integer in [lo, hi]
+    int lo, hi;
+    bool diag;                 // only read by -DSKM_DIAG builds
+};
+const char *const SORT_WORDS[] = {"rocprim", "onesweep", nullptr};
+const char *const PATH_WORDS[] = {"lists", "cursor", nullptr};
+const option_desc OPTIONS[] = {
+    {"SKM_SORT", &skm_options::sort, 0, SORT_WORDS, 0, 0, false},
+    {"SKM_COSINE_PATH", &skm_options::cosine_path, 0, PATH_WORDS, 0, 0, false},
+    {"SKM_HEAVY_PANEL", &skm_options::heavy_panel, -1, nullptr, 0, 1, false},
+    {"SKM_COSINE_OVERLAP", &skm_options::cosine_overlap, 0, nullptr, 0, 1, false},
+    {"SKM_GRAM_SHAPE", &skm_options::gram_shape, 0, nullptr, 0, 4, false},
+    {"SKM_DENSE_VARIANT", &skm_options::dense_variant, 0, nullptr, 0, 11, false},
+#ifdef SKM_DIAG  // (the product library does not even carry the names: tests/test_host_api.py)
+    {"SKM_COSINE_ABLATE", &skm_options::cosine_ablate, 0, nullptr, 0, 3, true},
+    {"SKM_GRAM_ABLATE", &skm_options::gram_ablate, 0, nullptr, 0, 4, true},
+    {"SKM_OVERLAP_BLOCKS", &skm_options::overlap_blocks, 0, nullptr, 0, 16, true},
+    {"SKM_DENSE_SPLIT", &skm_options::dense_split, 0, nullptr, 0, 8, true},
+#endif
+};
+skm_options g_env_opts, g_opts;
+bool g_opts_read = false;
+
+bool parse_option(const option_desc &d, const char *value, int *out)
+{
+    if (!value || !*value) {
+        *out = d.unset;
+        return true;
+    }
+    if (d.words) {
+        for (int i = 0; d.words[i]; ++i)
+            if (strcmp(value, d.words[i]) == 0) {
+                *out = i + 1;
+                return true;
+            }
+        return false;
+    }
+    char *end = nullptr;
+    const long v = strtol(value, &end, 10);
+    if (end == value || *end || v < d.lo || v > d.hi)
+        return false;
+    *out = (int)v;
+    return true;
+}
+
+void read_options_once()
+{
+    if (g_opts_read)
+        return;
+    for (const option_desc &d : OPTIONS) {
+        int v = d.unset;
+        const char *e = getenv(d.name);
+        if (!parse_option(d, e, &v)) {
+            fprintf(stderr, "libsnekmer_hip: %s=%s is not a value of that option: ignored\n", d.name, e);
+            v = d.unset;
+        }
+        g_env_opts.*(d.field) = v;
+    }
+    g_opts = g_env_opts;
+    g_opts_read = true;
+}
+}  // namespace
+
+const skm_options &skm_opts()
+{
+    read_options_once();
+    return g_opts;
+}
+
+extern "C" int skm_set_option(const char *name, const char *value)
+{
+    SKM_REQUIRE(name, SKM_E_BADARG, "skm_set_option: null name");
+    read_options_once();
+    for (const option_desc &d : OPTIONS)
+        if (strcmp(name, d.name) == 0) {
+            int v = g_env_opts.*(d.field);
+            if (value)
+                SKM_REQUIRE(parse_option(d, value, &v), SKM_E_BADARG, "skm_set_option: %s does not take the value \"%s\"", name, value);
+            g_opts.*(d.field) = v;
+            return SKM_OK;
+        }
+    skm_set_error("skm_set_option: no option named %s", name);
+    return SKM_E_BADARG;
+}
+
+extern "C" int skm_get_option(const char *name, char *buf, int cap)
+{
+    SKM_REQUIRE(name && buf && cap > 0, SKM_E_BADARG, "skm_get_option: bad argument");
+    read_options_once();
+    for (const option_desc &d : OPTIONS)
+        if (strcmp(name, d.name) == 0) {
+            const int v = g_opts.*(d.field);
+            if (v == d.unset)
+                buf[0] = 0;
+            else if (d.words)
+                snprintf(buf, (size_t)cap, "%s", d.words[v - 1]);
+            else
+                snprintf(buf, (size_t)cap, "%d", v);
+            return SKM_OK;
+        }
+    skm_set_error("skm_get_option: no option named %s", name);
+    return SKM_E_BADARG;
+}
+
 extern "C" int skm_device_count(int *h_count)
 {
     SKM_REQUIRE(h_count, SKM_E_BADARG, "skm_device_count: null output");

@@ -1046,7 +1046,7 @@ int skm_basis_sort_state(skm_ctx *ctx, int64_t cap, int key_bits, int code_bits,
     void *p;
     SKM_TRY(skm_ws(ctx, WS_ROCPRIM, skm_onesweep::state_bytes(cap, 8192, passes) + skm_onesweep::state_bytes(cap, 2048, passes), &p));
     *out_state = (uint32_t *)p;
-    *out_words = (int64_t)((skm_onesweep::sort_state_bytes(cap, key_bits) + 3) / 4);
+    *out_words = (int64_t)((skm_onesweep::sort_state_bytes(cap, key_bits, code_bits / 8) + 3) / 4);
     if (out_passes)
         *out_passes = passes;
     if (out_key_bits)
@@ -1081,7 +1081,7 @@ int skm_basis_stage_async(skm_ctx *ctx, int code_bits, int key_bits, int64_t cap
         uint32_t *vtmp = (uint32_t *)p;
         SKM_TRY(skm_ws(ctx, WS_ROCPRIM, skm_onesweep::state_bytes(cap, 8192, passes) + skm_onesweep::state_bytes(cap, 2048, passes), &p));
         const bool zeroed = prepared.zero == (uint32_t *)p &&
-                            (size_t)prepared.zero_words * 4 >= skm_onesweep::sort_state_bytes(cap, key_bits);
+                            (size_t)prepared.zero_words * 4 >= skm_onesweep::sort_state_bytes(cap, key_bits, code_bits / 8);
         if (code_bits == 32)
             SKM_TRY(skm_onesweep::sort_pairs_dev<uint32_t>(ctx, d_nnz, cap, (const uint32_t *)d_codes, (uint32_t *)skeys, sidx,
                                                             (uint32_t *)ktmp, vtmp, p, key_bits, "onesweep_sort_codes", zeroed, zeroed && prepared.hist));

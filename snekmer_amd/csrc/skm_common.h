@@ -125,20 +125,35 @@ static inline int skm_grid_cap(const skm_ctx *ctx, int64_t want, int per_cu = 8)
 }
 
 // Which sort the basis stage uses.  Both are stable sorts of the same keys: identical results.  Measured on MI355X
-// (tools/small_batch_gap.py, red6 k=12, 4 digits): the library's own one-sweep sort (skm_onesweep.h: 6 launches, sized
-// by the device-side entry count) takes 0.078 / 0.122 ms for 0.3 / 1.0 M pairs where rocPRIM's Onesweep (~17 stream
-// operations) takes 0.119 / 0.160; from 3 M pairs on rocPRIM's passes are faster (0.16 vs 0.24 ms at 3 M, 0.85 vs 1.12 ms
-// at 29 M: its tuned ranking moves 2.6 TB/s per pass, ours 1.7).  So: ours up to 1.3 M pairs (round 5; 2^21 in round 4) - every single-file job of
-// the reference, snekmer/rules/kmerize.smk:57-65 - rocPRIM above.  SKM_SORT=rocprim / onesweep force one (A/B timing).
+// (tools/ab_sort_mid.sh, red6 k=12, 4 digits, ms per sort, own / rocPRIM): 0.3 M pairs 0.058 / 0.120, 1.0 M 0.108 / 0.160,
+// 1.45 M 0.105 / 0.118, 2.0 M 0.127 / 0.128, 2.5 M 0.131 / 0.155, 2.9 M 0.136 / 0.161, 3.5 M 0.159 / 0.175; from 4 M on the
+// grid of the own sort no longer fits the chip at once and rocPRIM's tuned ranking wins (4.1 M 0.212 / 0.193, 5.8 M 0.260 /
+// 0.251, 29 M 0.89 / 0.85).  So: ours up to 4 M pairs (round 5; 2^21 in round 4) - every single-file job of the reference,
+// snekmer/rules/kmerize.smk:57-65, and BASELINE configs[1] - rocPRIM above.  SKM_SORT=rocprim / onesweep force one (A/B timing).
+#ifndef SKM_OS_MAX_CAP
+#define SKM_OS_MAX_CAP ((int64_t)1 << 22)
+#endif
+// Process-wide switches between exact kernels (skm_set_option; include/snekmer_hip.h): read from the environment once.
+struct skm_options {
+    int sort = 0;            // SKM_SORT: 0 by size, 1 rocprim, 2 onesweep
+    int cosine_path = 0;     // SKM_COSINE_PATH: 0 by shape, 1 lists, 2 cursor
+    int heavy_panel = -1;    // SKM_HEAVY_PANEL: -1 by the hint, 0 off, 1 on
+    int cosine_overlap = 0;  // SKM_COSINE_OVERLAP
+    int gram_shape = 0;      // SKM_GRAM_SHAPE
+    int dense_variant = 0;   // SKM_DENSE_VARIANT
+    // diagnostic builds only (-DSKM_DIAG: results NOT valid for the ablations)
+    int cosine_ablate = 0, gram_ablate = 0, overlap_blocks = 0, dense_split = 0;
+};
+const skm_options &skm_opts();
+
 static inline bool skm_use_onesweep(int64_t cap)
 {
-    const char *e = getenv("SKM_SORT");
-    if (e && strcmp(e, "rocprim") == 0)
+    const int forced = skm_opts().sort;
+    if (forced == 1)
         return false;
-    if (e && strcmp(e, "onesweep") == 0)
+    if (forced == 2)
         return cap < ((int64_t)1 << 30);
-    return cap <= ((int64_t)5 << 18);  // 1.3 M pairs (round 5, ms per sort, own / rocPRIM: 0.3 M 0.058 / 0.120, 0.6 M 0.081 / 0.144,
-                                       // 1.05 M 0.096 / 0.162, 1.45 M 0.136 / 0.118, 2.0 M 0.170 / 0.129)
+    return cap <= SKM_OS_MAX_CAP;
 }
 
 // Stage functions shared by the fused entry point skm_vectorize_csr (skm_api.hip would be the natural home; they

@@ -1253,9 +1253,8 @@ bool heavy_panels_wanted(skm_ctx *ctx, int64_t nrows, int64_t m)
 {
     if (m > ((int64_t)1 << 20) || nrows < PB_ROWS)
         return false;
-    const char *e = getenv("SKM_HEAVY_PANEL");
-    if (e)
-        return atoi(e) != 0;
+    if (skm_opts().heavy_panel >= 0)
+        return skm_opts().heavy_panel != 0;
     // (one counter per row block of the blocked schedule, 16 words: the whole-call form uses the first only)
     const volatile uint32_t *last = (const volatile uint32_t *)((uint8_t *)ctx->h_pinned + 2048);
     uint64_t heavy = 0;
@@ -1439,8 +1438,7 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     uint32_t *fb_list = nullptr, *fb_count = nullptr, *wide_list = (uint32_t *)p + (strips + 8);
 #ifdef SKM_DIAG
     // Diagnostic builds of the cursor kernel (tools/ablate_cosine.py): results are NOT valid.
-    const char *abl_env = getenv("SKM_COSINE_ABLATE");
-    const int abl = abl_env ? atoi(abl_env) : 0;
+    const int abl = skm_opts().cosine_ablate;
     if (abl >= 1 && abl <= 3 && mode == 0 && vec) {
         SKM_PROF(ctx, "k_cosine_strip");
 #define SKM_CURSOR_ABL(ABL)                                                                                          \
@@ -1457,8 +1455,8 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
         return skm_check_launch("k_cosine_strip");
     }
 #endif
-    const char *path_env = getenv("SKM_COSINE_PATH");  // "cursor" forces the fallback kernel everywhere
-    if (path_env && strcmp(path_env, "cursor") == 0) {
+    const int forced_path = skm_opts().cosine_path;  // 2 ("cursor") forces the fallback kernel everywhere
+    if (forced_path == 2) {
         if (phase == 1)
             return SKM_OK;
         SKM_TRY(cosine_prologue(ctx, nullptr, 0, state, 0ull, d_yrnorm, m, st));
@@ -1473,7 +1471,7 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     // of a few hundred records against itself) take the list kernels like large ones: the cursor kernel advances one
     // posting per memory round trip and list, so a k-mer shared by all rows costs it m round trips per strip
     // (measured, 200 - 1000 rows: 0.12 ms whatever the size, against 0.04 - 0.05 ms for the four list-path launches).
-    if (m <= CH && nrows >= 8 * m && !(path_env && strcmp(path_env, "lists") == 0)) {  // SKM_COSINE_PATH=lists keeps the list path (tests)
+    if (m <= CH && nrows >= 8 * m && forced_path != 1) {  // SKM_COSINE_PATH=lists keeps the list path (tests)
         if (phase == 1)
             return SKM_OK;
         SKM_TRY(cosine_prologue(ctx, nullptr, 0, state, 0ull, d_yrnorm, m, st));
@@ -1510,8 +1508,7 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     if (phase != 2)
         SKM_TRY(cosine_prologue(ctx, fb_flag, strips + 8, state, fixed_ent, d_yrnorm, m, st));
 #ifdef SKM_DIAG
-    const char *gabl_env = getenv("SKM_GRAM_ABLATE");  // diagnostic builds of k_gram_sparse (1, 2, 4: results NOT valid)
-    const int gabl = gabl_env ? atoi(gabl_env) : 0;
+    const int gabl = skm_opts().gram_ablate;  // diagnostic builds of k_gram_sparse (1, 2, 4: results NOT valid)
 #else
     constexpr int gabl = 0;
 #endif
@@ -1525,17 +1522,17 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     // the writer's launches sum to 7.5-7.7 ms instead of 6.6-7.1), so the writer's own roofline fraction drops from 0.72-0.76
     // to 0.66 for a gain inside the box-to-box spread: it stays opt-in.  A batch whose previous call handed thousands of
     // rows to the heavy kernel takes the panel pipeline (written for the whole call) whatever the variable says.
-    const char *ov_env = getenv("SKM_COSINE_OVERLAP");
+    const bool ov_wanted = skm_opts().cosine_overlap == 1;
     bool panels_first = false;
     if constexpr (sizeof(PW) == 8)
         panels_first = heavy_panels_wanted(ctx, nrows, m);
     int nblk = 1;
-    if (phase == 0 && gabl == 0 && ov_env && atoi(ov_env) == 1 && !panels_first && nrows >= 4096 &&
+    if (phase == 0 && gabl == 0 && ov_wanted && !panels_first && nrows >= 4096 &&
         (double)nrows * (double)ld * 4.0 >= 2e9 && overlap_streams(ctx) == SKM_OK)
         nblk = 8;
 #ifdef SKM_DIAG
-    if (nblk > 1 && getenv("SKM_OVERLAP_BLOCKS"))  // diagnostic: block count of the overlapped schedule (2..16)
-        nblk = max(2, min(16, atoi(getenv("SKM_OVERLAP_BLOCKS"))));
+    if (nblk > 1 && skm_opts().overlap_blocks)  // diagnostic: block count of the overlapped schedule (2..16)
+        nblk = max(2, min(16, skm_opts().overlap_blocks));
 #endif
     const int64_t brows = skm_ceil_div(skm_ceil_div(nrows, nblk), 8) * 8;  // whole cursor strips per block
     hipStream_t s_g = nblk > 1 ? ctx->s_gram : st, s_w = nblk > 1 ? ctx->s_writer : st;
@@ -1564,8 +1561,7 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
     k_gram_sparse<0, 1, FIRST_GH, 256, 2, GG, UU, PW><<<(unsigned)bn, 256, 0, gs>>>(                                 \
         d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0 + b0, row0 + b1, SLOT, b0, g_ent, cap_ent, \
         g_counter, g_start + b0, g_len + b0, b_over_list, b_over_count, d_xrnorm, &state->min_yrnorm, G_WIDE_ROW)
-            const char *shape_env = getenv("SKM_GRAM_SHAPE");
-            const int shape = shape_env ? atoi(shape_env) : 0;
+            const int shape = skm_opts().gram_shape;
             if (gabl == 0 && shape == 1)
                 SKM_GRAM_SHAPE(16, 2);
             else if (gabl == 0 && shape == 2)

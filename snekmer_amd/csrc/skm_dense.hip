@@ -1091,8 +1091,7 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
     // groups, both operands through LDS from tiled copies) with / without the symmetric form, 10 / 11 v5 (A through LDS, B
     // straight into registers; the default where K % 256 == 0) with / without it.  Round 5 removed 3 (round 1's lock-step
     // 256 x 256 kernel) and 4 / 5 (v4 staging from row-major operands).
-    const char *v_env = getenv("SKM_DENSE_VARIANT");
-    const int forced0 = v_env ? atoi(v_env) : 0;
+    const int forced0 = skm_opts().dense_variant;
     const bool v2 = kdim % BK2 == 0 && forced0 != 1;
     const bool v4 = kdim % BK4 == 0 && kdim >= 4 * BK4 && n >= 1024 && m >= 1024 &&
                     (forced0 == 0 || forced0 == 6 || forced0 == 7 || forced0 == 10 || forced0 == 11);
@@ -1138,8 +1137,7 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
                 }
             }
 #ifdef SKM_DIAG
-            if (const char *fs = getenv("SKM_DENSE_SPLIT")) {  // A/B timing: force the split count (1 = off)
-                const int cand = atoi(fs);
+            if (const int cand = skm_opts().dense_split) {  // A/B timing: force the split count (1 = off)
                 const int64_t per = skm_ceil_div(skm_ceil_div(nst5, cand > 0 ? cand : 1), 4) * 4;
                 if (cand >= 1 && cand <= 8 && per >= 4 && skm_ceil_div(nst5, per) == cand) {
                     nsplit = cand;

@@ -25,7 +25,7 @@
 #define SKM_OS_LARGE_TB 512  // (29 M pairs, 4 passes: 1024 x 8 0.99 ms, 512 x 8 0.89, 256 x 8 1.13; rocPRIM 0.85)
 #endif
 #ifndef SKM_OS_SMALL_LOG2
-#define SKM_OS_SMALL_LOG2 22
+#define SKM_OS_SMALL_LOG2 20
 #endif
 
 namespace skm_onesweep {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(TB) void k_histogram(const int64_t *__restrict__ d_
     }
 }
 
-template <typename K, int TB, int IPT, bool FIRST, bool TICKET = true>
+template <typename K, int TB, int IPT, bool FIRST>
 __global__ __launch_bounds__(TB) void k_pass(const int64_t *__restrict__ d_n, const K *__restrict__ kin, K *__restrict__ kout,
                                              const uint32_t *__restrict__ vin, uint32_t *__restrict__ vout, state_header *st,
                                              uint32_t *__restrict__ tile_state, int pass, int key_bits)
@@ -83,14 +83,16 @@ __global__ __launch_bounds__(TB) void k_pass(const int64_t *__restrict__ d_n, co
     const int shift = pass * RADIX_BITS;
     const uint32_t mask = (1u << min(RADIX_BITS, key_bits - shift)) - 1u;
     const int64_t n = *d_n;
-    // tiles in arrival order (atomic ticket), so that every tile a look-back waits for is already running; a grid small
-    // enough to be resident as a whole (TICKET false) needs no such order and saves the ticket's round trip
-    if (TICKET && tid == 0)
+    // tiles in arrival order (atomic ticket), so that every tile a look-back waits for is already running.  (Tiles by
+    // blockIdx for a grid that is resident as a whole measured 2 us faster per pass; HIP promises nothing about dispatch
+    // order, a 128 KiB writer workgroup of another stream may leave room for one of these per CU instead of five, and a
+    // long fuzz run of round 5 stopped once, unexplained, with that path in the library: the ticket is taken always.)
+    if (tid == 0)
         s_tile = atomicAdd(&st->ticket[pass], 1u);
     for (int z = tid; z < NW * RADIX; z += TB)
         (&s_whist[0][0])[z] = 0u;
     __syncthreads();
-    const int64_t tile = TICKET ? s_tile : blockIdx.x;
+    const int64_t tile = s_tile;
     const int64_t tile_base = tile * TILE;
     if (tile_base >= n)  // uniform; no earlier tile ever waits for this one
         return;
@@ -267,15 +269,39 @@ static inline size_t state_bytes(int64_t cap, int tile, int passes)
     return sizeof(state_header) + sizeof(uint32_t) * (size_t)ntiles * RADIX * (size_t)passes;
 }
 
+// Tile shape (threads, keys per thread) for `cap` keys of `key_bytes` bytes.  Small inputs: 256 x 8 (many tiles in flight:
+// the passes are latency-bound there).  From 1 M keys the passes are bound by how many ROUNDS of workgroups the grid
+// takes (a pass of 354 tiles of 1024 x 8 on 256 CUs takes as long as one of 512), so the tile grows with the input to
+// keep the whole grid resident at once - 1024 x 8 / x 12 / x 16, one workgroup per CU (LDS: 8 or 12 bytes per key) - up to
+// 4 M keys; above that 512 x 8 (29 M pairs, 4 passes: 1024 x 8 0.99 ms, 512 x 8 0.89, 256 x 8 1.13; rocPRIM 0.85).
+static inline void tile_shape(int64_t cap, int key_bytes, int *tb, int *ipt)
+{
+    *tb = SKM_OS_LARGE_TB;
+    *ipt = 8;
+    if (cap <= ((int64_t)1 << SKM_OS_SMALL_LOG2)) {
+        *tb = 256;
+    } else if (cap <= ((int64_t)1 << 21)) {
+        *tb = 1024;
+    } else if (key_bytes <= 4 && cap <= ((int64_t)3 << 20)) {
+        *tb = 1024;
+        *ipt = 12;
+    } else if (key_bytes <= 4 && cap <= ((int64_t)1 << 22)) {
+        *tb = 1024;
+        *ipt = 16;
+    }
+}
+
 // what sort_pairs_dev clears (or wants cleared) at d_state for `cap` keys
-static inline size_t sort_state_bytes(int64_t cap, int key_bits)
+static inline size_t sort_state_bytes(int64_t cap, int key_bits, int key_bytes)
 {
     const int passes = (key_bits + RADIX_BITS - 1) / RADIX_BITS;
-    return state_bytes(cap, cap <= ((int64_t)1 << SKM_OS_SMALL_LOG2) ? 256 * 8 : SKM_OS_LARGE_TB * 8, passes);
+    int tb, ipt;
+    tile_shape(cap, key_bytes, &tb, &ipt);
+    return state_bytes(cap, tb * ipt, passes);
 }
 
 // Stable sort of the first *d_n (<= cap < 2^30) keys of `kin` with payload = index; result in kout / vout.  ktmp / vtmp:
-// scratch of cap elements each; d_state: state_bytes().  Nothing waits for the device.
+// scratch of cap elements each; d_state: state_bytes() of the smallest tile (2048).  Nothing waits for the device.
 template <typename K>
 static int sort_pairs_dev(skm_ctx *ctx, const int64_t *d_n, int64_t cap, const K *kin, K *kout, uint32_t *vout, K *ktmp,
                           uint32_t *vtmp, void *d_state, int key_bits, const char *label, bool state_is_zero = false,
@@ -284,10 +310,9 @@ static int sort_pairs_dev(skm_ctx *ctx, const int64_t *d_n, int64_t cap, const K
     hipStream_t s = ctx->stream;
     const int passes = (key_bits + RADIX_BITS - 1) / RADIX_BITS;
     SKM_REQUIRE(passes >= 1 && passes <= MAX_PASSES && cap < ((int64_t)1 << 30), SKM_E_BADARG, "onesweep: bad size");
-    // small inputs: 256-thread tiles of 2048 keys (more tiles in flight: the passes are latency-bound there);
-    // large ones: 1024 x 8 (the shape rocPRIM's tuning also prefers on this chip)
-    const bool small = cap <= ((int64_t)1 << SKM_OS_SMALL_LOG2);
-    const int tile = small ? 256 * 8 : SKM_OS_LARGE_TB * 8;
+    int tb, ipt;
+    tile_shape(cap, (int)sizeof(K), &tb, &ipt);
+    const int tile = tb * ipt;
     const int64_t ntiles = (cap + tile - 1) / tile + 1;
     state_header *st = (state_header *)d_state;
     uint32_t *tile_state = (uint32_t *)((uint8_t *)d_state + sizeof(state_header));
@@ -306,33 +331,24 @@ static int sort_pairs_dev(skm_ctx *ctx, const int64_t *d_n, int64_t cap, const K
         K *dst_k = to_out ? kout : ktmp;
         uint32_t *dst_v = to_out ? vout : vtmp;
         uint32_t *ts = tile_state + (size_t)p * (size_t)ntiles * RADIX;
-#define SKM_OS_PASS(TB, FIRST)                                                                                        \
-    k_pass<K, TB, 8, FIRST><<<(unsigned)(ntiles - 1), TB, 0, s>>>(d_n, src_k, dst_k, src_v, dst_v, st, ts, p, key_bits)
-#define SKM_OS_PASS_NT(TB, FIRST)                                                                                     \
-    k_pass<K, TB, 8, FIRST, false><<<(unsigned)(ntiles - 1), TB, 0, s>>>(d_n, src_k, dst_k, src_v, dst_v, st, ts, p, key_bits)
-        // Tiles by blockIdx instead of a ticket (one round trip less per pass) would be safe for a grid that is resident as a
-        // whole, and measured 2 us faster per pass; but HIP promises nothing about dispatch order, a 128 KiB writer
-        // workgroup of another stream may leave room for one of these per CU instead of five, and a long fuzz run of this
-        // round stopped once, unexplained, with that path in the library: the ticket stays on every pass.
-        const bool resident = false;
-        if (resident) {
-            if (p == 0)
-                SKM_OS_PASS_NT(256, true);
-            else
-                SKM_OS_PASS_NT(256, false);
-        } else if (small) {
-            if (p == 0)
-                SKM_OS_PASS(256, true);
-            else
-                SKM_OS_PASS(256, false);
-        } else {
-            if (p == 0)
-                SKM_OS_PASS(SKM_OS_LARGE_TB, true);
-            else
-                SKM_OS_PASS(SKM_OS_LARGE_TB, false);
-        }
+#define SKM_OS_PASS(TB, IPT)                                                                                                   \
+    do {                                                                                                                       \
+        if (p == 0)                                                                                                            \
+            k_pass<K, TB, IPT, true><<<(unsigned)(ntiles - 1), TB, 0, s>>>(d_n, src_k, dst_k, src_v, dst_v, st, ts, p, key_bits);  \
+        else                                                                                                                   \
+            k_pass<K, TB, IPT, false><<<(unsigned)(ntiles - 1), TB, 0, s>>>(d_n, src_k, dst_k, src_v, dst_v, st, ts, p, key_bits); \
+    } while (0)
+        if (tb == 256)
+            SKM_OS_PASS(256, 8);
+        else if (tb == 1024 && ipt == 8)
+            SKM_OS_PASS(1024, 8);
+        else if (sizeof(K) <= 4 && tb == 1024 && ipt == 12)
+            SKM_OS_PASS(1024, (sizeof(K) <= 4 ? 12 : 8));
+        else if (sizeof(K) <= 4 && tb == 1024 && ipt == 16)
+            SKM_OS_PASS(1024, (sizeof(K) <= 4 ? 16 : 8));
+        else
+            SKM_OS_PASS(SKM_OS_LARGE_TB, 8);
 #undef SKM_OS_PASS
-#undef SKM_OS_PASS_NT
         src_k = dst_k;
         src_v = dst_v;
     }

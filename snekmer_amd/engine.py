@@ -647,9 +647,7 @@ class Pipeline:
         self._basis, self._basis_stale = value, False
 
     def _sparse_forced(self) -> bool:
-        import os
-
-        return self.dense_route in (False, "never") or os.environ.get("SKM_COSINE_PATH") in ("lists", "cursor")
+        return self.dense_route in (False, "never") or _hip.get_option("SKM_COSINE_PATH") in ("lists", "cursor")
 
     def wants_dense(self, batch: SeqBatch) -> bool:
         """The host-side routing rule: a function of (alphabet, k, batch shape) only."""
@@ -734,13 +732,10 @@ class Pipeline:
 
     # ---- whole steps as HIP graphs
     GRAPH_AUTO_RESIDUES = 1 << 23  # "auto": up to ~28 k sequences of 300 aa; above, the launches are a percent of the step
-    GRAPH_ENV = ("SKM_COSINE_PATH", "SKM_HEAVY_PANEL", "SKM_COSINE_OVERLAP", "SKM_SORT", "SKM_DENSE_VARIANT", "SKM_OVERLAP_BLOCKS",
-                 "SKM_GRAM_SHAPE")  # host-side switches between exact kernels: a capture freezes them, so they are part of its key
+    GRAPH_ENV = _hip.OPTION_NAMES  # host-side switches between exact kernels: a capture freezes them, so they are part of its key
     GRAPH_SLOTS = 8
 
     def _graph_key(self, batch: SeqBatch):
-        import os
-
         if self.graphs is False or getattr(self.ctx, "profiling", False) or batch.ctx is not self.ctx or _hip.under_profiler():
             return None
         if not self.fused or self.post32 or batch.n < 1 or batch.total < 1 or batch.max_len < 1:
@@ -748,7 +743,7 @@ class Pipeline:
         if self.graphs == "auto" and batch.total > self.GRAPH_AUTO_RESIDUES:
             return None
         return (batch.d_seq.ptr, batch.d_seq.nbytes, batch.d_off.ptr, batch.n, batch.total, batch.max_len,
-                tuple(os.environ.get(v) for v in self.GRAPH_ENV), self.dense_route)
+                tuple(_hip.get_option(v) for v in self.GRAPH_ENV), self.dense_route)
 
     def _signature(self):
         """(address, bytes) of every buffer the kernels of the last step touched besides the batch and the context's scratch:
@@ -873,15 +868,19 @@ class OverlappedPipeline:
     i.e. before calling step() again, exactly as with Pipeline.  The streams must sit on different hardware queues:
     snekmer_amd._hip asks the HIP runtime for eight (GPU_MAX_HW_QUEUES) when it loads the library first."""
 
-    EV_VEC, EV_COS = 0, 2  # event slots: EV_VEC + set on the side contexts, EV_COS + set on the main one
+    EV_VEC, EV_COS = 0, 4  # event slots: EV_VEC + set on the side contexts, EV_COS + set on the main one
     SIDE_CU_GROUPS = (0, 3)  # measured on the bench workload: groups 0-0 12.7 ms, 0-1 10.1, 0-2 10.0, 0-3 9.66, 0-4 10.35, all 10.5
     SIDE_LIST_FRACTION = 0.6  # bench workload, ms per step: 0 9.75, 0.2 9.74, 0.4 9.47, 0.5 9.29-9.36, 0.6 9.25, 0.7 9.27, 0.8 9.63, 1 9.99
     SPLIT_MIN_ROWS = 16384  # below this a batch's lists all stay on the main context
+    DEPTH = 1  # batches in flight on side contexts (each on its own context and buffer set)
 
     def __init__(self, ctx: _hip.Context, lut: AlphabetLUT, k: int, side_ctx: Optional[_hip.Context] = None,
-                 side_list_fraction: Optional[float] = None):
+                 side_list_fraction: Optional[float] = None, depth: Optional[int] = None):
         self.ctx, self.lut, self.k = ctx, lut, k
         self.fraction = self.SIDE_LIST_FRACTION if side_list_fraction is None else float(side_list_fraction)
+        self.depth = self.DEPTH if depth is None else int(depth)
+        if not 1 <= self.depth <= 3:
+            raise ValueError("depth: 1, 2 or 3 batches ahead")
 
         def confined():
             try:  # half of the compute units: what the next batch's kernels may fill beside this batch's writer
@@ -890,16 +889,22 @@ class OverlappedPipeline:
                 return _hip.Context(ctx.device)
 
         first = side_ctx if side_ctx is not None else confined()
-        second = first
-        if self.fraction > 0:  # lists on the side: one side context per buffer set
-            second = _hip.Context(ctx.device, cu_groups=first.cu_groups) if first.cu_groups else _hip.Context(ctx.device)
-        self.sides = [first, second]
+        nsets = self.depth + 1
+        self.sides = [first] * nsets
+        if self.fraction > 0 or self.depth > 1:  # lists on the side (they live in a context's scratch), or batches side by side: one side context per buffer set
+            self.sides = [first] + [_hip.Context(ctx.device, cu_groups=first.cu_groups) if first.cu_groups else _hip.Context(ctx.device)
+                                    for _ in range(nsets - 1)]
         self.side = first
-        self.sets = [[None, None, None], [None, None, None]]  # (csr, basis, rnorm) per buffer set
-        self.ready = None   # set holding a vectorized batch that has not been consumed yet
+        self.sets = [[None, None, None] for _ in range(nsets)]  # (csr, basis, rnorm) per buffer set
+        self.queue = []     # sets holding a vectorized batch that has not been consumed yet, oldest first
         self.nxt = 0
         self.out = None
         self.csr = self.basis = self.rnorm = None  # the set the last step() consumed
+
+    @property
+    def ready(self):
+        """The set the next step() consumes (None: nothing prefetched)."""
+        return self.queue[0] if self.queue else None
 
     def _split_row(self, n: int) -> int:
         """Rows [0, r) get their lists on the main context, rows [r, n) on the side context."""
@@ -919,11 +924,11 @@ class OverlappedPipeline:
 
     def prefetch(self, batch: SeqBatch) -> None:
         """Vectorize `batch` on a side context into the free buffer set (and build the lists of its last rows there)."""
-        if self.ready is not None:
+        if len(self.queue) >= self.depth:
             raise RuntimeError("a prefetched batch is waiting: call step() first")
         s = self.nxt
         side = self.sides[s]
-        # the set's previous contents (and that side context's lists) were last read by the cosine two steps ago
+        # the set's previous contents (and that side context's lists) were last read by the cosine depth + 1 steps ago
         side.wait_event(self.ctx, self.EV_COS + s)
         if batch.ctx is not self.ctx and all(batch.ctx is not c for c in self.sides):
             raise ValueError("the batch must live on the pipeline's device")
@@ -934,14 +939,14 @@ class OverlappedPipeline:
         if r < n:
             self._block(side, s, r, n, 1, 0, (n + 3) // 4 * 4)
         side.record_event(self.EV_VEC + s)
-        self.ready = s
-        self.nxt = 1 - s
+        self.queue.append(s)
+        self.nxt = (s + 1) % len(self.sets)
 
     def step(self, next_batch: Optional[SeqBatch] = None):
         """Cosine of the prefetched batch (queued on the main context), then the prefetch of `next_batch`."""
-        if self.ready is None:
+        if not self.queue:
             raise RuntimeError("nothing prefetched: call prefetch(batch) first")
-        s, self.ready = self.ready, None
+        s = self.queue.pop(0)
         self.csr, self.basis, self.rnorm = self.sets[s]
         self.ctx.wait_event(self.sides[s], self.EV_VEC + s)
         n = self.csr.n

@@ -24,11 +24,35 @@ def pytest_generate_tests(metafunc):
         metafunc.parametrize("_cosine_path", COSINE_PATHS, indirect=True)
 
 
+@pytest.fixture
+def skm_option():
+    """set(name, value): skm_set_option for the rest of the test (the library reads the SKM_* environment variables once,
+    when it is loaded, so a test switches kernels through the API); everything goes back to the environment's values at
+    teardown.  Unknown names / values raise: a test cannot silently run the default kernel instead of the one it names."""
+    from snekmer_amd import _hip
+
+    touched = []
+
+    def set_(name, value):
+        touched.append(name)
+        _hip.set_option(name, value)
+
+    yield set_
+    for name in touched:
+        _hip.set_option(name, None)
+
+
 @pytest.fixture(autouse=True)
-def _cosine_path(request, monkeypatch):
+def _cosine_path(request):
     path = getattr(request, "param", "default")
-    if path == "default":
-        monkeypatch.delenv("SKM_COSINE_PATH", raising=False)
-    else:
-        monkeypatch.setenv("SKM_COSINE_PATH", path)
-    return path
+    from snekmer_amd import _hip
+
+    try:
+        _hip.set_option("SKM_COSINE_PATH", None if path == "default" else path)
+    except _hip.HipUnavailable:
+        if path != "default":
+            raise
+        yield path
+        return
+    yield path
+    _hip.set_option("SKM_COSINE_PATH", None)

@@ -74,6 +74,7 @@ def draw_batch(rng, big=False):
 
 def one_round(ctx, seed, verbose=False):
     from oracle import c_oracle as orc
+    from snekmer_amd import _hip
     from snekmer_amd import alphabet as A
     from snekmer_amd import engine
     from snekmer_amd.utils import pack_sequences
@@ -134,16 +135,8 @@ def one_round(ctx, seed, verbose=False):
         err = float(np.abs(S["three"][rows] - ref).max())
         assert err <= 1e-5, f"{tag}: cosine vs oracle {err}"
         for env in ({"SKM_COSINE_PATH": "cursor"}, {"SKM_COSINE_PATH": "lists"}, {"SKM_COSINE_OVERLAP": "1", "SKM_COSINE_PATH": "lists"}):
-            saved = {kk: os.environ.get(kk) for kk in ("SKM_COSINE_PATH", "SKM_COSINE_OVERLAP")}
-            os.environ.update(env)
-            try:
+            with _hip.options(**env):
                 alt = p.cosine().download().reshape(p.out.shape)[:n, :n]
-            finally:
-                for kk, vv in saved.items():
-                    if vv is None:
-                        os.environ.pop(kk, None)
-                    else:
-                        os.environ[kk] = vv
             same(alt, S["three"], f"cosine under {env}")
         if seed % 8 == 5:
             # a stream of two batches through OverlappedPipeline with the lists of a random share of the rows built on the

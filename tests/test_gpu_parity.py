@@ -10,6 +10,7 @@ import pickle
 import numpy as np
 import pytest
 
+from snekmer_amd import _hip
 from helpers import GOLDEN, alpha_key, csr_to_dense, demo_records, ensure_red6, gjson, gnpz, parse_tag
 
 pytestmark = pytest.mark.gpu
@@ -319,15 +320,10 @@ def test_cosine_medium_vs_oracle_all_modes(ctx):
     blk = pipe.cosine(row0=501, row1=1203).download().reshape(pipe.out.shape)[: 1203 - 501, :n]
     assert (blk == S[501:1203]).all()
     # the cursor (fallback) kernel alone gives the same bits as sparse-Gram + writer (+ fallback strips)
-    old_path = os.environ.get("SKM_COSINE_PATH")
-    os.environ["SKM_COSINE_PATH"] = "cursor"
-    try:
+    from snekmer_amd import _hip
+
+    with _hip.options(SKM_COSINE_PATH="cursor"):
         S_cur = pipe.cosine().download().reshape(pipe.out.shape)[:n, :n]
-    finally:
-        if old_path is None:
-            del os.environ["SKM_COSINE_PATH"]
-        else:
-            os.environ["SKM_COSINE_PATH"] = old_path
     assert (S_cur == S).all()
     # distance mode
     b = pipe.basis
@@ -751,11 +747,8 @@ def test_cosine_dense_i8_mfma_exact_gram_and_scaling(ctx):
     _check_dense_symmetric(ctx, rng, 1500, 768)    # the same through v5
     _check_dense_symmetric(ctx, rng, 2304, 256)    # whole tiles
     for variant in ("6", "7", "11"):  # the kernels the default route no longer picks at this shape stay exact
-        os.environ["SKM_DENSE_VARIANT"] = variant
-        try:
+        with _hip.options(SKM_DENSE_VARIANT=variant):
             _check_dense_gram(ctx, rng, 1100, 1029, 512)
-        finally:
-            os.environ.pop("SKM_DENSE_VARIANT")
 
 
 def _check_dense_gram(ctx, rng, n, m, kdim):
@@ -1231,7 +1224,7 @@ def test_sharded_pipeline_two_ranks_over_rccl_on_two_gpus(ctx, tmp_path, mode):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-def test_heavy_rows_on_the_matrix_cores_equal_the_walk(ctx, monkeypatch, mode):
+def test_heavy_rows_on_the_matrix_cores_equal_the_walk(ctx, skm_option, mode):
     """SKM_HEAVY_PANEL=1 sends the long-list columns of the heavy rows through int8 panels and an MFMA GEMM
     (skm_heavy_panel.h); =0 walks every posting list.  Both are exact integer dot products with the same float32
     scaling, so the matrices must be IDENTICAL, and equal to the oracle's.  The batch has what the panel path must
@@ -1278,7 +1271,7 @@ def test_heavy_rows_on_the_matrix_cores_equal_the_walk(ctx, monkeypatch, mode):
     ld = (n + 3) // 4 * 4
     outs = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("SKM_HEAVY_PANEL", flag)
+        skm_option("SKM_HEAVY_PANEL", flag)
         S = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, b.ncols_hint(), b.colptr, b.post, pipe.rnorm, mode=mode, ld=ld)
         if flag == "1":
             import ctypes as C
@@ -1305,7 +1298,7 @@ def test_heavy_rows_on_the_matrix_cores_equal_the_walk(ctx, monkeypatch, mode):
 
 
 @pytest.mark.cosine_paths
-def test_overlapped_cosine_schedule_equals_default(ctx, monkeypatch):
+def test_overlapped_cosine_schedule_equals_default(ctx, skm_option):
     """SKM_COSINE_OVERLAP=1 (row blocks; lists built on one CU-masked stream while the previous block
     is written on another) must give the default schedule's matrix bit for bit."""
     from snekmer_amd import alphabet as A
@@ -1318,10 +1311,10 @@ def test_overlapped_cosine_schedule_equals_default(ctx, monkeypatch):
     batch = engine.SeqBatch(ctx, res, off)
     pipe = engine.Pipeline(ctx, lut, 12)
     pipe.vectorize(batch)
-    monkeypatch.setenv("SKM_COSINE_OVERLAP", "0")
+    skm_option("SKM_COSINE_OVERLAP", "0")
     ref = pipe.cosine()
     pipe.out = None  # keep `ref`, write the second run to a fresh buffer
-    monkeypatch.setenv("SKM_COSINE_OVERLAP", "1")
+    skm_option("SKM_COSINE_OVERLAP", "1")
     got = pipe.cosine()
     ld = ref.shape[1]
     for r0 in range(0, n, 2000):  # 3000-row blocks: every chunk boundary and block edge is covered
@@ -1372,6 +1365,22 @@ def test_overlapped_pipeline_equals_pipeline_on_a_stream_of_batches(ctx):
             split.sync()
             got = out.download().reshape(out.shape)[: b.n, : b.n]
             assert (got == want[i]).all(), (fraction, i)
+    # two and three batches in flight on side contexts (depth + 1 buffer sets and side contexts in rotation)
+    for depth, fraction in ((2, 0.0), (2, 1.0), (3, 0.6)):
+        deep = engine.OverlappedPipeline(ctx, lut, 12, side_list_fraction=fraction, depth=depth)
+        deep.SPLIT_MIN_ROWS = 64
+        assert len(deep.sets) == depth + 1 and len(set(map(id, deep.sides))) == depth + 1
+        for b in batches[:depth]:
+            deep.prefetch(b)
+        with pytest.raises(RuntimeError):
+            deep.prefetch(batches[depth])
+        for i, b in enumerate(batches):
+            out = deep.step(batches[i + depth] if i + depth < len(batches) else None)
+            deep.sync()
+            got = out.download().reshape(out.shape)[: b.n, : b.n]
+            assert (got == want[i]).all(), (depth, fraction, i)
+        with pytest.raises(RuntimeError):
+            deep.step(None)
 
 
 @pytest.mark.parametrize("name,k,n", [("red6", 12, 1000), ("standard", 12, 700), ("solvacc", 8, 1500)])
@@ -1544,7 +1553,7 @@ def test_heavy_rows_every_list_shape_vs_oracle(ctx, mode):
     ld = (n + 3) // 4 * 4
     S = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, bs.ncols_hint(), bs.colptr, bs.post, pipe.rnorm, mode=mode, ld=ld)
     S = S.download().reshape(-1, ld)[:n, :n]
-    if os.environ.get("SKM_COSINE_PATH") != "cursor":
+    if _hip.get_option("SKM_COSINE_PATH") != "cursor":
         import ctypes as C
 
         st = (C.c_int64 * 4)()
@@ -1642,7 +1651,7 @@ def test_config3_full_size_100k_overlapped_pipeline_the_timed_object(ctx):
     pipe.out = None
 
 
-def test_heavy_panels_at_100k_skewed_rows_equal_the_walk(ctx, monkeypatch):
+def test_heavy_panels_at_100k_skewed_rows_equal_the_walk(ctx, skm_option):
     """bench.py's skewed workload at full size (100 k rows, 79 k of them heavy, families to 5 000): the whole 10^10-cell
     matrix with the heavy rows' long-list columns on the matrix cores against the same matrix with every list walked,
     reduced on the device to a float64 sum and a non-zero count per row (skm_matrix_row_stats).  Both forms compute
@@ -1659,7 +1668,7 @@ def test_heavy_panels_at_100k_skewed_rows_equal_the_walk(ctx, monkeypatch):
     pipe = engine.Pipeline(ctx, A.build_lut("red6"), 12)
     stats = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("SKM_HEAVY_PANEL", flag)
+        skm_option("SKM_HEAVY_PANEL", flag)
         out = pipe.step(batch)
         stats[flag] = engine.matrix_row_stats(ctx, out, n, n, out.shape[1])
     ps = (C.c_int64 * 6)()
@@ -1727,13 +1736,16 @@ def test_group_sum_cosine_vs_totals_and_top2(ctx, tag):
     assert (idx2 == out["top2_index"]).all() and np.abs(val2 - out["top2_score"]).max() <= COS_TOL
     # the route a handful of columns takes by default (cursor kernel, no neighbour lists) gives the same bits
     # as the list path the test session pins (tests/conftest.py)
-    old_path = os.environ.pop("SKM_COSINE_PATH", None)
+    from snekmer_amd import _hip
+
+    old_path = _hip.get_option("SKM_COSINE_PATH")
+    _hip.set_option("SKM_COSINE_PATH", None)
     try:
         S_def, ld_def = skm_apply.cosine_rows_vs_totals(ctx, csr, basis.ncols, out["totals"])
         S_def = S_def.download().reshape(-1, ld_def)[:n, :2]
     finally:
         if old_path is not None:
-            os.environ["SKM_COSINE_PATH"] = old_path
+            _hip.set_option("SKM_COSINE_PATH", old_path)
     assert (S_def == S).all()
 
 
@@ -2358,7 +2370,7 @@ def test_config4_one_rank_share_125k_rows_vs_1m(ctx):
 # ------------------------------------------------------------------ fused vectorize (no host synchronisation)
 @pytest.mark.cosine_paths
 @pytest.mark.parametrize("name,k", [("red6", 12), ("standard", 12), ("hydro", 20), ("hydro", 3), ("hydro", 32)])
-def test_fused_vectorize_equals_the_three_call_form(ctx, name, k, monkeypatch):
+def test_fused_vectorize_equals_the_three_call_form(ctx, name, k, skm_option):
     """skm_vectorize_csr (count + basis/postings + norms in one call, sizes left on the device) against
     skm_count_csr + skm_basis_build + skm_row_norms_csr: every output array identical, and the cosine matrix with it;
     all size classes (long sequences take the LDS-block and global-scratch count kernels), both code widths.
@@ -2403,10 +2415,10 @@ def test_fused_vectorize_equals_the_three_call_form(ctx, name, k, monkeypatch):
     # The library's own sort reads the entry count on the device.  The vendor sort (SKM_SORT=rocprim, kept for A/B
     # timing) sorts the capacity instead, over a sentinel fill past the entry count: both are stable sorts of the same
     # keys, so every array is the same again.
-    monkeypatch.setenv("SKM_SORT", "onesweep")  # (the default picks by size: this batch is below the switch-over)
+    skm_option("SKM_SORT", "onesweep")  # (the default picks by size: this batch is below the switch-over)
     Sd = engine.Pipeline(ctx, lut, k, fused=True, dense_route=False).step(batch)
     assert (Sd.download().reshape(Sd.shape)[:n, :n] == Sb).all()
-    monkeypatch.setenv("SKM_SORT", "rocprim")
+    skm_option("SKM_SORT", "rocprim")
     c = engine.Pipeline(ctx, lut, k, fused=True, dense_route=False)
     Sc = c.step(batch)
     assert (Sc.download().reshape(Sc.shape)[:n, :n] == Sb).all()
@@ -2419,6 +2431,38 @@ def test_fused_vectorize_equals_the_three_call_form(ctx, name, k, monkeypatch):
 
 
 @pytest.mark.cosine_paths
+@pytest.mark.parametrize("name,n", [("red6", 4500), ("red6", 8500), ("red6", 12500), ("red6", 16000), ("standard", 4500), ("standard", 9000)])
+def test_own_sort_every_tile_shape_equals_the_vendor_sort(ctx, name, n, skm_option):
+    """skm_onesweep.h picks its tile by the capacity (256 x 8 up to 1 M keys, 1024 x 8 / x 12 / x 16 so that a grid of up to
+    4 M 4-byte keys is resident at once, 512 x 8 above and for 8-byte keys from 2 M): batches of 1.3 / 2.5 / 3.7 / 4.7 M
+    entries with 4-byte codes and 1.3 / 2.7 M with 8-byte codes through the fused vectorize call with the own sort and with
+    rocPRIM's - both stable sorts of the same keys, so every array of the basis stage and the cosine are identical."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_families
+
+    lut = A.build_lut(name)
+    res, off, _ = synth_families(n, 300, family=50, seed=77 + n)
+    batch = engine.SeqBatch(ctx, res, off)
+    got = {}
+    for srt in ("onesweep", "rocprim"):
+        skm_option("SKM_SORT", srt)
+        p = engine.Pipeline(ctx, lut, 12, dense_route=False)
+        for _ in range(2):
+            S = p.step(batch)
+        nnz, B = p.csr.nnz, p.basis.ncols
+        ld = S.shape[1]
+        got[srt] = (nnz, B, p.csr.colidx.download(nnz), p.basis.codes.download(B), p.basis.colptr.download(B + 1),
+                    engine.matrix_row_stats(ctx, S, n, n, ld), S.download(ld, offset=(n // 2) * ld))
+        p = S = None
+    a, b = got["onesweep"], got["rocprim"]
+    assert a[0] == b[0] > 1000000 and a[1] == b[1]
+    for x, y in zip(a[2:5], b[2:5]):
+        assert (x == y).all()
+    assert (a[5][0] == b[5][0]).all() and (a[5][1] == b[5][1]).all() and (a[6] == b[6]).all()
+    assert (np.diff(a[3].astype(np.uint64)) > 0).all()  # the basis: strictly increasing codes
+
+
 @pytest.mark.parametrize("seqs", [["MKV", "", "XXXXXXXXXXXXXXXXXXXX", "*"], ["MKVLAAGIWSTCMKVLAAGIWSTC"],
                                   ["MKVLAAGIWSTCDE", "MKVLAAGIWSTCDE", "XX"]])
 def test_fused_vectorize_degenerate_batches(ctx, seqs):

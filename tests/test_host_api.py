@@ -50,10 +50,36 @@ def test_product_library_carries_no_result_invalidating_switches():
     blob = open(_hip.LIB_PATH, "rb").read()
     for needle in (b"SKM_COSINE_ABLATE", b"SKM_GRAM_ABLATE", b"skm_debug_gram_phases"):
         assert needle not in blob
-    src = open(os.path.join(ROOT, "snekmer_amd", "csrc", "skm_cosine_csr.hip")).read()
-    for m in re.finditer(r"getenv\(\"(SKM_[A-Z_]+ABLATE)\"\)", src):
-        before = src[: m.start()]
-        assert before.rfind("#ifdef SKM_DIAG") > before.rfind("#endif"), m.group(1)
+    # the ablation switches are read (skm_opts().*_ablate) inside #ifdef SKM_DIAG only, and no call path reads the environment
+    for name in ("skm_cosine_csr.hip", "skm_dense.hip", "skm_basis.hip", "skm_kmer.hip", "skm_common.h"):
+        src = open(os.path.join(ROOT, "snekmer_amd", "csrc", name)).read()
+        assert "getenv(" not in src, name
+        for m in re.finditer(r"skm_opts\(\)\.(cosine_ablate|gram_ablate|overlap_blocks|dense_split)", src):
+            before = src[: m.start()]
+            assert before.rfind("#ifdef SKM_DIAG") > before.rfind("#endif"), (name, m.group(1))
+
+
+def test_options_start_from_the_environment_and_refuse_what_they_do_not_know():
+    """skm_set_option / skm_get_option: process-wide switches between exact kernels; the environment is read once."""
+    import subprocess
+    import sys
+
+    assert _hip.get_option("SKM_SORT") in (None, os.environ.get("SKM_SORT"))
+    with _hip.options(SKM_SORT="rocprim", SKM_HEAVY_PANEL=0):
+        assert _hip.get_option("SKM_SORT") == "rocprim" and _hip.get_option("SKM_HEAVY_PANEL") == "0"
+        with _hip.options(SKM_SORT="onesweep"):
+            assert _hip.get_option("SKM_SORT") == "onesweep"
+        assert _hip.get_option("SKM_SORT") == "rocprim"
+    assert _hip.get_option("SKM_SORT") == os.environ.get("SKM_SORT") and _hip.get_option("SKM_HEAVY_PANEL") == os.environ.get("SKM_HEAVY_PANEL")
+    for name, value in (("SKM_SORT", "bubble"), ("SKM_NO_SUCH", "1"), ("SKM_DENSE_VARIANT", "12"), ("SKM_HEAVY_PANEL", "yes"),
+                        ("SKM_COSINE_ABLATE", "1")):
+        with pytest.raises(_hip.HipError, match="BADARG"):
+            _hip.set_option(name, value)
+    # a fresh process starts from its environment
+    code = "from snekmer_amd import _hip; print(_hip.get_option('SKM_COSINE_PATH'), _hip.get_option('SKM_GRAM_SHAPE'))"
+    env = dict(os.environ, SKM_COSINE_PATH="lists", SKM_GRAM_SHAPE="3", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["lists", "3"]
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -31,10 +31,7 @@ rows = {v: [] for v in variants}
 ctx.profile_enable(True)
 for rnd in range(5):
     for vname, env in variants.items():
-        os.environ["SKM_DENSE_VARIANT"] = env
-        os.environ.pop("SKM_DENSE_ABLATE", None)
-        if vname in ABL:
-            os.environ["SKM_DENSE_ABLATE"] = ABL[vname]
+        _hip.set_option("SKM_DENSE_VARIANT", env)
         ctx.profile_reset()
         out = engine.cosine_dense_i8(ctx, n, n, kdim, pipe.dense, pipe.dense, pipe.rnorm, pipe.rnorm, out=pipe.out)
         ms = ctx.profile_read("k_cosine_dense_i8")[1]
@@ -51,7 +48,7 @@ for rnd in range(5):
                 print(f"symmetric vs full: max |diff| {d:.2e} (rounding order of the two norms)")
             else:
                 assert (sample == ref).all(), f"variant {vname} differs from the first variant"
-os.environ.pop("SKM_DENSE_VARIANT")
+_hip.set_option("SKM_DENSE_VARIANT", None)
 for vname, v in rows.items():
     ms = sorted(v)[len(v) // 2]
     full = 2.0 * n * n * kdim

@@ -15,9 +15,7 @@ ctx = _hip.Context(0)
 lut = alphabet.build_lut("red6")
 out = None
 for shuffle, overlap in ((True, False), (False, False), (True, True), (False, True)):
-    os.environ.pop("SKM_COSINE_OVERLAP", None)
-    if overlap:
-        os.environ["SKM_COSINE_OVERLAP"] = "1"
+    _hip.set_option("SKM_COSINE_OVERLAP", 1 if overlap else None)
     res, off, _ = synth_families(n, 300, family=100, seed=BASE_SEED + 2, shuffle=shuffle)
     batch = engine.SeqBatch(ctx, res, off)
     p = engine.Pipeline(ctx, lut, 12)

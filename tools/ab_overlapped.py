@@ -40,7 +40,9 @@ def main():
         side = _hip.Context(0, cu_groups=groups("SKM_AB_SIDE_GROUPS"))
     # SKM_AB_FRACTION=f: the neighbour lists of the last f * n rows are built on the side context
     frac = float(os.environ["SKM_AB_FRACTION"]) if os.environ.get("SKM_AB_FRACTION") else None
-    b = engine.OverlappedPipeline(ctx, lut, 12, side_ctx=side, side_list_fraction=frac)
+    # SKM_AB_DEPTH=d: d batches in flight on side contexts
+    depth = int(os.environ.get("SKM_AB_DEPTH", "1"))
+    b = engine.OverlappedPipeline(ctx, lut, 12, side_ctx=side, side_list_fraction=frac, depth=depth)
     b.out = a.step(batch)  # share the 40 GB result buffer
     ctx.sync()
     ld = a.out.shape[1]
@@ -48,13 +50,14 @@ def main():
     rows = np.linspace(0, n - 1, 64).astype(np.int64)
     want = [a.out.download(n, offset=int(r) * ld) for r in rows]
     ctx.call("skm_memset", __import__("ctypes").c_void_p(a.out.ptr), 0, __import__("ctypes").c_size_t(a.out.nbytes))
-    b.prefetch(batch)
+    for _ in range(depth):
+        b.prefetch(batch)
     b.step(batch)
     b.sync()
     sums_b, nnz_b = engine.matrix_row_stats(ctx, b.out, n, n, ld)
     same = bool((sums_a == sums_b).all() and (nnz_a == nnz_b).all() and
                 all((b.out.download(n, offset=int(r) * ld) == w).all() for r, w in zip(rows, want)))
-    out = {"n": n, "steps": steps, "identical": same, "runs": []}
+    out = {"n": n, "steps": steps, "depth": depth, "fraction": b.fraction, "identical": same, "runs": []}
     for rep in range(3):
         a.step(batch)
         ctx.sync()
@@ -72,7 +75,8 @@ def main():
         tb = (time.perf_counter() - t0) / steps * 1e3
         out["runs"].append({"pipeline_ms": ta, "overlapped_ms": tb})
     # drain the prefetched batch so that the process ends with nothing queued
-    b.step(None)
+    for _ in range(depth):
+        b.step(None)
     b.sync()
     print(json.dumps(out))
 

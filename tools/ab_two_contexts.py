@@ -34,7 +34,6 @@ def run(k, steps=12):
 
 
 for env in ({}, {"SKM_COSINE_OVERLAP": "1"}):
-    os.environ.pop("SKM_COSINE_OVERLAP", None)
-    os.environ.update(env)
+    _hip.set_option("SKM_COSINE_OVERLAP", env.get("SKM_COSINE_OVERLAP"))
     for k in (1, 2, 1, 2):
         print(f"{env or 'back to back'}: {k} context(s): {run(k):.3f} ms/step")

@@ -54,25 +54,24 @@ rows = {}
 for rnd in range(3):
     for name, env in cases:
         for k in KNOBS:
-            os.environ.pop(k, None)
-        os.environ.update(env)
+            _hip.set_option(k, env.get(k))
         ctx.profile_reset()
         pipe.cosine()
         rows.setdefault(name, []).append(tuple(ctx.profile_read(k)[1] for k in
                                                ("k_gram_sparse", "k_gram_sparse_big", "k_cosine_write", "k_cosine_strip")))
 for k in KNOBS:
-    os.environ.pop(k, None)
+    _hip.set_option(k, None)
 print(f"{'case':28s} gram   big    write  cursor   (ms, median of 3)")
 for name, v in rows.items():
     med = [sorted(x[i] for x in v)[1] for i in range(4)]
     print(f"{name:28s} " + " ".join(f"{x:6.2f}" for x in med))
 
-os.environ["SKM_GRAM_ABLATE"] = "3"
+_hip.set_option("SKM_GRAM_ABLATE", 3)
 pipe.cosine()
 ticks = (C.c_ulonglong * 8)()
 ctx.lib.skm_debug_gram_phases.argtypes = [C.c_void_p, C.c_void_p]
 ctx.lib.skm_debug_gram_phases(ctx.handle, ticks)
-os.environ.pop("SKM_GRAM_ABLATE")
+_hip.set_option("SKM_GRAM_ABLATE", None)
 names = ["zero+rowptr", "tasks+scan", "pair loop", "emit"]
 tot = sum(ticks[:4]) or 1
 print("gram phases (ticks per row, share of workgroup lifetime): " +

@@ -20,7 +20,7 @@ ctx.profile_enable(True)
 out = {}
 for label, var in (("symmetric", None), ("rectangular", "11")):
     if var:
-        os.environ["SKM_DENSE_VARIANT"] = var
+        _hip.set_option("SKM_DENSE_VARIANT", var)
     for _ in range(2):
         engine.cosine_dense_i8(ctx, nm, nm, dp.kdim, dp.dense, dp.dense, dp.rnorm, dp.rnorm, out=dp.out)
     ctx.profile_reset()
@@ -28,5 +28,5 @@ for label, var in (("symmetric", None), ("rectangular", "11")):
         engine.cosine_dense_i8(ctx, nm, nm, dp.kdim, dp.dense, dp.dense, dp.rnorm, dp.rnorm, out=dp.out)
     ms = ctx.profile_read("k_cosine_dense_i8")[1] / 5
     out[label] = {"ms": round(ms, 3), "POPS_full_product": round(2.0 * nm * nm * dp.kdim / (ms * 1e-3) / 1e15, 3)}
-    os.environ.pop("SKM_DENSE_VARIANT", None)
+    _hip.set_option("SKM_DENSE_VARIANT", None)
 print(json.dumps(out))

@@ -11,7 +11,7 @@ from snekmer_amd import _hip, engine
 
 ctx = _hip.Context(0)
 rng = np.random.default_rng(0)
-os.environ["SKM_DENSE_SPLIT"] = "1"
+# (a -DSKM_DIAG build can force the split count: _hip.set_option("SKM_DENSE_SPLIT", 1))
 for n, kdim in ((1024, 256), (1024, 1024), (1024, 4096), (3383, 256), (3383, 1024), (3383, 6656), (8192, 256), (8192, 6656)):
     X = (rng.random((n, kdim)) < 0.05).astype(np.int8)
     d = ctx.to_device(X)

@@ -92,10 +92,7 @@ def main():
                            ("11", "rectangular launch, v5: A through LDS, B straight into registers (what a rectangular X, Y call runs)"),
                            ("6", "symmetric launch (X is Y: upper tiles + mirrored stores), v4"),
                            (None, "symmetric launch, v5 (what DensePipeline runs)")):
-        if variant:
-            os.environ["SKM_DENSE_VARIANT"] = variant
-        else:
-            os.environ.pop("SKM_DENSE_VARIANT", None)
+        _hip.set_option("SKM_DENSE_VARIANT", variant)
         engine.cosine_dense_i8(ctx, n, n, k, d, d, rn, rn, out=res)
         ctx.sync()
         t0 = time.perf_counter()
@@ -112,7 +109,7 @@ def main():
         out.setdefault("product", []).append({"call": f"skm_cosine_dense_i8: {label}", "ms": ms, "POPS_by_full_problem": ops / (ms * 1e-3) / 1e15,
                                               "equals_first_variant_of_its_kind_on_sample": digest == ref_sum,
                                               "note": "includes the float32 scaling epilogue and the operand re-tiling pass"})
-    os.environ.pop("SKM_DENSE_VARIANT", None)
+    _hip.set_option("SKM_DENSE_VARIANT", None)
     print(json.dumps(out))
 
 
