@@ -83,10 +83,13 @@ __global__ __launch_bounds__(TB) void k_pass(const int64_t *__restrict__ d_n, co
     const int shift = pass * RADIX_BITS;
     const uint32_t mask = (1u << min(RADIX_BITS, key_bits - shift)) - 1u;
     const int64_t n = *d_n;
-    // tiles in arrival order (atomic ticket), so that every tile a look-back waits for is already running.  (Tiles by
-    // blockIdx for a grid that is resident as a whole measured 2 us faster per pass; HIP promises nothing about dispatch
-    // order, a 128 KiB writer workgroup of another stream may leave room for one of these per CU instead of five, and a
-    // long fuzz run of round 5 stopped once, unexplained, with that path in the library: the ticket is taken always.)
+    // tiles in arrival order (atomic ticket), so that every tile a look-back waits for is already running: a workgroup
+    // only ever waits for workgroups that hold a ticket, whatever else shares the chip.  (Tiles by blockIdx for a grid that
+    // is resident as a whole measured 2 us faster per pass, and is a deadlock with other streams around: workgroups go
+    // round-robin to the 8 XCDs, each XCD starts its share in order, and the passes of TWO contexts' sorts - or a sort
+    // beside another stream's 128 KiB writer workgroups - can fill XCD a with tiles of sort A that spin on a tile waiting
+    // for room on XCD b, which is full of tiles of sort B spinning on one that waits for room on XCD a.  A long fuzz run
+    // of round 5 stopped once with that path in the library; the ticket is taken always.)
     if (tid == 0)
         s_tile = atomicAdd(&st->ticket[pass], 1u);
     for (int z = tid; z < NW * RADIX; z += TB)
