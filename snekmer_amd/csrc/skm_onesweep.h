@@ -25,7 +25,7 @@
 #define SKM_OS_LARGE_TB 512  // (29 M pairs, 4 passes: 1024 x 8 0.99 ms, 512 x 8 0.89, 256 x 8 1.13; rocPRIM 0.85)
 #endif
 #ifndef SKM_OS_SMALL_LOG2
-#define SKM_OS_SMALL_LOG2 20
+#define SKM_OS_SMALL_LOG2 19
 #endif
 
 namespace skm_onesweep {
@@ -272,8 +272,8 @@ static inline size_t state_bytes(int64_t cap, int tile, int passes)
     return sizeof(state_header) + sizeof(uint32_t) * (size_t)ntiles * RADIX * (size_t)passes;
 }
 
-// Tile shape (threads, keys per thread) for `cap` keys of `key_bytes` bytes.  Small inputs: 256 x 8 (many tiles in flight:
-// the passes are latency-bound there).  From 1 M keys the passes are bound by how many ROUNDS of workgroups the grid
+// Tile shape (threads, keys per thread) for `cap` keys of `key_bytes` bytes.  Up to 0.5 M keys: 256 x 8 (many tiles in flight:
+// the passes are latency-bound there; 1.0 M keys: 0.109 ms with it, 0.094 with 1024 x 8).  Above, the passes are bound by how many ROUNDS of workgroups the grid
 // takes (a pass of 354 tiles of 1024 x 8 on 256 CUs takes as long as one of 512), so the tile grows with the input to
 // keep the whole grid resident at once - 1024 x 8 / x 12 / x 16, one workgroup per CU (LDS: 8 or 12 bytes per key) - up to
 // 4 M keys; above that 512 x 8 (29 M pairs, 4 passes: 1024 x 8 0.99 ms, 512 x 8 0.89, 256 x 8 1.13; rocPRIM 0.85).
