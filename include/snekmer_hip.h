@@ -58,6 +58,7 @@ int skm_device_count(int *h_count);
  *   SKM_SORT            "rocprim" | "onesweep": the basis stage's sort whatever the size (default: by size)
  *   SKM_COSINE_PATH     "lists" | "cursor": skm_cosine_csr's routing (default: by shape)
  *   SKM_HEAVY_PANEL     "0" | "1": heavy-row panels off / on (default: by the previous call's heavy-row count)
+ *   SKM_HEAVY_PACK      "0" | "1": 16-bit packed tiles for heavy rows off / on (default: by the same count)
  *   SKM_COSINE_OVERLAP  "1": the blocked two-stream schedule inside skm_cosine_csr
  *   SKM_GRAM_SHAPE      "1".."4": lane-group shape of k_gram_sparse
  *   SKM_DENSE_VARIANT   "1" | "2" | "6" | "7" | "10" | "11": the int8 GEMM kernel (see skm_cosine_dense_i8)

@@ -197,7 +197,7 @@ def _check(lib, status: int):
         raise HipError(status, lib.skm_last_error().decode("utf-8", "replace"))
 
 
-OPTION_NAMES = ("SKM_SORT", "SKM_COSINE_PATH", "SKM_HEAVY_PANEL", "SKM_COSINE_OVERLAP", "SKM_GRAM_SHAPE", "SKM_DENSE_VARIANT")
+OPTION_NAMES = ("SKM_SORT", "SKM_COSINE_PATH", "SKM_HEAVY_PANEL", "SKM_HEAVY_PACK", "SKM_COSINE_OVERLAP", "SKM_GRAM_SHAPE", "SKM_DENSE_VARIANT")
 
 
 def set_option(name: str, value) -> None:

@@ -24,6 +24,7 @@ const option_desc OPTIONS[] = {
     {"SKM_SORT", &skm_options::sort, 0, SORT_WORDS, 0, 0, false},
     {"SKM_COSINE_PATH", &skm_options::cosine_path, 0, PATH_WORDS, 0, 0, false},
     {"SKM_HEAVY_PANEL", &skm_options::heavy_panel, -1, nullptr, 0, 1, false},
+    {"SKM_HEAVY_PACK", &skm_options::heavy_pack, -1, nullptr, 0, 1, false},
     {"SKM_COSINE_OVERLAP", &skm_options::cosine_overlap, 0, nullptr, 0, 1, false},
     {"SKM_GRAM_SHAPE", &skm_options::gram_shape, 0, nullptr, 0, 4, false},
     {"SKM_DENSE_VARIANT", &skm_options::dense_variant, 0, nullptr, 0, 11, false},
@@ -32,6 +33,7 @@ const option_desc OPTIONS[] = {
     {"SKM_GRAM_ABLATE", &skm_options::gram_ablate, 0, nullptr, 0, 4, true},
     {"SKM_OVERLAP_BLOCKS", &skm_options::overlap_blocks, 0, nullptr, 0, 16, true},
     {"SKM_DENSE_SPLIT", &skm_options::dense_split, 0, nullptr, 0, 8, true},
+    {"SKM_HEAVY_ABLATE", &skm_options::heavy_ablate, 0, nullptr, 0, 31, true},
 #endif
 };
 skm_options g_env_opts, g_opts;

@@ -138,11 +138,12 @@ struct skm_options {
     int sort = 0;            // SKM_SORT: 0 by size, 1 rocprim, 2 onesweep
     int cosine_path = 0;     // SKM_COSINE_PATH: 0 by shape, 1 lists, 2 cursor
     int heavy_panel = -1;    // SKM_HEAVY_PANEL: -1 by the hint, 0 off, 1 on
+    int heavy_pack = -1;     // SKM_HEAVY_PACK: -1 by the hint, 0 off, 1 on
     int cosine_overlap = 0;  // SKM_COSINE_OVERLAP
     int gram_shape = 0;      // SKM_GRAM_SHAPE
     int dense_variant = 0;   // SKM_DENSE_VARIANT
     // diagnostic builds only (-DSKM_DIAG: results NOT valid for the ablations)
-    int cosine_ablate = 0, gram_ablate = 0, overlap_blocks = 0, dense_split = 0;
+    int cosine_ablate = 0, gram_ablate = 0, overlap_blocks = 0, dense_split = 0, heavy_ablate = 0;
 };
 const skm_options &skm_opts();
 

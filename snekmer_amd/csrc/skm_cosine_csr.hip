@@ -528,6 +528,7 @@ constexpr int HEAVY_CH = 32768, HEAVY_TB = 1024, HEAVY_EMAX = 2048, HEAVY_U = 4,
 // 128 KiB tile + 24 KiB of list state: this kernel (like the writer's 128 KiB tile) needs gfx950's 160 KiB of LDS per
 // workgroup; the library is built for gfx950 only (csrc/Makefile).
 static_assert(HEAVY_CH * 4 + 3 * HEAVY_EMAX * 4 + 64 <= 160 * 1024, "k_cosine_heavy needs 160 KiB of LDS (gfx950)");
+constexpr int HEAVYK_TB = 1024, HEAVYK_EMAX = 2048;  // the PACK forms: 64 KiB tile (two columns per word) + 24 KiB of list state + 64 KiB of cached postings
 constexpr int HEAVYP_CH = 32768, HEAVYP_TB = 1024, HEAVYP_EMAX = 2048;  // the PANEL form (16384 / 512 / 1024, two workgroups per CU, measured slower: 15.3 vs 13.8 ms)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "libsnekmer_hip is written for gfx950 (MI355X): 160 KiB LDS tiles, gfx950 MFMA shapes"
@@ -541,7 +542,25 @@ constexpr int HEAVYP_CH = 32768, HEAVYP_TB = 1024, HEAVYP_EMAX = 2048;  // the P
 // HC columns per step, HT threads, HE list entries: (32768, 1024, 2048) = one workgroup per CU, the general form;
 // (16384, 512, 1024) = the PANEL form: two workgroups per CU (what remains to walk beside a panel is a few short lists:
 // the row is bound by the latency of its steps, which a second row in flight hides)
-template <int MODE, bool VEC, typename PW, bool PANEL, int HC, int HT, int HE>
+// PACK: TWO columns per 32-bit accumulator word (16 bits each), for rows whose dot products are all below 2^16 by
+// Cauchy-Schwarz (rnorm_x * min_j rnorm_y > 2^-16: every row of ordinary proteins; the sums are of non-negative terms, so no
+// partial sum carries into the neighbour's half either).  The tile of a 32768-column step is then 64 KiB, and the 64 KiB it
+// frees hold a CACHE of the row's postings: (neighbour row, v * v') of every list the panel does not cover, fetched ONCE per
+// row in one round of loads - all short lists if their postings fit, the long ones too if there is room - and scanned
+// out of LDS in every column step.  Without it every list is visited in every step (a cursor, a round trip to its
+// postings, mostly to find that none falls into the step's columns): the row's time was those rounds - with 8 instead of
+// 16 waves per row and two rows per CU (a 512-thread form of PACK) a row took exactly twice as long.  Rows that fail
+// the 16-bit test are left to the launch of the unpacked form behind this one; lists that do not fit the cache are walked
+// per step as before.
+#ifdef SKM_DIAG
+// timing-only ablations of k_cosine_heavy (results NOT valid; SKM_HEAVY_ABLATE bits: 1 no global stores, 2 no walk of long
+// lists, 4 no panel row, 8 no short lists / cache, 16 nothing after the row's set-up)
+__device__ int g_heavy_abl;
+#define SKM_HEAVY_ABL(bit) (heavy_abl & (bit))
+#else
+#define SKM_HEAVY_ABL(bit) false
+#endif
+template <int MODE, bool VEC, typename PW, bool PANEL, int HC, int HT, int HE, bool PACK = false>
 __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__ xrowptr,
                                                            const uint32_t *__restrict__ xcolidx,
                                                            const uint32_t *__restrict__ xcounts,
@@ -553,18 +572,33 @@ __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__
                                                            const uint32_t *__restrict__ row_list,
                                                            const uint32_t *__restrict__ row_count,
                                                            uint32_t *__restrict__ g_len, float *__restrict__ out, int64_t ld,
-                                                           panel_bufs pnl)
+                                                           panel_bufs pnl, const float *__restrict__ min_yrnorm)
 {
     constexpr int CHH = HC, TBH = HT, NW = HT / 64, U = HEAVY_U;
-    static_assert(HC * 4 + 3 * HE * 4 + 1024 <= (HT == 1024 ? 160 : 80) * 1024, "LDS budget of k_cosine_heavy");
-    __shared__ __attribute__((aligned(16))) int s_acc[CHH];
+    constexpr int ACCW = PACK ? HC / 2 : HC;  // accumulator words per step
+    constexpr bool CACHE = PACK;
+    constexpr int CN = CACHE ? 8192 : 1;  // cached postings per row
+    static_assert(ACCW * 4 + 3 * HE * 4 + (CACHE ? CN * 8 : 0) + 1024 <= (HT == 1024 ? 160 : 80) * 1024, "LDS budget of k_cosine_heavy");
+    __shared__ __attribute__((aligned(16))) int s_acc[ACCW];
+    __shared__ uint2 s_cache[CN];                     // (neighbour row, v * v')
+    __shared__ uint32_t s_ncache, s_tshort, s_tlong;  // cache fill; postings behind the row's short / long lists
     __shared__ uint32_t s_cur[HE], s_end[HE], s_val[HE];
     __shared__ uint32_t s_nlong, s_nshort, s_self;
     __shared__ uint32_t s_jb[PB_STEPS + 2];  // PANEL: first entry of the block's row list J at or after every column step's start
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t cnt = *row_count;
-    for (int z = tid; z < CHH / 4; z += TBH)
+    for (int z = tid; z < ACCW / 4; z += TBH)
         reinterpret_cast<int4 *>(s_acc)[z] = make_int4(0, 0, 0, 0);
+    auto acc_add = [&](uint32_t off, int val) {
+        if (PACK)
+            atomicAdd(&s_acc[off >> 1], val << ((off & 1u) * 16u));
+        else
+            atomicAdd(&s_acc[off], val);
+    };
+    const float min_yr = PACK ? *min_yrnorm : 0.0f;
+#ifdef SKM_DIAG
+    const int heavy_abl = g_heavy_abl;
+#endif
     for (uint32_t idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
         const int64_t r = rbase + row_list[PANEL ? pnl.perm[idx] : idx];  // row counted from row0 (g_len, out)
         const int64_t i = row0 + r;
@@ -572,13 +606,18 @@ __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__
         const uint32_t pblk = idx / (uint32_t)PB_ROWS, prow = idx % (uint32_t)PB_ROWS;
         const uint32_t pK = (PANEL && pblk < (uint32_t)pnl.nb) ? pnl.meta[pblk * 4 + 0] : 0u;
         const uint32_t pJ = pK ? pnl.meta[pblk * 4 + 1] : 0u;
-        if (PANEL ? pK == 0u : g_len[r] == G_DONE_ROW)  // uniform.  PANEL form: only rows with a panel (the general
-            continue;                                    // form, launched behind it, takes the others); general form: not again
+        if (g_len[r] == G_DONE_ROW || (PANEL && pK == 0u))  // uniform.  Not again; PANEL form: only rows with a panel (the
+            continue;                                        // general form, launched behind it, takes the others)
+        if (PACK && !((double)xrnorm[i] * (double)min_yr > 0x1p-16 * (1.0 + 1e-3)))  // a dot product may need more than 16 bits
+            continue;
         __syncthreads();  // the previous row's tile and lists are no longer in use
         if (tid == 0) {
             s_nlong = 0;
             s_nshort = 0;
             s_self = 0;
+            s_ncache = 0;
+            s_tshort = 0;
+            s_tlong = 0;
         }
         static_assert(!PANEL || CHH == PB_STEP_COLS, "k_panel_rows cuts J at multiples of PB_STEP_COLS");
         if (PANEL && pJ && tid <= PB_STEPS)  // J is sorted: the part of it inside column step t is [s_jb[t], s_jb[t + 1])
@@ -626,6 +665,18 @@ __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__
                 s_end[slot] = pe;
                 s_val[slot] = v;
             }
+            if (CACHE) {  // postings behind the short and the long lists (wave sums)
+                uint32_t ts = is_short ? pe - pb : 0u, tl = is_long ? min(pe - pb, 1u << 20) : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    ts += __shfl_xor(ts, o);
+                    tl += __shfl_xor(tl, o);
+                }
+                if (lane == 0 && ts)
+                    atomicAdd(&s_tshort, ts);
+                if (lane == 0 && tl)
+                    atomicAdd(&s_tlong, min(tl, 1u << 20));
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
@@ -637,6 +688,65 @@ __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__
         if (nlong + nshort > (uint32_t)HE)  // uniform: the row stays flagged (cursor kernel)
             continue;
         const float ri = xrnorm[i];
+        // ---- CACHE: the row's postings into LDS, one round of loads (see the comment in front of the kernel)
+        if (SKM_HEAVY_ABL(16)) {
+            if (tid == 0)
+                g_len[r] = G_DONE_ROW;
+            continue;
+        }
+        const bool cache_short = CACHE && s_tshort <= (uint32_t)CN && !SKM_HEAVY_ABL(8);
+        const bool cache_long = cache_short && nlong && s_tlong <= (uint32_t)CN - s_tshort;
+        if (CACHE) {
+            if (cache_short) {
+                for (uint32_t l0 = (uint32_t)wid * 4u; l0 < nshort; l0 += NW * 4u) {
+                    const uint32_t l = l0 + (uint32_t)(lane >> 4), gl = (uint32_t)(lane & 15);
+                    const bool have = l < nshort;
+                    const uint32_t slot = (uint32_t)HE - 1u - (have ? l : 0u);
+                    const uint32_t p = s_cur[slot], pe = have ? s_end[slot] : 0u, v = s_val[slot];
+                    uint32_t base = 0;
+                    if (have && gl == 0)
+                        base = atomicAdd(&s_ncache, pe - p);
+                    base = __shfl(base, lane & 48);
+                    PW pw[4];
+#pragma unroll
+                    for (int round = 0; round < 4; ++round) {  // 4 x 16 >= 64 postings
+                        const uint32_t at = p + (uint32_t)round * 16u + gl;
+                        pw[round] = ypost[have && at < pe ? at : 0u];  // posting 0 exists: the row has a non-empty list
+                    }
+#pragma unroll
+                    for (int round = 0; round < 4; ++round) {
+                        const uint32_t at = p + (uint32_t)round * 16u + gl;
+                        if (have && at < pe)
+                            s_cache[base + (at - p)] = make_uint2(posting<PW>::row(pw[round]), v * posting<PW>::count(pw[round], ypostcnt, at));
+                    }
+                }
+            }
+            if (cache_long) {
+                for (uint32_t l = (uint32_t)wid; l < nlong; l += NW) {  // wave-uniform
+                    const uint32_t p = s_cur[l], pe = s_end[l], v = s_val[l];
+                    uint32_t base = 0;
+                    if (lane == 0)
+                        base = atomicAdd(&s_ncache, pe - p);
+                    base = __shfl(base, 0);
+                    for (uint32_t at0 = p; at0 < pe; at0 += (uint32_t)(U * 64)) {
+                        PW pw[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const uint32_t at = at0 + (uint32_t)(u * 64 + lane);
+                            pw[u] = ypost[at < pe ? at : 0u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const uint32_t at = at0 + (uint32_t)(u * 64 + lane);
+                            if (at < pe)
+                                s_cache[base + (at - p)] = make_uint2(posting<PW>::row(pw[u]), v * posting<PW>::count(pw[u], ypostcnt, at));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const uint32_t ncache = CACHE ? s_ncache : 0u;
         // PANEL: the row of G reaches the tile through registers that are loaded one step ahead, in front of the previous
         // step's stores: a wait for a load also waits for every store issued before it, so loads issued behind the
         // stores would expose the stores' latency in every step
@@ -664,7 +774,7 @@ __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__
             // group that still has postings in this column range, then adds them: one memory round trip per round of
             // the whole group (with one list at a time, the second and later rounds of every list were a round trip
             // each and set the kernel's rate)
-            if (nlong) {
+            if (nlong && !cache_long && !SKM_HEAVY_ABL(2)) {
                 constexpr int NG = HEAVY_NG;
                 for (uint32_t l0 = (uint32_t)wid * NG; l0 < nlong; l0 += NW * NG) {  // wave-uniform
                     uint32_t lp[NG], lpe[NG], lv[NG];
@@ -703,7 +813,7 @@ __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__
                                 const uint32_t j = posting<PW>::row(buf[g][u]);
                                 const bool in = act[g] && at < lpe[g] && j < j1u;
                                 if (in)
-                                    atomicAdd(&s_acc[j - j0u], (int)(lv[g] * posting<PW>::count(buf[g][u], ypostcnt, at)));
+                                    acc_add(j - j0u, (int)(lv[g] * posting<PW>::count(buf[g][u], ypostcnt, at)));
                                 took += (uint32_t)__popcll(__ballot(in));
                             }
                             lp[g] += took;
@@ -717,8 +827,16 @@ __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__
                             s_cur[l0 + g] = lp[g];
                 }
             }
+            // ---- the cached postings: those of this step's columns
+            if (CACHE) {
+                for (uint32_t q = (uint32_t)tid; q < ncache; q += (uint32_t)TBH) {
+                    const uint2 e = s_cache[q];
+                    if (e.x >= j0u && e.x < j1u)
+                        acc_add(e.x - j0u, (int)e.y);
+                }
+            }
             // ---- short lists (at most 64 postings): four lists per wave and round, 16 lanes each
-            for (uint32_t l0 = (uint32_t)wid * 4u; l0 < nshort; l0 += NW * 4u) {
+            for (uint32_t l0 = (uint32_t)wid * 4u; l0 < (cache_short || SKM_HEAVY_ABL(8) ? 0u : nshort); l0 += NW * 4u) {
                 const uint32_t l = l0 + (uint32_t)(lane >> 4), gl = (uint32_t)(lane & 15);
                 const bool have = l < nshort;
                 const uint32_t slot = (uint32_t)HE - 1u - (have ? l : 0u);
@@ -732,7 +850,7 @@ __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__
                     const uint32_t j = posting<PW>::row(pw);
                     const bool in = ok && j < j1u;
                     if (in)
-                        atomicAdd(&s_acc[j - j0u], (int)(v * posting<PW>::count(pw, ypostcnt, at)));
+                        acc_add(j - j0u, (int)(v * posting<PW>::count(pw, ypostcnt, at)));
                     const unsigned long long bal = __ballot(in);
                     const uint32_t took = (uint32_t)__popcll((bal >> (lane & 48)) & 0xFFFFull);
                     p += took;
@@ -744,17 +862,17 @@ __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__
                     s_cur[slot] = p;
             }
             if (tid == 0 && (uint32_t)i >= j0u && (uint32_t)i < j1u && s_self)
-                atomicAdd(&s_acc[(uint32_t)i - j0u], (int)s_self);
+                acc_add((uint32_t)i - j0u, (int)s_self);
             const uint32_t step = (uint32_t)(j0 / CHH);  // PANEL: m <= 2^20, at most PB_STEPS steps
-            if (PANEL && pJ) {  // the panel's share: row prow of G, scattered through the block's row list (ascending)
+            if (PANEL && pJ && !SKM_HEAVY_ABL(4)) {  // the panel's share: row prow of G, scattered through the block's row list (ascending)
 #pragma unroll
                 for (int u = 0; u < GP; ++u)
                     if (gv[u])
-                        atomicAdd(&s_acc[gj[u] - j0u], gv[u]);
+                        acc_add(gj[u] - j0u, gv[u]);
                 for (uint32_t q = s_jb[step] + (uint32_t)(tid + GP * TBH); q < s_jb[step + 1]; q += TBH) {  // more than 2048 rows of J in one step
                     const int g = grow[q];
                     if (g)
-                        atomicAdd(&s_acc[gjl[q] - j0u], g);
+                        acc_add(gjl[q] - j0u, g);
                 }
             }
             __syncthreads();
@@ -767,11 +885,19 @@ __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__
                 const int64_t jc = j0 + 4 * (int64_t)z;
                 if (jc >= m)
                     break;
-                const int4 a = reinterpret_cast<int4 *>(s_acc)[z];
-                reinterpret_cast<int4 *>(s_acc)[z] = make_int4(0, 0, 0, 0);
+                int4 a;
+                if (PACK) {
+                    const int2 w = reinterpret_cast<int2 *>(s_acc)[z];
+                    reinterpret_cast<int2 *>(s_acc)[z] = make_int2(0, 0);
+                    a = make_int4(w.x & 0xFFFF, (int)((uint32_t)w.x >> 16), w.y & 0xFFFF, (int)((uint32_t)w.y >> 16));
+                } else {
+                    a = reinterpret_cast<int4 *>(s_acc)[z];
+                    reinterpret_cast<int4 *>(s_acc)[z] = make_int4(0, 0, 0, 0);
+                }
                 // the neighbours' norms are only fetched for cells that hold a dot product: even a heavy row is mostly
                 // zeros (a family of 5 000 in 100 000 columns), and a load per store also makes every wait for a load
-                // drain the stores in front of it
+                // drain the stores in front of it.  (Round 5: all loads of a step issued before its first store, pieces
+                // held in registers: 12.4 vs 12.15 ms, 13.97 vs 13.14 unpacked - slower.)
                 float rj[4] = {0.f, 0.f, 0.f, 0.f};
                 if ((a.x | a.y | a.z | a.w) != 0) {
                     if (VEC && jc + 3 < m) {
@@ -793,6 +919,8 @@ __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__
                     }
                 }
                 float *dst = out + r * ld + jc;
+                if (SKM_HEAVY_ABL(1))
+                    continue;
                 if (VEC && jc + 3 < m) {
                     const f32x4 pack = {o[0], o[1], o[2], o[3]};
                     __builtin_nontemporal_store(pack, reinterpret_cast<f32x4 *>(dst));
@@ -1263,6 +1391,20 @@ bool heavy_panels_wanted(skm_ctx *ctx, int64_t nrows, int64_t m)
     return heavy >= 4096u;
 }
 
+// The packed form of k_cosine_heavy (two columns per accumulator word, the row's postings cached in LDS) is one or two more
+// launches in front of the unpacked one: taken when the previous call handed on a thousand rows or more (same stale
+// hint), or as SKM_HEAVY_PACK=1 / 0 says.
+bool heavy_pack_wanted(skm_ctx *ctx)
+{
+    if (skm_opts().heavy_pack >= 0)
+        return skm_opts().heavy_pack != 0;
+    const volatile uint32_t *last = (const volatile uint32_t *)((uint8_t *)ctx->h_pinned + 2048);
+    uint64_t heavy = 0;
+    for (int b = 0; b < 16; ++b)
+        heavy += last[b];
+    return heavy >= 1024u;
+}
+
 template <typename PW>
 int heavy_panels_run(skm_ctx *ctx, const int64_t *d_xrowptr, const uint32_t *d_xcolidx, const uint32_t *d_xcounts,
                      const uint32_t *d_ycolptr, const PW *d_ypost, const uint32_t *d_ypostcnt, int64_t m, int64_t row0,
@@ -1606,6 +1748,7 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
         }
         panel_bufs pnl = {};
         bool use_panels = false;
+        const bool pack_heavy = heavy_pack_wanted(ctx);
         if constexpr (sizeof(PW) == 8) {
             if (nblk == 1 && panels_first) {
                 const int prc = heavy_panels_run<PW>(ctx, d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, m, row0, b0, bn,
@@ -1617,20 +1760,35 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
         }
         {
             // rows the first pass could not hold: Gram and write fused, one row per workgroup, dense LDS tile
+#ifdef SKM_DIAG
+            {
+                const int abl_h = skm_opts().heavy_ablate;
+                SKM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_heavy_abl), &abl_h, sizeof(int), 0, hipMemcpyHostToDevice, s_w));
+            }
+#endif
             SKM_PROF_ON(ctx, "k_cosine_heavy", s_w);
+#define SKM_HEAVY_ARGS                                                                                               \
+    d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, d_ypost, d_ypostcnt, d_yrnorm, row0, b0, b_over_list, b_over_count, \
+        g_len, d_out, ld, pnl, &state->min_yrnorm
 #define SKM_HEAVY(MODE, VEC)                                                                                         \
     do {                                                                                                             \
-        if (use_panels) /* rows with a panel first (the PANEL form skips the others) */                              \
+        if (use_panels) { /* rows with a panel first (the PANEL forms skip the others); packed tiles, then what they left */ \
+            if (pack_heavy)                                                                                          \
+                k_cosine_heavy<MODE, VEC, PW, true, HEAVYP_CH, HEAVYK_TB, HEAVYK_EMAX, true>                         \
+                    <<<skm_grid_cap(ctx, bn, 1), HEAVYK_TB, 0, s_w>>>(SKM_HEAVY_ARGS);                               \
             k_cosine_heavy<MODE, VEC, PW, true, HEAVYP_CH, HEAVYP_TB, HEAVYP_EMAX><<<skm_grid_cap(ctx, bn, 1), HEAVYP_TB, 0, s_w>>>( \
-                d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, d_ypost, d_ypostcnt, d_yrnorm, row0, b0, b_over_list, \
-                b_over_count, g_len, d_out, ld, pnl);                                                                \
+                SKM_HEAVY_ARGS);                                                                                     \
+        }                                                                                                            \
         /* every row (left): the general form */                                                                     \
+        if (pack_heavy)                                                                                              \
+            k_cosine_heavy<MODE, VEC, PW, false, HEAVY_CH, HEAVYK_TB, HEAVYK_EMAX, true>                             \
+                <<<skm_grid_cap(ctx, bn, 1), HEAVYK_TB, 0, s_w>>>(SKM_HEAVY_ARGS);                                   \
         k_cosine_heavy<MODE, VEC, PW, false, HEAVY_CH, HEAVY_TB, HEAVY_EMAX><<<skm_grid_cap(ctx, bn, 1), HEAVY_TB, 0, s_w>>>( \
-            d_xrowptr, d_xcolidx, d_xcounts, d_xrnorm, m, d_ycolptr, d_ypost, d_ypostcnt, d_yrnorm, row0, b0, b_over_list, \
-            b_over_count, g_len, d_out, ld, pnl);                                                                    \
+            SKM_HEAVY_ARGS);                                                                                         \
     } while (0)
             SKM_BY_MODE_VEC(SKM_HEAVY);
 #undef SKM_HEAVY
+#undef SKM_HEAVY_ARGS
         }
         SKM_TRY(skm_check_launch("k_cosine_heavy"));
         {

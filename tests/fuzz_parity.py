@@ -134,7 +134,8 @@ def one_round(ctx, seed, verbose=False):
         ref = orc.cosine_rows(o_rowptr, ocol, o_counts, len(ob), rows)
         err = float(np.abs(S["three"][rows] - ref).max())
         assert err <= 1e-5, f"{tag}: cosine vs oracle {err}"
-        for env in ({"SKM_COSINE_PATH": "cursor"}, {"SKM_COSINE_PATH": "lists"}, {"SKM_COSINE_OVERLAP": "1", "SKM_COSINE_PATH": "lists"}):
+        for env in ({"SKM_COSINE_PATH": "cursor"}, {"SKM_COSINE_PATH": "lists"}, {"SKM_COSINE_OVERLAP": "1", "SKM_COSINE_PATH": "lists"},
+                    {"SKM_COSINE_PATH": "lists", "SKM_HEAVY_PACK": "1"}, {"SKM_COSINE_PATH": "lists", "SKM_HEAVY_PACK": "1", "SKM_HEAVY_PANEL": "1"}):
             with _hip.options(**env):
                 alt = p.cosine().download().reshape(p.out.shape)[:n, :n]
             same(alt, S["three"], f"cosine under {env}")

@@ -1270,8 +1270,11 @@ def test_heavy_rows_on_the_matrix_cores_equal_the_walk(ctx, skm_option, mode):
     b = pipe.basis
     ld = (n + 3) // 4 * 4
     outs = {}
-    for flag in ("0", "1"):
+    # panels off / on, and the heavy kernel's 16-bit packed tiles (two rows in flight per CU; rows whose dot products may
+    # need more than 16 bits - this batch has counts above 127 - are left to the unpacked launch behind it) off / on
+    for flag, pack in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
         skm_option("SKM_HEAVY_PANEL", flag)
+        skm_option("SKM_HEAVY_PACK", pack)
         S = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, b.ncols_hint(), b.colptr, b.post, pipe.rnorm, mode=mode, ld=ld)
         if flag == "1":
             import ctypes as C
@@ -1279,9 +1282,10 @@ def test_heavy_rows_on_the_matrix_cores_equal_the_walk(ctx, skm_option, mode):
             st = (C.c_int64 * 4)()
             ctx.call("skm_cosine_csr_stats", st)
             assert st[0] >= 6000  # rows handed to the heavy kernels
-        outs[flag] = S.download().reshape(-1, ld)[:n, :n].copy()
+        outs[flag + pack] = S.download().reshape(-1, ld)[:n, :n].copy()
         del S
-    assert (outs["0"] == outs["1"]).all()
+    assert (outs["00"] == outs["10"]).all() and (outs["00"] == outs["01"]).all() and (outs["00"] == outs["11"]).all()
+    outs["1"] = outs["11"]
     # a row block (what one rank computes) through the panels
     blk = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, b.ncols_hint(), b.colptr, b.post, pipe.rnorm, row0=3000, row1=9000,
                                mode=mode, ld=ld).download().reshape(-1, ld)[:6000, :n]
@@ -1581,6 +1585,20 @@ def test_heavy_rows_every_list_shape_vs_oracle(ctx, mode):
     S32 = engine.cosine_matrix(ctx, p32.csr, p32.rnorm, n, b32.ncols, b32.colptr, b32.post, p32.rnorm, mode=mode, ld=ld,
                                post_bits=32, postcnt=b32.postcnt)
     assert (S32.download().reshape(-1, ld)[:n, :n] == S).all()
+    # the heavy kernel with two columns per accumulator word (forced on: the default takes it from a thousand heavy rows in the
+    # previous call): both posting widths, vector and scalar stores, a row block
+    with _hip.options(SKM_HEAVY_PACK=1):
+        Sp = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, bs.ncols_hint(), bs.colptr, bs.post, pipe.rnorm, mode=mode, ld=ld)
+        assert (Sp.download().reshape(-1, ld)[:n, :n] == S).all()
+        Sp = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, bs.ncols_hint(), bs.colptr, bs.post, pipe.rnorm, mode=mode, ld=n + 1,
+                                  row0=301, row1=1777)
+        assert (Sp.download().reshape(-1, n + 1)[: 1777 - 301, :n] == S[301:1777]).all()
+        Sp = engine.cosine_matrix(ctx, p32.csr, p32.rnorm, n, b32.ncols, b32.colptr, b32.post, p32.rnorm, mode=mode, ld=ld,
+                                  post_bits=32, postcnt=b32.postcnt)
+        assert (Sp.download().reshape(-1, ld)[:n, :n] == S).all()
+    with _hip.options(SKM_HEAVY_PACK=0):
+        Sp = engine.cosine_matrix(ctx, pipe.csr, pipe.rnorm, n, bs.ncols_hint(), bs.colptr, bs.post, pipe.rnorm, mode=mode, ld=ld)
+        assert (Sp.download().reshape(-1, ld)[:n, :n] == S).all()
 
 
 @pytest.mark.parametrize("name,k", [("red6", 12), ("standard", 12), ("hydro", 14)])
@@ -1667,12 +1685,17 @@ def test_heavy_panels_at_100k_skewed_rows_equal_the_walk(ctx, skm_option):
     batch = engine.SeqBatch(ctx, res, off)
     pipe = engine.Pipeline(ctx, A.build_lut("red6"), 12)
     stats = {}
-    for flag in ("0", "1"):
+    for flag, pack in (("0", "0"), ("1", "0"), ("1", "1"), ("0", "1")):
         skm_option("SKM_HEAVY_PANEL", flag)
+        skm_option("SKM_HEAVY_PACK", pack)
         out = pipe.step(batch)
-        stats[flag] = engine.matrix_row_stats(ctx, out, n, n, out.shape[1])
-    ps = (C.c_int64 * 6)()
-    ctx.call("skm_heavy_panel_stats", ps)
+        stats[flag + pack] = engine.matrix_row_stats(ctx, out, n, n, out.shape[1])
+        if flag == "1" and pack == "1":
+            ps = (C.c_int64 * 6)()
+            ctx.call("skm_heavy_panel_stats", ps)
+    stats["0"], stats["1"] = stats["00"], stats["11"]
+    for key in ("10", "01"):
+        assert (stats[key][1] == stats["00"][1]).all() and (stats[key][0] == stats["00"][0]).all(), key
     assert ps[0] > 50000 and ps[2] <= ps[1] // 10  # tens of thousands of heavy rows, nearly every block with a panel
     assert (stats["0"][1] == stats["1"][1]).all()   # non-zero cells per row
     assert (stats["0"][0] == stats["1"][0]).all()   # row sums

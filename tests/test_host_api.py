@@ -48,13 +48,13 @@ def test_driver_build_hook_returns():
 def test_product_library_carries_no_result_invalidating_switches():
     """The timing-only ablations live in the -DSKM_DIAG build (libsnekmer_hip_diag.so) alone."""
     blob = open(_hip.LIB_PATH, "rb").read()
-    for needle in (b"SKM_COSINE_ABLATE", b"SKM_GRAM_ABLATE", b"skm_debug_gram_phases"):
+    for needle in (b"SKM_COSINE_ABLATE", b"SKM_GRAM_ABLATE", b"SKM_HEAVY_ABLATE", b"skm_debug_gram_phases"):
         assert needle not in blob
     # the ablation switches are read (skm_opts().*_ablate) inside #ifdef SKM_DIAG only, and no call path reads the environment
     for name in ("skm_cosine_csr.hip", "skm_dense.hip", "skm_basis.hip", "skm_kmer.hip", "skm_common.h"):
         src = open(os.path.join(ROOT, "snekmer_amd", "csrc", name)).read()
         assert "getenv(" not in src, name
-        for m in re.finditer(r"skm_opts\(\)\.(cosine_ablate|gram_ablate|overlap_blocks|dense_split)", src):
+        for m in re.finditer(r"skm_opts\(\)\.(cosine_ablate|gram_ablate|heavy_ablate|overlap_blocks|dense_split)", src):
             before = src[: m.start()]
             assert before.rfind("#ifdef SKM_DIAG") > before.rfind("#endif"), (name, m.group(1))
 

@@ -17,4 +17,4 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
 for k, d in agg.items():
     print(k)
     for c, v in sorted(d.items()):
-        print(f"   {c:32s} n={len(v):3d} avg={sum(v)/len(v):.4g}")
+        print(f"   {c:32s} n={len(v):3d} avg={sum(v)/len(v):.4g} sum={sum(v):.4g}")
