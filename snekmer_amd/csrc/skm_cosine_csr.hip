@@ -528,7 +528,10 @@ constexpr int HEAVY_CH = 32768, HEAVY_TB = 1024, HEAVY_EMAX = 2048, HEAVY_U = 4,
 // 128 KiB tile + 24 KiB of list state: this kernel (like the writer's 128 KiB tile) needs gfx950's 160 KiB of LDS per
 // workgroup; the library is built for gfx950 only (csrc/Makefile).
 static_assert(HEAVY_CH * 4 + 3 * HEAVY_EMAX * 4 + 64 <= 160 * 1024, "k_cosine_heavy needs 160 KiB of LDS (gfx950)");
-constexpr int HEAVYK_TB = 1024, HEAVYK_EMAX = 2048;  // the PACK forms: 64 KiB tile (two columns per word) + 24 KiB of list state + 64 KiB of cached postings
+#ifndef SKM_HEAVYK_TB
+#define SKM_HEAVYK_TB 1024  // (512: two workgroups per CU, no room for the cache: A/B builds)
+#endif
+constexpr int HEAVYK_TB = SKM_HEAVYK_TB, HEAVYK_EMAX = SKM_HEAVYK_TB == 1024 ? 2048 : 1024;  // the PACK forms: 64 KiB tile (two columns per word) + 24 KiB of list state + 64 KiB of cached postings
 constexpr int HEAVYP_CH = 32768, HEAVYP_TB = 1024, HEAVYP_EMAX = 2048;  // the PANEL form (16384 / 512 / 1024, two workgroups per CU, measured slower: 15.3 vs 13.8 ms)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "libsnekmer_hip is written for gfx950 (MI355X): 160 KiB LDS tiles, gfx950 MFMA shapes"
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__
 {
     constexpr int CHH = HC, TBH = HT, NW = HT / 64, U = HEAVY_U;
     constexpr int ACCW = PACK ? HC / 2 : HC;  // accumulator words per step
-    constexpr bool CACHE = PACK;
+    constexpr bool CACHE = PACK && HT == 1024;
     constexpr int CN = CACHE ? 8192 : 1;  // cached postings per row
     static_assert(ACCW * 4 + 3 * HE * 4 + (CACHE ? CN * 8 : 0) + 1024 <= (HT == 1024 ? 160 : 80) * 1024, "LDS budget of k_cosine_heavy");
     __shared__ __attribute__((aligned(16))) int s_acc[ACCW];
@@ -1775,14 +1778,14 @@ int cosine_csr_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uin
         if (use_panels) { /* rows with a panel first (the PANEL forms skip the others); packed tiles, then what they left */ \
             if (pack_heavy)                                                                                          \
                 k_cosine_heavy<MODE, VEC, PW, true, HEAVYP_CH, HEAVYK_TB, HEAVYK_EMAX, true>                         \
-                    <<<skm_grid_cap(ctx, bn, 1), HEAVYK_TB, 0, s_w>>>(SKM_HEAVY_ARGS);                               \
+                    <<<skm_grid_cap(ctx, bn, HEAVYK_TB == 1024 ? 1 : 2), HEAVYK_TB, 0, s_w>>>(SKM_HEAVY_ARGS);                               \
             k_cosine_heavy<MODE, VEC, PW, true, HEAVYP_CH, HEAVYP_TB, HEAVYP_EMAX><<<skm_grid_cap(ctx, bn, 1), HEAVYP_TB, 0, s_w>>>( \
                 SKM_HEAVY_ARGS);                                                                                     \
         }                                                                                                            \
         /* every row (left): the general form */                                                                     \
         if (pack_heavy)                                                                                              \
             k_cosine_heavy<MODE, VEC, PW, false, HEAVY_CH, HEAVYK_TB, HEAVYK_EMAX, true>                             \
-                <<<skm_grid_cap(ctx, bn, 1), HEAVYK_TB, 0, s_w>>>(SKM_HEAVY_ARGS);                                   \
+                <<<skm_grid_cap(ctx, bn, HEAVYK_TB == 1024 ? 1 : 2), HEAVYK_TB, 0, s_w>>>(SKM_HEAVY_ARGS);                                   \
         k_cosine_heavy<MODE, VEC, PW, false, HEAVY_CH, HEAVY_TB, HEAVY_EMAX><<<skm_grid_cap(ctx, bn, 1), HEAVY_TB, 0, s_w>>>( \
             SKM_HEAVY_ARGS);                                                                                         \
     } while (0)
