@@ -1439,7 +1439,7 @@ int heavy_panels_run(skm_ctx *ctx, const int64_t *d_xrowptr, const uint32_t *d_x
         return at;
     };
     const size_t o_key = take(4 * hcap), o_skey = take(4 * hcap), o_perm = take(4 * hcap), o_ktmp = take(4 * hcap),
-                 o_vtmp = take(4 * hcap), o_cnt = take(8), o_dk = take(4 * nb * PB_DICT), o_ds = take(4 * nb * PB_DICT),
+                 o_vtmp = take(4 * hcap), o_cnt = take(8), o_dk = take(8 * nb * PB_DICT),
                  o_cols = take(4 * nb * PB_KMAX), o_bad = take(nb * PB_KMAX), o_meta = take(16 * nb),
                  o_jl = take(4 * nb * PB_JMAX), o_jb = take(4 * nb * (PB_STEPS + 1)), o_A = take(nb * PB_ROWS * PB_KMAX),
                  o_G = take(4 * nb * (size_t)PB_ROWS * PB_JMAX),
@@ -1458,8 +1458,7 @@ int heavy_panels_run(skm_ctx *ctx, const int64_t *d_xrowptr, const uint32_t *d_x
     pb.skey = (uint32_t *)(base + o_skey);
     pb.perm = (uint32_t *)(base + o_perm);
     pb.count64 = (int64_t *)(base + o_cnt);
-    pb.dict_key = (uint32_t *)(base + o_dk);
-    pb.dict_slot = (uint32_t *)(base + o_ds);
+    pb.dict = (uint2 *)(base + o_dk);
     pb.cols = (uint32_t *)(base + o_cols);
     pb.bad = base + o_bad;
     pb.meta = (uint32_t *)(base + o_meta);

@@ -44,8 +44,9 @@ struct panel_bufs {
     uint32_t *skey;       // [hcap] sorted keys
     uint32_t *perm;       // [hcap] sorted position -> index into over_list
     int64_t *count64;     // the heavy-row count as the sort wants it
-    uint32_t *dict_key;   // [nb][PB_DICT]
-    uint32_t *dict_slot;  // [nb][PB_DICT]
+    uint2 *dict;          // [nb][PB_DICT]: (column, slot); the slot is PB_NOSLOT for a column without one and, once k_panel_rows
+                          // has run, for a bad one: a lookup is ONE 8-byte load per probe (keys, slots and bad flags in three
+                          // arrays were three dependent loads at the end of the heavy kernel's per-row set-up chain)
     uint32_t *cols;       // [nb][PB_KMAX]
     uint8_t *bad;         // [nb][PB_KMAX]
     uint32_t *meta;       // [nb][4]: K, |J|, rows in the block, 0
@@ -63,15 +64,13 @@ static_assert(PB_DICT == 1 << 13, "panel_hash");
 // slot of column c in block b's dictionary, PB_NOSLOT when absent / not given a slot / bad
 __device__ __forceinline__ uint32_t panel_lookup(const panel_bufs &pb, uint32_t b, uint32_t c)
 {
-    const uint32_t *keys = pb.dict_key + (size_t)b * PB_DICT;
+    const uint2 *dict = pb.dict + (size_t)b * PB_DICT;
     uint32_t h = panel_hash(c);
     for (int probe = 0; probe < 32; ++probe) {
-        const uint32_t k = keys[h];
-        if (k == c) {
-            const uint32_t s = pb.dict_slot[(size_t)b * PB_DICT + h];
-            return (s != PB_NOSLOT && !pb.bad[(size_t)b * PB_KMAX + s]) ? s : PB_NOSLOT;
-        }
-        if (k == NONE)
+        const uint2 e = dict[h];
+        if (e.x == c)
+            return e.y;
+        if (e.x == NONE)
             return PB_NOSLOT;
         h = (h + 1) & (PB_DICT - 1);
     }
@@ -205,8 +204,7 @@ __global__ __launch_bounds__(1024) void k_panel_dict(const int64_t *__restrict__
         }
     });
     for (int z = tid; z < PB_DICT; z += 1024) {
-        pb.dict_key[(size_t)b * PB_DICT + z] = s_key[z];
-        pb.dict_slot[(size_t)b * PB_DICT + z] = s_slot[z];
+        pb.dict[(size_t)b * PB_DICT + z] = make_uint2(s_key[z], s_slot[z]);
     }
     if (tid == 0) {
         pb.meta[b * 4 + 0] = min(s_k, (uint32_t)PB_KMAX);
@@ -299,6 +297,13 @@ __global__ __launch_bounds__(1024) void k_panel_rows(const uint32_t *__restrict_
         if (!fits)
             pb.meta[b * 4 + 0] = 0u;  // block disabled: its rows are walked in full
     }
+    // bad slots (a count above 127 on either side; the X side was marked by k_panel_dict, the Y side above, in front of a
+    // barrier) leave the dictionary: panel_lookup then needs no flag array
+    for (int z = tid; z < PB_DICT; z += 1024) {
+        const uint32_t s = pb.dict[(size_t)b * PB_DICT + z].y;
+        if (s != PB_NOSLOT && pb.bad[(size_t)b * PB_KMAX + s])
+            pb.dict[(size_t)b * PB_DICT + z].y = PB_NOSLOT;
+    }
 }
 
 // G[b] = A[b] B[b]^T with B never stored: a workgroup owns a run of 128-row tiles of J; per tile it builds the B tile
@@ -309,6 +314,10 @@ typedef int pi32x16 __attribute__((ext_vector_type(16)));
 typedef int pi32x4 __attribute__((ext_vector_type(4)));
 constexpr int PG_CHUNKS = 8;               // workgroups per block
 constexpr int PG_KP = PB_KMAX + 16;        // LDS row stride of the B tile (bank spread)
+#ifndef SKM_PG_U
+#define SKM_PG_U 8
+#endif
+constexpr int PG_U = SKM_PG_U;             // postings per slot and round trip of the B-tile fill
 constexpr int PG_TB = 512;                 // 8 waves: all fill the B tile, four multiply each half of A against it
 
 template <typename PW>
@@ -320,6 +329,12 @@ __global__ __launch_bounds__(PG_TB) void k_panel_gemm(const uint32_t *__restrict
     extern __shared__ __attribute__((aligned(16))) int8_t s_dynb[];  // B tile [TN][PG_KP]
     __shared__ __attribute__((aligned(16))) int8_t s_a[PB_ROWS * LROW];
     __shared__ uint32_t s_j[TN];
+    // rank of a row of Y inside the tile's slice of J: a hash table of (row << 7 | rank) words, 512 slots for 128 rows - one
+    // LDS read per posting where the binary search in s_j took seven dependent ones (and, one thread per list, was the
+    // fill's time: 45 postings per thread and tile)
+    constexpr int PG_TAB = 512;
+    __shared__ uint32_t s_tab[PG_TAB];
+    static_assert(TN == 128, "s_tab packs the rank in 7 bits (and rows of Y in 25: panels need m <= 2^20)");
     int8_t *s_b = s_dynb;
     const uint32_t cnt = min(*row_count, (uint32_t)(pb.nb * PB_ROWS));
     const uint32_t b = blockIdx.y;
@@ -364,40 +379,60 @@ __global__ __launch_bounds__(PG_TB) void k_panel_gemm(const uint32_t *__restrict
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t col0 = t * TN, ncol = min((uint32_t)TN, J - col0);
         __syncthreads();  // the previous tile's fragment reads are done
+        uint32_t myj = 0xFFFFFFFFu;
         if (tid < TN)
-            s_j[tid] = tid < (int)ncol ? jl[col0 + tid] : 0xFFFFFFFFu;
+            s_j[tid] = myj = tid < (int)ncol ? jl[col0 + tid] : 0xFFFFFFFFu;
+        s_tab[tid] = 0xFFFFFFFFu;
+        static_assert(PG_TB == PG_TAB, "one table slot per thread");
         for (uint32_t z = tid; z < (uint32_t)TN * kq; z += PG_TB)
             *reinterpret_cast<int4 *>(s_b + (z / kq) * PG_KP + (z % kq) * 16) = make_int4(0, 0, 0, 0);
         __syncthreads();
+        if (myj != 0xFFFFFFFFu) {
+            uint32_t h = (myj * 2654435761u) >> (32 - 9);
+            while (atomicCAS(&s_tab[h], 0xFFFFFFFFu, (myj << 7) | (uint32_t)tid) != 0xFFFFFFFFu)
+                h = (h + 1u) & (PG_TAB - 1);
+        }
+        __syncthreads();
         const uint32_t jhi = s_j[ncol - 1];
+        // both of the thread's slots in the same round trip, PG_U postings each (round 4: one slot after the other, four
+        // postings per round trip - the fill, a chain of such round trips per tile, was most of the kernel's time)
+        bool more[SPT];
+        bool any_more = false;
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
-            const uint32_t s = tid + q * PG_TB;
-            while (cur[q] < end[q]) {
-                PW pw[4];  // four postings per memory round trip (the list is walked by ONE thread)
+            more[q] = cur[q] < end[q];
+            any_more |= more[q];
+        }
+        while (any_more) {
+            PW pw[SPT][PG_U];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    pw[u] = ypost[min(cur[q] + (uint32_t)u, end[q] - 1u)];
+            for (int q = 0; q < SPT; ++q)
+#pragma unroll
+                for (int u = 0; u < PG_U; ++u)
+                    pw[q][u] = ypost[more[q] ? min(cur[q] + (uint32_t)u, end[q] - 1u) : 0u];  // (posting 0 exists: K > 0)
+            any_more = false;
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const uint32_t s = tid + q * PG_TB;
                 int took = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t j = posting<PW>::row(pw[u]);
-                    if (took != u || cur[q] + (uint32_t)u >= end[q] || j > jhi)
+                for (int u = 0; u < PG_U; ++u) {
+                    const uint32_t j = posting<PW>::row(pw[q][u]);
+                    if (!more[q] || took != u || cur[q] + (uint32_t)u >= end[q] || j > jhi)
                         continue;
-                    int lo = 0, hi = (int)ncol - 1;  // every row of a slot's list is in J
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (s_j[mid] < j)
-                            lo = mid + 1;
-                        else
-                            hi = mid;
+                    // every row of a slot's list is in J, and j lies in this tile's slice of it (the cursor starts at the
+                    // chunk's first row and j <= jhi): the probe finds it
+                    uint32_t h = (j * 2654435761u) >> (32 - 9), e = s_tab[h];
+                    for (int probe = 0; probe < PG_TAB && (e >> 7) != j; ++probe) {
+                        h = (h + 1u) & (PG_TAB - 1);
+                        e = s_tab[h];
                     }
-                    s_b[lo * PG_KP + s] = (int8_t)posting<PW>::count(pw[u], ypostcnt, cur[q] + (uint32_t)u);
+                    s_b[(e & 127u) * PG_KP + s] = (int8_t)posting<PW>::count(pw[q][u], ypostcnt, cur[q] + (uint32_t)u);
                     took = u + 1;
                 }
                 cur[q] += (uint32_t)took;
-                if (took < 4)
-                    break;
+                more[q] = more[q] && took == PG_U && cur[q] < end[q];
+                any_more |= more[q];
             }
         }
         pi32x16 acc[2][2];
