@@ -881,13 +881,48 @@ __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__
             __syncthreads();
             if (j0 + CHH < m)
                 g_prefetch(step + 1);  // in front of this step's stores
-            // ---- scale, store, clear (the writer's store shape: 16-byte non-temporal stores, 1 KiB per wave instruction)
+            // ---- scale, store, clear (the writer's store shape: 16-byte non-temporal stores, 1 KiB per wave instruction).
+            // The neighbours' norms are only fetched for pieces that hold a dot product (even a heavy row is mostly zeros),
+            // but of the 256 columns of a wave's piece some nearly always do: with the load beside the piece's store a
+            // step cost NQ load latencies in series.  Two sweeps: the norms of all NQ pieces are requested first (the
+            // tile is only looked at), then every piece is read again, cleared, scaled and stored.
+            constexpr int NQ = CHH / 4 / TBH;
+            float4 rjv[NQ];
 #pragma unroll
-            for (int q = 0; q < CHH / 4 / TBH; ++q) {
+            for (int q = 0; q < NQ; ++q) {
+                const int z = tid + q * TBH;
+                const int64_t jc = j0 + 4 * (int64_t)z;
+                rjv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                bool nz = false;
+                if (jc < m) {
+                    if (PACK) {
+                        const int2 w = reinterpret_cast<const int2 *>(s_acc)[z];
+                        nz = (w.x | w.y) != 0;
+                    } else {
+                        const int4 w = reinterpret_cast<const int4 *>(s_acc)[z];
+                        nz = (w.x | w.y | w.z | w.w) != 0;
+                    }
+                }
+                if (nz) {
+                    if (VEC && jc + 3 < m) {
+                        rjv[q] = *reinterpret_cast<const float4 *>(yrnorm + jc);
+                    } else {
+                        rjv[q].x = yrnorm[jc];
+                        if (jc + 1 < m)
+                            rjv[q].y = yrnorm[jc + 1];
+                        if (jc + 2 < m)
+                            rjv[q].z = yrnorm[jc + 2];
+                        if (jc + 3 < m)
+                            rjv[q].w = yrnorm[jc + 3];
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
                 const int z = tid + q * TBH;
                 const int64_t jc = j0 + 4 * (int64_t)z;
                 if (jc >= m)
-                    break;
+                    continue;
                 int4 a;
                 if (PACK) {
                     const int2 w = reinterpret_cast<int2 *>(s_acc)[z];
@@ -897,23 +932,7 @@ __global__ __launch_bounds__(HT) void k_cosine_heavy(const int64_t *__restrict__
                     a = reinterpret_cast<int4 *>(s_acc)[z];
                     reinterpret_cast<int4 *>(s_acc)[z] = make_int4(0, 0, 0, 0);
                 }
-                // the neighbours' norms are only fetched for cells that hold a dot product: even a heavy row is mostly
-                // zeros (a family of 5 000 in 100 000 columns), and a load per store also makes every wait for a load
-                // drain the stores in front of it.  (Round 5: all loads of a step issued before its first store, pieces
-                // held in registers: 12.4 vs 12.15 ms, 13.97 vs 13.14 unpacked - slower.)
-                float rj[4] = {0.f, 0.f, 0.f, 0.f};
-                if ((a.x | a.y | a.z | a.w) != 0) {
-                    if (VEC && jc + 3 < m) {
-                        const float4 t4 = *reinterpret_cast<const float4 *>(yrnorm + jc);
-                        rj[0] = t4.x, rj[1] = t4.y, rj[2] = t4.z, rj[3] = t4.w;
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (jc + u < m)
-                                rj[u] = yrnorm[jc + u];
-                    }
-                }
-                float o[4] = {(float)a.x * ri * rj[0], (float)a.y * ri * rj[1], (float)a.z * ri * rj[2], (float)a.w * ri * rj[3]};
+                float o[4] = {(float)a.x * ri * rjv[q].x, (float)a.y * ri * rjv[q].y, (float)a.z * ri * rjv[q].z, (float)a.w * ri * rjv[q].w};
                 if (MODE == 1) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {

@@ -120,7 +120,8 @@ __global__ __launch_bounds__(1024) void k_panel_dict(const int64_t *__restrict__
                                                      const uint32_t *__restrict__ row_list,
                                                      const uint32_t *__restrict__ row_count, panel_bufs pb)
 {
-    __shared__ uint32_t s_key[PB_DICT], s_slot[PB_DICT], s_cnt[PB_DICT];
+    // (two arrays = 64 KiB: two blocks' workgroups per CU, and the ~310 blocks of a 100 k-row skewed batch in one round of the grid)
+    __shared__ uint32_t s_key[PB_DICT], s_slot[PB_DICT];  // s_slot: the number of rows holding the column until step 2 turns it into the slot
     __shared__ uint32_t s_k;
     const uint32_t cnt = min(*row_count, (uint32_t)(pb.nb * PB_ROWS));
     const uint32_t b = blockIdx.x, first = b * PB_ROWS;
@@ -130,8 +131,7 @@ __global__ __launch_bounds__(1024) void k_panel_dict(const int64_t *__restrict__
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int z = tid; z < PB_DICT; z += 1024) {
         s_key[z] = NONE;
-        s_slot[z] = PB_NOSLOT;
-        s_cnt[z] = 0;
+        s_slot[z] = 0;
     }
     if (tid < PB_KMAX)
         pb.bad[(size_t)b * PB_KMAX + tid] = 0;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(1024) void k_panel_dict(const int64_t *__restrict__
         for (int probe = 0; probe < 32; ++probe) {
             const uint32_t old = atomicCAS(&s_key[h], NONE, c);
             if (old == NONE || old == c) {
-                atomicAdd(&s_cnt[h], 1u);
+                atomicAdd(&s_slot[h], 1u);
                 break;
             }
             h = (h + 1) & (PB_DICT - 1);
@@ -173,7 +173,9 @@ __global__ __launch_bounds__(1024) void k_panel_dict(const int64_t *__restrict__
     // 2. slots for the first PB_KMAX of those that at least PB_MIN_ROWS rows of the block share: a column of one or two
     // rows gains nothing from a panel, and its posting list would drag unrelated rows into J
     for (int z = tid; z < PB_DICT; z += 1024) {
-        if (s_key[z] != NONE && s_cnt[z] >= PB_MIN_ROWS) {
+        const uint32_t holders = s_slot[z];
+        s_slot[z] = PB_NOSLOT;
+        if (s_key[z] != NONE && holders >= PB_MIN_ROWS) {
             const uint32_t s = atomicAdd(&s_k, 1u);
             if (s < (uint32_t)PB_KMAX) {
                 s_slot[z] = s;
