@@ -1614,6 +1614,47 @@ def test_skewed_workload_20k_vs_oracle(ctx, name, k):
     _sampled_row_check(ctx, name, k, 20000, seed_idx=11, nsample=64, full_stats=True, packed=(res, off))
 
 
+def test_skewed_batches_through_the_overlapped_pipeline_with_panels_and_packed_tiles(ctx, skm_option):
+    """A stream of two skewed batches (families of thousands: most rows go to the heavy kernels) through
+    engine.OverlappedPipeline with the lists of 60 % of the rows built on side contexts (skm_cosine_csr_phase: the heavy
+    kernels then run on the main stream against a side context's scratch and its min-norm), panels and packed tiles forced on:
+    every result equal to the one-stream pipeline's with both off."""
+    import ctypes as C
+
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.synth import synth_skewed
+
+    lut = A.build_lut("red6")
+    batches = []
+    for seed in (41, 42):
+        res, off, _ = synth_skewed(20000, seed=20250523 + seed)
+        batches.append(engine.SeqBatch(ctx, res, off))
+    skm_option("SKM_HEAVY_PANEL", 0)
+    skm_option("SKM_HEAVY_PACK", 0)
+    ref = engine.Pipeline(ctx, lut, 12)
+    want = []
+    for b in batches:
+        S = ref.step(b)
+        want.append((engine.matrix_row_stats(ctx, S, b.n, b.n, S.shape[1]), S.download(S.shape[1] * 8, offset=(b.n // 3) * S.shape[1])))
+    st = (C.c_int64 * 4)()
+    ctx.call("skm_cosine_csr_stats", st)
+    assert st[0] > 5000  # rows handed to the heavy kernels
+    ref.out = S = None
+    skm_option("SKM_HEAVY_PANEL", 1)
+    skm_option("SKM_HEAVY_PACK", 1)
+    pipe = engine.OverlappedPipeline(ctx, lut, 12, side_list_fraction=0.6)
+    pipe.SPLIT_MIN_ROWS = 64
+    pipe.prefetch(batches[0])
+    for i, b in enumerate(batches):
+        out = pipe.step(batches[i + 1] if i + 1 < len(batches) else None)
+        pipe.sync()
+        (sums, nnz), rows = want[i]
+        got_s, got_n = engine.matrix_row_stats(ctx, out, b.n, b.n, out.shape[1])
+        assert (got_n == nnz).all() and (got_s == sums).all(), i
+        assert (out.download(out.shape[1] * 8, offset=(b.n // 3) * out.shape[1]) == rows).all(), i
+
+
 def test_config3_full_size_100k_red6_k12(ctx):
     """BASELINE configs[2], the benchmarked workload, at full size (40 GB result in HBM)."""
     _sampled_row_check(ctx, "red6", 12, 100000, seed_idx=2, full_stats=True)
