@@ -97,13 +97,27 @@ __global__ __launch_bounds__(256) void k_panel_key(const int64_t *__restrict__ x
     for (int64_t idx = wave; idx < (int64_t)cnt; idx += nwaves) {
         const int64_t i = row0 + rbase + row_list[idx];
         uint32_t best = 0xFFFFFFFFu;
-        for (int64_t t = xrowptr[i] + lane; t < xrowptr[i + 1]; t += 64) {
-            const uint32_t c = xcolidx[t];
-            if (c != NONE) {
-                const uint32_t p0 = ycolptr[c], df = ycolptr[c + 1] - p0;
-                if (df > PB_DF_LONG && df <= PB_DF_MAX)
-                    best = min(best, posting<PW>::row(ypost[p0]));
+        constexpr int UN = 4;  // 256 entries per round trip: column id -> column start / end -> first posting are dependent gathers
+        const int64_t e1 = xrowptr[i + 1];
+        for (int64_t t0 = xrowptr[i]; t0 < e1; t0 += 64 * UN) {
+            uint32_t c[UN], p0[UN], df[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int64_t t = t0 + u * 64 + lane;
+                c[u] = t < e1 ? xcolidx[t] : NONE;
             }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                p0[u] = df[u] = 0;
+                if (c[u] != NONE) {
+                    p0[u] = ycolptr[c[u]];
+                    df[u] = ycolptr[c[u] + 1] - p0[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (df[u] > PB_DF_LONG && df[u] <= PB_DF_MAX)
+                    best = min(best, posting<PW>::row(ypost[p0[u]]));
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
@@ -141,19 +155,51 @@ __global__ __launch_bounds__(1024) void k_panel_dict(const int64_t *__restrict__
     if (tid == 0)
         s_k = 0;
     __syncthreads();
-    auto for_entries = [&](auto need_df, auto &&fn) {
-        for (uint32_t r = wid; r < rows; r += 16) {
+    // the wave's rows (r = wid, wid + 16, ...: at most 16 of them): row id and entry range, one lane per row, loaded together
+    // (perm -> row list -> row pointers was a chain of three dependent loads in front of every row)
+    int64_t my_e0 = 0, my_e1 = 0;
+    {
+        const uint32_t r = (uint32_t)wid + 16u * (uint32_t)lane;
+        if (lane < 16 && r < rows) {
             const int64_t i = row0 + rbase + row_list[pb.perm[first + r]];
-            for (int64_t t = xrowptr[i] + lane; t < xrowptr[i + 1]; t += 64) {
-                const uint32_t c = xcolidx[t];
-                if (c == NONE)
-                    continue;
-                if (decltype(need_df)::value) {  // (two random gathers per entry: only the pass that builds the table pays)
-                    const uint32_t df = ycolptr[c + 1] - ycolptr[c];
-                    if (!(df > PB_DF_LONG && df <= PB_DF_MAX))
-                        continue;
+            my_e0 = xrowptr[i];
+            my_e1 = xrowptr[i + 1];
+        }
+    }
+    auto for_entries = [&](auto need_df, auto &&fn) {
+        constexpr int UN = 4;  // 64 x UN entries of a row per round trip (one at a time: each a chain of two or three dependent
+                               // gathers at HBM latency, 16 rows x 5 rounds x 2 passes of them in series per wave)
+        for (uint32_t r = wid, k = 0; r < rows; r += 16, ++k) {
+            const int64_t e0 = __shfl(my_e0, (int)k), e1 = __shfl(my_e1, (int)k);
+            for (int64_t t0 = e0; t0 < e1; t0 += 64 * UN) {
+                uint32_t c[UN], v[UN], lo[UN], hi[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int64_t t = t0 + u * 64 + lane;
+                    c[u] = t < e1 ? xcolidx[t] : NONE;
+                    v[u] = t < e1 ? xcounts[t] : 0u;
                 }
-                fn(r, c, xcounts[t]);
+                if (decltype(need_df)::value) {  // (two random gathers per entry: only the pass that builds the table pays)
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        lo[u] = hi[u] = 0;
+                        if (c[u] != NONE) {
+                            lo[u] = ycolptr[c[u]];
+                            hi[u] = ycolptr[c[u] + 1];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    if (c[u] == NONE)
+                        continue;
+                    if (decltype(need_df)::value) {
+                        const uint32_t df = hi[u] - lo[u];
+                        if (!(df > PB_DF_LONG && df <= PB_DF_MAX))
+                            continue;
+                    }
+                    fn(r, c[u], v[u]);
+                }
             }
         }
     };
