@@ -178,7 +178,11 @@ __global__ __launch_bounds__(256) void k_cosine_dense_i8(int64_t n, int64_t m, i
 constexpr int BK2 = 128;
 constexpr int STAGE_BYTES = (BM + BN) * BK2;  // 32 KiB
 
-template <int MODE>
+// SYM (X is Y, round 5): a one-dimensional grid over the tile pairs ty <= tx; the tile below the diagonal gets the same floats
+// through mirrored stores (4-byte stores a row apart: a small launch's output is a few tens of megabytes and stays in
+// L2 until its lines are complete - this form only serves launches of a few hundred tiles, where it beats the 256 x 256
+// kernels: N = 3 383, K = 6 656 (the reference's CI proteome): 105 tiles of 256 x 256 0.109 ms, 729 of 128 x 128 0.104, 378 here).
+template <int MODE, bool SYM = false>
 __global__ __launch_bounds__(256) void k_cosine_dense_i8_v2(int64_t n, int64_t m, int64_t kdim,
                                                             const int8_t *__restrict__ X,
                                                             const int8_t *__restrict__ Y,
@@ -189,7 +193,18 @@ __global__ __launch_bounds__(256) void k_cosine_dense_i8_v2(int64_t n, int64_t m
     __shared__ __attribute__((aligned(16))) int8_t s_t[2 * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
-    const int64_t row0 = (int64_t)blockIdx.y * BM, col0 = (int64_t)blockIdx.x * BN;
+    int64_t ty = blockIdx.y, tx = blockIdx.x;
+    if (SYM) {  // blockIdx.x enumerates the pairs row by row: row ty holds tiles tx = ty .. T - 1
+        const int64_t T = (n + BM - 1) / BM;
+        int64_t rest = blockIdx.x;
+        ty = 0;
+        while (rest >= T - ty) {
+            rest -= T - ty;
+            ++ty;
+        }
+        tx = ty + rest;
+    }
+    const int64_t row0 = ty * BM, col0 = tx * BN;
 
     i32x16 acc[2][2];
 #pragma unroll
@@ -268,6 +283,8 @@ __global__ __launch_bounds__(256) void k_cosine_dense_i8_v2(int64_t n, int64_t m
                             o = 0.0f;
                     }
                     out[i * ld + j] = o;
+                    if (SYM && tx != ty)
+                        out[j * ld + i] = o;
                 }
             }
         }
@@ -1093,9 +1110,19 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
     // 256 x 256 kernel) and 4 / 5 (v4 staging from row-major operands).
     const int forced0 = skm_opts().dense_variant;
     const bool v2 = kdim % BK2 == 0 && forced0 != 1;
-    const bool v4 = kdim % BK4 == 0 && kdim >= 4 * BK4 && n >= 1024 && m >= 1024 &&
-                    (forced0 == 0 || forced0 == 6 || forced0 == 7 || forced0 == 10 || forced0 == 11);
     const bool sym = d_x == d_y && n == m && d_xrnorm == d_yrnorm && forced0 != 7 && forced0 != 11;
+    // A symmetric launch of few 256 x 256 tiles leaves most of the chip idle: up to SKM_V2_MAX_TILES of them (N <= ~4 000) the
+    // 128 x 128 kernel takes it in its symmetric form - four times the workgroups, two per CU, no re-tiling passes in front.
+    // tools/bench_dense_small.py, K = 6 656, ms (256 x 256 v5 with split-K / 128 x 128 symmetric): N = 1 100 0.068 / 0.049,
+    // 1 500 0.069 / 0.050, 2 000 0.074 / 0.053, 2 600 0.104 / 0.054, 3 383 (the reference's CI proteome) 0.109 / 0.072,
+    // 4 200 0.128 / 0.126, 5 000 0.124 / 0.154, 8 000 0.300 / 0.334; N = 3 383 with K = 1 024: 0.052 / 0.032, K = 13 312: 0.180 / 0.130.
+#ifndef SKM_V2_MAX_TILES
+#define SKM_V2_MAX_TILES 140
+#endif
+    const int64_t tiles256 = skm_ceil_div(n, BM3) * (skm_ceil_div(n, BM3) + 1) / 2;
+    const bool small_launch = forced0 == 0 && v2 && sym && tiles256 <= SKM_V2_MAX_TILES;
+    const bool v4 = kdim % BK4 == 0 && kdim >= 4 * BK4 && n >= 1024 && m >= 1024 && !small_launch &&
+                    (forced0 == 0 || forced0 == 6 || forced0 == 7 || forced0 == 10 || forced0 == 11);
     SKM_PROF(ctx, "k_cosine_dense_i8");
     if (v4) {
         const int64_t nsy4 = skm_ceil_div(skm_ceil_div(n, BM3), 4), nsx4 = skm_ceil_div(skm_ceil_div(m, BN3), SKM_ST_W);
@@ -1216,7 +1243,14 @@ static int cosine_dense_i8_impl(skm_ctx *ctx, int64_t n, int64_t m, int64_t kdim
             return skm_check_launch("k_cosine_dense_i8");
         }
     } else if (v2) {
-        if (mode == 0)
+        if (sym && forced0 != 2) {  // (SKM_DENSE_VARIANT=2: the rectangular launch)
+            const int64_t T = skm_ceil_div(n, BM);
+            const dim3 gsym((unsigned)(T * (T + 1) / 2));
+            if (mode == 0)
+                k_cosine_dense_i8_v2<0, true><<<gsym, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+            else
+                k_cosine_dense_i8_v2<1, true><<<gsym, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
+        } else if (mode == 0)
             k_cosine_dense_i8_v2<0><<<grid, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);
         else
             k_cosine_dense_i8_v2<1><<<grid, 256, 0, ctx->stream>>>(n, m, kdim, d_x, d_y, d_xrnorm, d_yrnorm, d_out, ld);

@@ -14,7 +14,10 @@ from snekmer_amd import _hip, engine
 ctx = _hip.Context(0)
 rng = np.random.default_rng(0)
 out = []
-for n, kdim in ((3383, 6656), (3383, 1024), (3383, 13312), (1500, 6656), (8000, 6656)):
+shapes = [(3383, 6656), (3383, 1024), (3383, 13312), (1500, 6656), (8000, 6656)]
+if len(sys.argv) > 1:  # N list, K = 6656
+    shapes = [(int(a), 6656) for a in sys.argv[1:]]
+for n, kdim in shapes:
     X = (rng.random((n, kdim)) < 0.05).astype(np.int8)
     d = ctx.to_device(X)
     rn = engine.row_norms_i8(ctx, n, kdim, d)
