@@ -1358,6 +1358,13 @@ __global__ __launch_bounds__(256) void k_csr_to_dense_i8_flag(int64_t n, const i
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t i = wave; i < n; i += nwaves) {
         const int64_t b = rowptr[i], e = rowptr[i + 1];
+        // the row is zeroed by the wave that fills it (kdim is a multiple of 64; 1 KiB per store instruction): no separate
+        // fill of the whole matrix in front of the kernel.  The wave waits for its zeros before it stores a count over them.
+        int4 *row16 = reinterpret_cast<int4 *>(out + i * kdim);
+        for (int64_t z = lane; z < kdim / 16; z += 64)
+            row16[z] = make_int4(0, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bool big = false;
         for (int64_t t = b + lane; t < e; t += 64) {
             const uint32_t v = counts[t];
@@ -1455,11 +1462,7 @@ extern "C" int skm_csr_to_dense_i8(skm_ctx *ctx, int64_t n, const int64_t *d_row
     if (n == 0 || kdim == 0)
         return SKM_OK;
     SKM_REQUIRE(d_rowptr && d_codes && d_counts && d_out && d_irr_list, SKM_E_BADARG, "skm_csr_to_dense_i8: null array");
-    {
-        SKM_PROF(ctx, "memset_dense_i8");
-        SKM_HIP(hipMemsetAsync(d_out, 0, (size_t)n * (size_t)kdim, ctx->stream));
-    }
-    SKM_PROF(ctx, "k_csr_to_dense_i8");
+    SKM_PROF(ctx, "k_csr_to_dense_i8");  // (zeroes every row it fills: round 5; a fill of the whole matrix in front before)
     k_csr_to_dense_i8_flag<<<skm_grid_cap(ctx, skm_ceil_div(n, 4), 16), 256, 0, ctx->stream>>>(n, d_rowptr, d_codes, d_counts, kdim,
                                                                                              d_out, d_irr_list, d_irr_count);
     return skm_check_launch("k_csr_to_dense_i8");
