@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void k_cosine_dense_i8(int64_t n, int64_t m, i
 constexpr int BK2 = 128;
 constexpr int STAGE_BYTES = (BM + BN) * BK2;  // 32 KiB
 
-// SYM (X is Y, round 5): a one-dimensional grid over the tile pairs ty <= tx; the tile below the diagonal gets the same floats
-// through mirrored stores (4-byte stores a row apart: a small launch's output is a few tens of megabytes and stays in
+// SYM (X is Y, round 5): a one-dimensional grid over the tile pairs ty <= tx; the tile below the diagonal gets its cells (the same
+// integer, scaled in the order the rectangular launch would use: identical bits) through mirrored stores (4-byte stores a row apart: a small launch's output is a few tens of megabytes and stays in
 // L2 until its lines are complete - this form only serves launches of a few hundred tiles, where it beats the 256 x 256
 // kernels: N = 3 383, K = 6 656 (the reference's CI proteome): 105 tiles of 256 x 256 0.109 ms, 729 of 128 x 128 0.104, 378 here).
 template <int MODE, bool SYM = false>
@@ -283,8 +283,12 @@ __global__ __launch_bounds__(256) void k_cosine_dense_i8_v2(int64_t n, int64_t m
                             o = 0.0f;
                     }
                     out[i * ld + j] = o;
-                    if (SYM && tx != ty)
-                        out[j * ld + i] = o;
+                    if (SYM && tx != ty) {  // the cell below the diagonal, multiplied in the order its own tile would use:
+                        float om = (float)acc[a][b][r] * rj * xr[i];  // (acc * r_j) * r_i, the bits of the rectangular launch
+                        if (MODE == 1)
+                            om = fminf(fmaxf(1.0f - om, 0.0f), 2.0f);
+                        out[j * ld + i] = om;
+                    }
                 }
             }
         }

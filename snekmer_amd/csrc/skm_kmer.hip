@@ -24,7 +24,8 @@ namespace {
 
 constexpr int SHORT_MAX = 512;    // windows handled by one wave's register sort (8 per lane)
 constexpr int LONGSEQ_MAX = 8192;    // windows handled by one workgroup: 16 waves' register sorts merged through LDS
-constexpr int NBUCKET = 7;        // 0: no windows, 1: short, 2: long (513..8192), 6: keys in global scratch; 3-5 unused
+constexpr int MIDSEQ_MAX = 4096;     // ... by a workgroup of 8 waves (round 5: nearly all of a proteome's long sequences; 4 such workgroups fit a CU)
+constexpr int NBUCKET = 7;        // 0: no windows, 1: short, 2: 513..4096, 3: 4097..8192, 6: keys in global scratch; 4-5 unused
 constexpr int BLK = 256;
 
 template <typename K>
@@ -94,8 +95,10 @@ __global__ void k_classify(const uint8_t *__restrict__ seq, const int64_t *__res
             row_nnz[i] = 0;
         } else if (w <= SHORT_MAX)
             bucket = 1;
-        else if (w <= LONGSEQ_MAX)
+        else if (w <= MIDSEQ_MAX)
             bucket = 2;
+        else if (w <= LONGSEQ_MAX)
+            bucket = 3;
         else
             bucket = 6;
         if (i == 0)
@@ -335,15 +338,16 @@ __device__ __forceinline__ void lds_exchange(K (&v)[8], K *s_x, int e0, int part
     }
 }
 
-constexpr int LONG_TB = 1024;
-template <typename K, bool WITH_POS>
+// LONG_TB threads, 8 windows each: 1024 threads for up to 8192 windows, 512 for up to 4096 (the 37 KiB of LDS of that form
+// let four sequences share a CU where the 16-wave form holds two, most of its waves sorting sentinels)
+template <typename K, bool WITH_POS, int MAXW>
 constexpr size_t count_long_lds()
 {
-    return (size_t)LONGSEQ_MAX * sizeof(K) + sizeof(uint32_t) * (LONGSEQ_MAX + 1) + (WITH_POS ? sizeof(uint32_t) * LONGSEQ_MAX : 0) +
-           (size_t)LONGSEQ_MAX + 64 + 16;
+    return (size_t)MAXW * sizeof(K) + sizeof(uint32_t) * (MAXW + 1) + (WITH_POS ? sizeof(uint32_t) * MAXW : 0) +
+           (size_t)MAXW + 64 + 16;
 }
 
-template <typename K, bool WITH_POS>
+template <typename K, bool WITH_POS, int LONG_TB>
 __global__ __launch_bounds__(LONG_TB) void k_count_long(skm_lut256 lut, int nsym, int k, const uint8_t *__restrict__ seq,
                                                         const int64_t *__restrict__ off, const int32_t *__restrict__ slen,
                                                         const uint32_t *__restrict__ list,
@@ -355,10 +359,11 @@ __global__ __launch_bounds__(LONG_TB) void k_count_long(skm_lut256 lut, int nsym
     __shared__ uint8_t s_lut[256];
     __shared__ K s_last[LONG_TB / 64];
     __shared__ uint32_t s_wtot[LONG_TB / 64];
+    constexpr int MAXW = LONG_TB * 8;
     K *s_x = reinterpret_cast<K *>(s_dyn);  // exchange buffer of the merges, then the distinct keys
-    uint32_t *s_start = reinterpret_cast<uint32_t *>(s_x + LONGSEQ_MAX);
-    uint32_t *s_pos = s_start + LONGSEQ_MAX + 1;
-    uint8_t *s_rank = reinterpret_cast<uint8_t *>(s_pos + (WITH_POS ? LONGSEQ_MAX : 0));
+    uint32_t *s_start = reinterpret_cast<uint32_t *>(s_x + MAXW);
+    uint32_t *s_pos = s_start + MAXW + 1;
+    uint8_t *s_rank = reinterpret_cast<uint8_t *>(s_pos + (WITH_POS ? MAXW : 0));
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const K SENT = sentinel<K>();
     const uint32_t nlist = *nlist_ptr;
@@ -839,13 +844,22 @@ int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const u
         SKM_TRY(skm_check_launch("k_count_short"));
     }
     if (!bounded || max_seq_len - k + 1 > SHORT_MAX) {
-        // 513..8192 windows: one workgroup of 16 waves per sequence, persistent grid (one workgroup per CU: ~100-137 KB of LDS)
+        // 513..4096 windows: one workgroup of 8 waves per sequence, persistent grid
         SKM_PROF(ctx, "k_count_long");
-        auto kern = k_count_long<K, WITH_POS>;
-        constexpr size_t lds = count_long_lds<K, WITH_POS>();
+        auto kern = k_count_long<K, WITH_POS, MIDSEQ_MAX / 8>;
+        constexpr size_t lds = count_long_lds<K, WITH_POS, MIDSEQ_MAX>();
+        kern<<<skm_grid_cap(ctx, n, 4), MIDSEQ_MAX / 8, lds, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + (int64_t)2 * n, fill + 2,
+                                                                    tmp_codes, tmp_counts, tmp_first, row_nnz);
+        SKM_TRY(skm_check_launch("k_count_long"));
+    }
+    if (!bounded || max_seq_len - k + 1 > MIDSEQ_MAX) {
+        // 4097..8192 windows: one workgroup of 16 waves per sequence, persistent grid (one workgroup per CU: ~100-137 KB of LDS)
+        SKM_PROF(ctx, "k_count_long");
+        auto kern = k_count_long<K, WITH_POS, LONGSEQ_MAX / 8>;
+        constexpr size_t lds = count_long_lds<K, WITH_POS, LONGSEQ_MAX>();
         SKM_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        kern<<<skm_grid_cap(ctx, n, 1), LONG_TB, lds, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + (int64_t)2 * n, fill + 2,
-                                                             tmp_codes, tmp_counts, tmp_first, row_nnz);
+        kern<<<skm_grid_cap(ctx, n, 1), LONGSEQ_MAX / 8, lds, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + (int64_t)3 * n, fill + 3,
+                                                                     tmp_codes, tmp_counts, tmp_first, row_nnz);
         SKM_TRY(skm_check_launch("k_count_long"));
     }
     if (bounded && max_seq_len - k + 1 > LONGSEQ_MAX) {
