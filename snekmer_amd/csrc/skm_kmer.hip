@@ -848,6 +848,8 @@ int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const u
         SKM_PROF(ctx, "k_count_long");
         auto kern = k_count_long<K, WITH_POS, MIDSEQ_MAX / 8>;
         constexpr size_t lds = count_long_lds<K, WITH_POS, MIDSEQ_MAX>();
+        if (lds > 64 * 1024)  // (8-byte codes with first positions: 70 KiB)
+            SKM_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<skm_grid_cap(ctx, n, 4), MIDSEQ_MAX / 8, lds, st>>>(lut, nsym, k, d_seq, d_off, slen, lists + (int64_t)2 * n, fill + 2,
                                                                     tmp_codes, tmp_counts, tmp_first, row_nnz);
         SKM_TRY(skm_check_launch("k_count_long"));
