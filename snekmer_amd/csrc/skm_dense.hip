@@ -509,17 +509,19 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v4(int64_t n, int64_t m
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int64_t i = ibase + li + u;
-                    float v = 0.0f;
+                    float v = 0.0f, vm = 0.0f;
                     if (i < n && j < m) {
                         v = (float)acc[a][b][4 * q + u] * xr[i] * rj;
-                        if (MODE == 1) {
+                        vm = (float)acc[a][b][4 * q + u] * rj * xr[i];  // the cell below the diagonal: (acc * r_j) * r_i, the
+                        if (MODE == 1) {                                 // bits its own tile (the rectangular launch) would give
                             v = fminf(fmaxf(1.0f - v, 0.0f), 2.0f);
+                            vm = fminf(fmaxf(1.0f - vm, 0.0f), 2.0f);
                             if (i == j)
-                                v = 0.0f;
+                                v = vm = 0.0f;
                         }
                         out[i * ld + j] = v;
                     }
-                    o[u] = v;
+                    o[u] = vm;
                 }
                 if (mirror)
                     *reinterpret_cast<float4 *>(tbuf + ccol * TROW + li) = make_float4(o[0], o[1], o[2], o[3]);
@@ -822,16 +824,18 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v5(int64_t n, int64_t m
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t i = ibase + li + u;
-                float v = 0.0f;
+                float v = 0.0f, vm = 0.0f;
                 if (i < n && j < m) {
                     v = (float)acc[a][4 * q + u] * xr[i] * rj;
-                    if (MODE == 1) {
+                    vm = (float)acc[a][4 * q + u] * rj * xr[i];  // the cell below the diagonal: (acc * r_j) * r_i, the bits its
+                    if (MODE == 1) {                             // own tile (the rectangular launch) would give
                         v = fminf(fmaxf(1.0f - v, 0.0f), 2.0f);
+                        vm = fminf(fmaxf(1.0f - vm, 0.0f), 2.0f);
                         if (i == j)
-                            v = 0.0f;
+                            v = vm = 0.0f;
                     }
                 }
-                o[u] = v;
+                o[u] = vm;
                 tdir[(li + u) * TROW + ccol] = v;
             }
             if (mirror)

@@ -786,10 +786,14 @@ def _check_dense_symmetric(ctx, rng, n, kdim):
             if mode == 1:
                 ref = np.clip(1.0 - ref, 0, 2)
                 np.fill_diagonal(ref, 0.0)
-            # mirrored tiles are bit-symmetric; inside diagonal tiles (i,j) and (j,i) multiply the two norms
-            # in opposite orders: one float32 rounding apart
+            # (i, j) and (j, i) multiply the two norms in opposite orders: one float32 rounding apart
             assert np.abs(S - S.T).max() <= 1.2e-7
             assert np.abs(S - ref).max() <= 2e-6
+            # ... and the cells below the diagonal, written from the tiles above it, carry the bits of the rectangular
+            # launch (round 5: every cell is (acc * r_row) * r_column whatever kernel and route produced it)
+            with _hip.options(SKM_DENSE_VARIANT=11 if kdim % 256 == 0 else 7 if kdim % 64 == 0 and kdim >= 256 and n >= 1024 else 2 if kdim % 128 == 0 else 1):
+                rect = engine.cosine_dense_i8(ctx, n, n, kdim, dX, dX, d_rn, d_rn, mode=mode, ld=ld)
+            assert (rect.download().reshape(-1, ld)[:n, :n] == S).all()
     ones = ctx.to_device(np.ones(n + 4, dtype=np.float32))
     out = engine.cosine_dense_i8(ctx, n, n, kdim, dX, dX, ones, ones)
     assert (out.download().reshape(out.shape)[:n, :n].astype(np.int64) == G).all()
@@ -816,7 +820,7 @@ def test_dense_pipeline_matches_sparse_pipeline_and_oracle(ctx, name, k):
     sparse = engine.Pipeline(ctx, lut, k)
     o2 = sparse.step(batch)
     S2 = o2.download().reshape(o2.shape)[:n, :n]
-    assert np.abs(S - S2).max() <= 2e-7
+    assert (S == S2).all()  # (every cell is (dot * r_row) * r_column on either route)
     D = dense.step(batch, mode=1).download().reshape(out.shape)[:n, :n]
     refD = np.clip(1.0 - ref, 0, 2)
     np.fill_diagonal(refD, 0.0)

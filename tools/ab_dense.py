@@ -42,10 +42,8 @@ for rnd in range(5):
             if ref is None:
                 ref = sample
             elif vname.split()[0] in SYMMETRIC:
-                # the mirrored half is (acc * r_i) * r_j instead of (acc * r_j) * r_i: one float32 rounding apart
-                d = float(np.abs(sample - ref).max())
-                assert d <= 2.5e-7, f"symmetric variant differs by {d}"
-                print(f"symmetric vs full: max |diff| {d:.2e} (rounding order of the two norms)")
+                # (round 5: the cells below the diagonal are scaled in the rectangular launch's order: identical bits)
+                assert (sample == ref).all(), f"symmetric variant {vname} differs from the rectangular launch"
             else:
                 assert (sample == ref).all(), f"variant {vname} differs from the first variant"
 _hip.set_option("SKM_DENSE_VARIANT", None)
