@@ -282,11 +282,21 @@ __global__ __launch_bounds__(1024) void k_panel_rows(const uint32_t *__restrict_
     for (uint32_t s = wid; s < K; s += 16) {
         const uint32_t c = pb.cols[(size_t)b * PB_KMAX + s];
         bool big = false;
-        for (uint32_t p = ycolptr[c] + lane, pe = ycolptr[c + 1]; p < pe; p += 64) {
-            const PW pw = ypost[p];
-            const uint32_t j = posting<PW>::row(pw);
-            atomicOr(&s_bm[j >> 5], 1u << (j & 31));
-            big |= posting<PW>::count(pw, ypostcnt, p) > 127u;
+        const uint32_t p0 = ycolptr[c], pe = ycolptr[c + 1];
+        for (uint32_t pp = p0 + lane; pp < pe; pp += 64 * 4) {  // four loads in flight per lane
+            PW pw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                pw[u] = ypost[min(pp + 64u * u, pe - 1u)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t p = pp + 64u * u;
+                if (p < pe) {
+                    const uint32_t j = posting<PW>::row(pw[u]);
+                    atomicOr(&s_bm[j >> 5], 1u << (j & 31));
+                    big |= posting<PW>::count(pw[u], ypostcnt, p) > 127u;
+                }
+            }
         }
         if (__any(big) && lane == 0)
             pb.bad[(size_t)b * PB_KMAX + s] = 1;  // a count above 127 on the Y side
