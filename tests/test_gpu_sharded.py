@@ -69,6 +69,45 @@ def _run_sharded(world, lut, k, res, off, bounds, body_extra):
     return run_world(world, body)
 
 
+@pytest.mark.parametrize("n", [18000, 26000])
+def test_sharded_two_thread_ranks_owner_sort_tile_shapes(ctx, n):
+    """Shards of 2.7 and 3.9 M residues: the stable grouping by owner (the one-sweep sort on one-byte keys) takes its 1024 x 12 /
+    1024 x 16 tiles there (skm_onesweep.h: the tile grows with the capacity so that a pass's grid is resident at once).  Every
+    rank's row block against the single-GPU result: totals, norms, per-row sums and non-zero counts of the whole block,
+    32 rows bit for bit."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd import engine
+    from snekmer_amd.dist import shard_bounds
+    from snekmer_amd.synth import synth_families
+
+    lut, k, world = A.build_lut("red6"), 12, 2
+    res, off, _ = synth_families(n, 300, family=40, seed=91)
+    bounds = shard_bounds(n, world)
+
+    def extra(rank, rctx, sp, shard):
+        lo, hi = bounds[rank]
+        out = sp.step(shard)
+        ld = out.shape[1]
+        sums, nnz = engine.matrix_row_stats(rctx, out, hi - lo, n, ld)
+        rows = np.linspace(0, hi - lo - 1, 32).astype(np.int64)
+        return {"sums": sums, "nnzrow": nnz, "rows": rows, "sample": np.stack([out.download(n, offset=int(r) * ld) for r in rows]),
+                "nnz": sp.nnz_total, "ncols": sp.basis.ncols, "rnorm": sp.rnorm.download(n)}
+
+    results, _ = _run_sharded(world, lut, k, res, off, bounds, extra)
+    ref = engine.Pipeline(ctx, lut, k)
+    S = ref.step(engine.SeqBatch(ctx, res, off))
+    ld = S.shape[1]
+    sums, nnzrow = engine.matrix_row_stats(ctx, S, n, n, ld)
+    rn = ref.rnorm.download(n)
+    for rank, r in enumerate(results):
+        lo, hi = bounds[rank]
+        assert (r["nnz"], r["ncols"]) == (ref.csr.nnz, ref.basis.ncols)
+        assert (r["rnorm"] == rn).all()
+        assert (r["nnzrow"] == nnzrow[lo:hi]).all() and (r["sums"] == sums[lo:hi]).all()
+        for q, row in enumerate(r["rows"]):
+            assert (r["sample"][q] == S.download(n, offset=int(lo + row) * ld)).all(), (rank, int(row))
+
+
 @pytest.mark.parametrize("world,n,name,by_residues", [(8, 2400, "red6", False), (4, 1800, "standard", True), (8, 5, "red6", False),
                                                       (3, 1000, "hydro", False)])
 def test_sharded_threads_small_dense_block_and_topk(ctx, world, n, name, by_residues):
