@@ -197,6 +197,9 @@ def _check(lib, status: int):
         raise HipError(status, lib.skm_last_error().decode("utf-8", "replace"))
 
 
+CALL_TRACE = None  # a collections.deque(maxlen=...) while a tool wants the last library calls recorded
+CALL_SYNC = False
+
 OPTION_NAMES = ("SKM_SORT", "SKM_COSINE_PATH", "SKM_HEAVY_PANEL", "SKM_HEAVY_PACK", "SKM_COSINE_OVERLAP", "SKM_GRAM_SHAPE", "SKM_DENSE_VARIANT")
 
 
@@ -420,7 +423,11 @@ class Context:
     def call(self, name: str, *args):
         if self.handle is None:
             raise HipError(-1, f"{name}: the context is closed")
+        if CALL_TRACE is not None:  # (tools/fuzz_watch.py: the last library calls, for a run that stops answering)
+            CALL_TRACE.append((name, id(self), tuple(a.value if hasattr(a, "value") and isinstance(a.value, int) else None for a in args)))
         _check(self.lib, getattr(self.lib, name)(self.handle, *args))
+        if CALL_SYNC:  # (the same tool, second run: wait for the device after every call so that a hang names its call)
+            _check(self.lib, self.lib.skm_sync(self.handle))
 
 
 class Graph:

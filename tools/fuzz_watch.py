@@ -18,10 +18,32 @@ seed, rounds = int(sys.argv[1]), int(sys.argv[2])
 limit = float(sys.argv[3]) if len(sys.argv) > 3 else 90.0
 if "red6" not in A.ALPHABETS:
     A.register_alphabet("red6", A.RED6_GROUPS)
+# the last library calls (every context) for the report of a round that does not finish; FUZZ_SYNC=1: wait for the device
+# after every call, so that the last entry IS the call that hangs (at the price of the overlap between calls)
+import collections  # noqa: E402
+import threading  # noqa: E402
+
+_hip.CALL_TRACE = collections.deque(maxlen=40)
+_hip.CALL_SYNC = os.environ.get("FUZZ_SYNC") == "1"
+beat = [time.monotonic(), seed]
+
+
+def watchdog():
+    while True:
+        time.sleep(2.0)
+        if time.monotonic() - beat[0] > limit:
+            print(f"no progress for {limit:.0f} s in round {beat[1]}; the last library calls (oldest first):", flush=True)
+            for name, cid, ints in list(_hip.CALL_TRACE):
+                print(f"  ctx {cid % 100000:5d} {name} {[v for v in ints if v is not None][:10]}", flush=True)
+            faulthandler.dump_traceback(all_threads=True)
+            os._exit(3)
+
+
+threading.Thread(target=watchdog, daemon=True).start()
 ctx = _hip.default_context()
 t0 = time.perf_counter()
 for s in range(seed, seed + rounds):
-    faulthandler.dump_traceback_later(limit, exit=True)
+    beat[0], beat[1] = time.monotonic(), s
     F.one_round(ctx, s, verbose=True)
     if s % 4 == 0:
         print(F.dense_round(ctx, s), flush=True)
@@ -33,5 +55,4 @@ for s in range(seed, seed + rounds):
         print(F.score_round(ctx, s), flush=True)
     if s % 8 == 5:
         print(F.surface_round(ctx, s), flush=True)
-    faulthandler.cancel_dump_traceback_later()
 print(f"fuzz ok: {rounds} rounds in {time.perf_counter() - t0:.0f} s", flush=True)
