@@ -34,6 +34,12 @@ def watchdog():
             for name, cid, ints in list(_hip.CALL_TRACE):
                 print(f"  ctx {cid % 100000:5d} {name} {[v for v in ints if v is not None][:10]}", flush=True)
             faulthandler.dump_traceback(all_threads=True)
+            try:  # is the device busy (a kernel that never ends) or idle (the host waits for something that is not coming)?
+                import subprocess
+
+                print(subprocess.run(["rocm-smi", "--showuse", "--showmemuse"], capture_output=True, text=True, timeout=20).stdout, flush=True)
+            except Exception as exc:  # noqa: BLE001
+                print(f"rocm-smi: {exc}", flush=True)
             os._exit(3)
 
 
