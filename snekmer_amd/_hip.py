@@ -260,8 +260,15 @@ class DeviceArray:
         self.ptr = ctx._malloc(max(self.nbytes, 1))
 
     def free(self):
-        if self.ptr is not None and self.ctx is not None and self.ctx.handle is not None:
-            self.ctx._free(self.ptr)
+        if self.ptr is not None and self.ctx is not None:
+            owner = self.ctx
+            if owner.handle is None:
+                # the context that allocated the array was closed first (engine.OverlappedPipeline's buffer sets outlive side
+                # contexts a caller closes): the memory is the device's, any live context of that device can release it
+                owner = _default_ctx if (_default_ctx is not None and _default_ctx.handle is not None
+                                         and _default_ctx.device == self.ctx.device) else None
+            if owner is not None:
+                owner._free(self.ptr)
         self.ptr = None
 
     def __del__(self):
