@@ -409,14 +409,27 @@ def main():
         step = lambda: pipe.step(batch)
         rows_local = n_total
         if args.pipeline == "overlapped":
-            # a stream of batches (here: the same batch again and again, every step recomputing everything).  The one-stream
-            # pipeline runs once first: the 40 GB result buffer is shared, and the extras measure it by itself afterwards
+            # a stream of batches THAT ARRIVES FROM THE HOST: three different batches (three seeds of the same generator) cycle
+            # through pinned staging buffers into three recycled pairs of device buffers, one asynchronous upload per step on a
+            # copy context of its own (engine.BatchUploader), ordered against the side context's vectorize by events on the
+            # device: no allocation, no fill and no host wait per batch.  Every job of the reference starts from a file
+            # (snekmer/rules/kmerize.smk:89-129).  The one-stream pipeline runs once first: the 40 GB result buffer is
+            # shared, and the extras measure it by itself afterwards
             pipe.step(batch)
             ctx.sync()
+            stream_batches = [(res, off)] + [synth_families(args.n, args.length, family=100, seed=seed + 101 * j)[:2] for j in (1, 2)]
+            uploader = engine.BatchUploader(ctx, max(int(r.size) for r, _ in stream_batches), args.n, slots=3)
             op = engine.OverlappedPipeline(ctx, lut, args.k)
             op.out = pipe.out
-            op.prefetch(batch)
-            step = lambda: op.step(batch)
+            stream_pos = [0]
+
+            def next_upload():
+                r, o = stream_batches[stream_pos[0] % len(stream_batches)]
+                stream_pos[0] += 1
+                return uploader.upload(r, o)
+
+            op.prefetch(next_upload())
+            step = lambda: op.step(next_upload())
     else:
         from snekmer_amd.dist import RcclExchange, ShardedPipeline, shard_bounds
 
@@ -467,9 +480,17 @@ def main():
         c.profile_enable(False)
     note(f"timed region: {elapsed / args.steps * 1e3:.3f} ms/step on rank {rank}")
     identity = None
+    stream_info = None
     if op is not None:
         last = op.step(None)  # the batch still prefetched: nothing stays queued
         op.sync()
+        # which batch that was: upload number stream_pos - 1 of the cycle; the one-stream reference below runs on a resident
+        # copy of the same residues
+        last_res, last_off = stream_batches[(stream_pos[0] - 1) % len(stream_batches)]
+        stream_info = {"distinct_batches": len(stream_batches), "uploads_in_timed_region": args.steps,
+                       "host_waits_for_a_staging_buffer": uploader.host_waits,
+                       "h2d_bytes_per_step": int(last_res.nbytes + 64 + last_off.nbytes)}
+        batch = engine.SeqBatch(ctx, last_res, last_off)
         # the timed object's result against the one-stream pipeline's, at the timed size: the WHOLE matrix of the last step
         # reduced on the device (float64 sum + non-zero count per row, skm_matrix_row_stats; the same kernels on the same
         # values in the same order, so equal results give equal sums), then the same buffer rewritten by Pipeline.step
@@ -489,11 +510,24 @@ def main():
                             "object against the oracle at this size: tests/test_gpu_parity.py::"
                             "test_config3_full_size_100k_overlapped_pipeline_the_timed_object"}
         note(f"overlapped vs single: equal={identity['equal']}")
+        # host -> result for ONE batch of the stream, nothing overlapped: pack into pinned staging, asynchronous upload,
+        # vectorize on the side context, cosine on the main one, wait (the PCIe-inclusive latency; never `value`)
+        lat = []
+        for _ in range(3):
+            op.sync()
+            t1 = time.perf_counter()
+            op.prefetch(uploader.upload(last_res, last_off))
+            op.step(None)
+            op.sync()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        stream_info["host_to_result_ms"] = min(lat)
         op.out = None
         sides = list(dict.fromkeys(op.sides))
         op = prof_ctxs = None
         for side in sides:
-            side.close()  # their streams go too: HIP maps streams onto a few hardware queues, and the extras open more
+            side.close()  # (their streams go back to the library's cache: skm_mem.hip)
+        uploader.close()
+        batch = engine.SeqBatch(ctx, res, off)  # the extras below run on the first batch, resident
 
     shard_check = None
     if dist is not None:
@@ -564,7 +598,10 @@ def main():
                 "basis_columns": pipe.basis.ncols,
                 "parallelism": f"row-sharded x{world}, postings built by k-mer owner (RCCL all-to-all + all-gathers)"
                 if sharded else "single GPU",
-                "pipelining": ("engine.OverlappedPipeline: the steps of a stream of batches.  While a step's cosine (sparse Gram + N x N writer) "
+                "pipelining": ("engine.OverlappedPipeline fed by engine.BatchUploader: the steps of a stream of batches that ARRIVES FROM THE HOST - "
+                               "three different batches cycle, one asynchronous upload per timed step from pinned staging into recycled device "
+                               "buffers on a copy stream, ordered by events on the device (no hipMalloc, fill or host wait per batch).  "
+                               "While a step's cosine (sparse Gram + N x N writer) "
                                "runs on the main stream, the NEXT batch's recode + count + sort + basis / postings run on a second stream "
                                "confined to half of the compute units (skm_create_confined), and so do the neighbour lists of that batch's "
                                "last 60 % of rows (skm_cosine_csr_phase), which the main stream then only has to write.  Every timed step holds one complete "
@@ -591,6 +628,8 @@ def main():
                 "whole_step_frac": rows_local * ld * 4 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
         }
+        if stream_info is not None:
+            line["stream_of_batches"] = stream_info
         if identity is not None:
             line["overlapped_equals_single"] = identity["equal"]
             line["overlapped_vs_single"] = identity

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SKM_ABI_VERSION 6
+#define SKM_ABI_VERSION 7
 
 #define SKM_OK 0
 #define SKM_E_BADARG (-1)
@@ -101,15 +101,38 @@ int skm_graph_nodes(skm_graph *graph, int64_t *h_nodes); /* kernels + fills + co
 int skm_graph_destroy(skm_ctx *ctx, skm_graph *graph);
 int skm_device_info(skm_ctx *ctx, char *h_name, int name_cap, int *h_cus, int64_t *h_mem_bytes);
 
-/* ---- device memory ----------------------------------------------------------------------- */
+/* ---- device memory ----------------------------------------------------------------------- *
+ * The arrays of a job (numpy arrays in the reference: snekmer/rules/kmerize.smk:112,132-139) come from a per-device
+ * pool of size classes.  skm_free never waits and never calls hipFree: the block is parked behind an event on every
+ * stream of the device that still has work queued, and skm_malloc hands it out again only once those have completed -
+ * freeing an array while kernels that read it are queued is safe by construction, on any context of the device (the
+ * context argument of skm_free only names the device).  Memory goes back to the runtime when the device runs out of it
+ * or skm_mem_trim asks, after an explicit wait for every stream.  Environment SKM_GUARD=1 (read once): 512 canary bytes
+ * behind every array, checked by skm_free (SKM_E_HIP naming the array's size and the first overwritten byte).
+ * skm_mem_stats: h_out8 = {bytes in live arrays, bytes parked, hipMalloc calls, hipFree calls, allocations served from
+ * parked blocks, parked blocks, cached streams, candidates skipped because their events had not completed}. */
 int skm_malloc(skm_ctx *ctx, size_t bytes, void **out_dptr);
 int skm_free(skm_ctx *ctx, void *dptr);
+int skm_mem_trim(skm_ctx *ctx, int64_t *h_released_bytes); /* host-sync (every stream of the device) */
+int skm_mem_stats(skm_ctx *ctx, int64_t *h_out8);
+/* For a watchdog thread while another thread does not return from a call: per context whether its streams are idle or
+ * busy, the first timed kernels (skm_profile_enable) that started and did not finish, and the pool's counters, as text.
+ * No context argument: it reports every context of the process. */
+int skm_debug_report(char *h_buf, int cap);
 /* Pinned host memory that kernels of this context's device can read and write at the same address (zero-copy,
  * coherent): the staging of the per-record API, where a launch + skm_sync beats two explicit copies.  The pointer
  * may be passed wherever a d_* argument is expected. */
 int skm_host_alloc(skm_ctx *ctx, size_t bytes, void **out_hptr);
 int skm_host_free(skm_ctx *ctx, void *hptr);
 int skm_memcpy_h2d(skm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* host-sync */
+/* The same copy queued on the context's stream without waiting: h_src must be pinned memory (skm_host_alloc) that stays
+ * untouched until the copy has run (skm_event_record behind it + skm_event_query, or skm_sync).  This is how a stream of
+ * batches arrives from the host (every job of the reference starts from a file, snekmer/rules/kmerize.smk:89-129):
+ * batch i + 1 is uploaded into recycled device buffers while batch i is computed. */
+int skm_memcpy_h2d_async(skm_ctx *ctx, void *d_dst, const void *h_src_pinned, size_t bytes);
+/* SKM_OK and *h_done = 1 once everything queued on the context before skm_event_record(ctx, slot) has run, 0 before
+ * (and 1 when nothing was ever recorded in the slot).  Never waits. */
+int skm_event_query(skm_ctx *ctx, int slot, int *h_done);
 int skm_memcpy_d2h(skm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* host-sync */
 int skm_memcpy_d2d(skm_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 int skm_memset(skm_ctx *ctx, void *d_dst, int byte_value, size_t bytes);

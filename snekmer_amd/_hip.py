@@ -7,6 +7,7 @@ numeric result comes from the HIP kernels.
 """
 import ctypes as C
 import os
+import sys
 import threading
 from typing import Optional, Tuple
 
@@ -17,9 +18,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNEKMER_HIP_LIB") or os.path.join(_HERE, "libsnekmer_hip.so")
 
 SKM_OK = 0
-ABI_VERSION = 6  # SKM_ABI_VERSION of include/snekmer_hip.h
+ABI_VERSION = 7  # SKM_ABI_VERSION of include/snekmer_hip.h
 ERRORS = {-1: "BADARG", -2: "NOMEM", -3: "HIP", -4: "OVERFLOW", -5: "UNSUPPORTED", -6: "COMM", -7: "STALE"}
 COMM_ID_BYTES = 128
+EVENT_SLOTS = 8  # SKM_EVENT_SLOTS
 
 
 class P2POp(C.Structure):
@@ -68,12 +70,17 @@ _SIGNATURES = {
     "skm_graph_destroy": (C.c_int, [_p, _p]),
     "skm_event_record": (C.c_int, [_p, C.c_int]),
     "skm_stream_wait": (C.c_int, [_p, _p, C.c_int]),
+    "skm_event_query": (C.c_int, [_p, C.c_int, C.POINTER(C.c_int)]),
     "skm_device_info": (C.c_int, [_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_i64)]),
     "skm_malloc": (C.c_int, [_p, C.c_size_t, C.POINTER(_p)]),
     "skm_free": (C.c_int, [_p, _p]),
+    "skm_mem_trim": (C.c_int, [_p, C.POINTER(_i64)]),
+    "skm_mem_stats": (C.c_int, [_p, C.POINTER(_i64)]),
+    "skm_debug_report": (C.c_int, [C.c_char_p, C.c_int]),
     "skm_host_alloc": (C.c_int, [_p, C.c_size_t, C.POINTER(_p)]),
     "skm_host_free": (C.c_int, [_p, _p]),
     "skm_memcpy_h2d": (C.c_int, [_p, _p, _p, C.c_size_t]),
+    "skm_memcpy_h2d_async": (C.c_int, [_p, _p, _p, C.c_size_t]),
     "skm_memcpy_d2h": (C.c_int, [_p, _p, _p, C.c_size_t]),
     "skm_memcpy_d2d": (C.c_int, [_p, _p, _p, C.c_size_t]),
     "skm_memset": (C.c_int, [_p, _p, C.c_int, C.c_size_t]),
@@ -195,6 +202,18 @@ def load_library():
 def _check(lib, status: int):
     if status != SKM_OK:
         raise HipError(status, lib.skm_last_error().decode("utf-8", "replace"))
+
+
+FREE_ERRORS = []  # messages of skm_free calls that failed (SKM_GUARD=1: an array was overrun); tests assert it stays empty
+
+
+def debug_report() -> str:
+    """skm_debug_report: streams idle / busy per context, timed kernels that started and did not finish, pool counters.
+    Safe to call from a watchdog thread while another thread is stuck inside a library call."""
+    lib = load_library()
+    buf = C.create_string_buffer(1 << 16)
+    lib.skm_debug_report(buf, len(buf))
+    return buf.value.decode("utf-8", "replace")
 
 
 CALL_TRACE = None  # a collections.deque(maxlen=...) while a tool wants the last library calls recorded
@@ -346,7 +365,37 @@ class Context:
         return out.value
 
     def _free(self, ptr: int):
-        self.lib.skm_free(self.handle, _p(ptr))
+        # (called from __del__: no exception can leave it; a failure - SKM_GUARD's overrun report - is kept and printed)
+        status = self.lib.skm_free(self.handle, _p(ptr))
+        if status != SKM_OK:
+            msg = self.lib.skm_last_error().decode("utf-8", "replace")
+            FREE_ERRORS.append(msg)
+            print(f"libsnekmer_hip: skm_free: {msg}", file=sys.stderr, flush=True)
+
+    def mem_stats(self) -> dict:
+        """skm_mem_stats: what the device's array pool holds and has done (include/snekmer_hip.h)."""
+        out = (_i64 * 8)()
+        _check(self.lib, self.lib.skm_mem_stats(self.handle, out))
+        keys = ("live_bytes", "parked_bytes", "hipMalloc_calls", "hipFree_calls", "reused", "parked_blocks", "cached_streams", "busy_skipped")
+        return dict(zip(keys, (int(v) for v in out)))
+
+    def trim(self) -> int:
+        """Give every parked block back to the runtime (waits for the device first); bytes released."""
+        out = _i64(0)
+        _check(self.lib, self.lib.skm_mem_trim(self.handle, C.byref(out)))
+        return int(out.value)
+
+    def h2d_async(self, dptr: int, pinned: np.ndarray, nbytes: Optional[int] = None):
+        """Queue a copy from pinned host memory (host_alloc) on this context's stream without waiting; the source must
+        stay untouched until the copy has run (record_event + event_done, or sync)."""
+        _check(self.lib, self.lib.skm_memcpy_h2d_async(self.handle, _p(dptr), pinned.ctypes.data_as(_p),
+                                                        pinned.nbytes if nbytes is None else int(nbytes)))
+
+    def event_done(self, slot: int) -> bool:
+        """True once everything queued before the last record_event(slot) has run (never waits)."""
+        done = C.c_int(0)
+        _check(self.lib, self.lib.skm_event_query(self.handle, slot, C.byref(done)))
+        return bool(done.value)
 
     def host_alloc(self, nbytes: int) -> np.ndarray:
         """Pinned, device-addressable host bytes (skm_host_alloc) as a uint8 array; `arr.ctypes.data` is valid as a
@@ -454,6 +503,7 @@ class Graph:
         return int(n.value)
 
     def close(self):
+        # (a context that was closed first has destroyed its live graphs itself: skm_destroy)
         if self.handle is not None and self.ctx.handle is not None:
             self.ctx.lib.skm_graph_destroy(self.ctx.handle, self.handle)
         self.handle = None

@@ -1,4 +1,5 @@
 // Context, memory, error and per-kernel timing plumbing of libsnekmer_hip.so.
+#include <algorithm>
 #include <cstring>
 #include <map>
 
@@ -169,22 +170,34 @@ int create_ctx(int device_id, int first_group, int last_group, skm_ctx **out_ctx
         usable = 0;
         for (int i = 0; i < ncu; ++i)
             usable += (mask[i / 32] >> (i % 32)) & 1u;
-        SKM_HIP(hipExtStreamCreateWithCUMask(&stream, (uint32_t)((ncu + 31) / 32), mask));
+        // (a stream of the same mask that an earlier context gave back is taken again: skm_mem.hip)
+        SKM_HIP(skm_stream_acquire(device_id, first_group, last_group, mask, (uint32_t)((ncu + 31) / 32), &stream));
     } else {
-        SKM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        SKM_HIP(skm_stream_acquire(device_id, -1, -1, nullptr, 0, &stream));
     }
     skm_ctx *ctx = new skm_ctx();
     ctx->device = device_id;
     ctx->num_cus = prop.multiProcessorCount;
     ctx->usable_cus = usable;
     ctx->stream = stream;
-    SKM_HIP(hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocDefault));
-    memset(ctx->h_pinned, 0, 4096);  // (offset 2048: the previous cosine call's heavy-row count, skm_cosine_csr.hip)
+    ctx->cu_first = first_group;
+    ctx->cu_last = last_group;
+    {
+        const hipError_t e = skm_pinned_acquire(device_id, &ctx->h_pinned);  // zeroed (offset 2048: the previous cosine call's heavy-row count)
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            skm_stream_release(device_id, first_group, last_group, stream);
+            delete ctx;
+            skm_set_error("%s: pinned page: %s", who, hipGetErrorString(e));
+            return SKM_E_NOMEM;
+        }
+    }
     void *dev = nullptr;
     if (hipHostGetDevicePointer(&dev, ctx->h_pinned, 0) == hipSuccess && dev)
         ctx->d_err = (uint32_t *)dev + SKM_DEVERR_WORD;
     else
         (void)hipGetLastError();
+    skm_registry_add(ctx);
     *out_ctx = ctx;
     return SKM_OK;
 }
@@ -204,31 +217,40 @@ extern "C" int skm_destroy(skm_ctx *ctx)
     if (!ctx)
         return SKM_OK;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    if (ctx->capturing) {  // an abandoned capture: end it so that the stream can be waited for and reused
+        hipGraph_t g = nullptr;
+        if (hipStreamEndCapture(ctx->stream, &g) == hipSuccess && g)
+            (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        ctx->capturing = false;
+    }
+    // Every stream of the device, not only this context's: another context's stream may be running a kernel that reads this
+    // context's scratch or writes its pinned words (skm_cosine_csr_phase 2 runs on the executing context's stream).  An
+    // explicit wait - nothing below relies on the runtime waiting inside a free.
+    skm_quiesce_device(ctx->device);
     skm_comm_destroy(ctx);
+    for (auto g : ctx->graphs)  // graphs the caller never destroyed (their handles are dead from here on)
+        skm_graph_release(g);
+    ctx->graphs.clear();
     for (auto &p : ctx->prof) {
-        hipEventDestroy(p.start);
-        hipEventDestroy(p.stop);
+        skm_event_release(ctx->device, true, p.start);
+        skm_event_release(ctx->device, true, p.stop);
     }
     for (auto e : ctx->event_pool)
-        hipEventDestroy(e);
+        skm_event_release(ctx->device, true, e);
+    skm_registry_remove(ctx);
     for (int i = 0; i < WS_COUNT; ++i)
         if (ctx->ws[i])
-            hipFree(ctx->ws[i]);
-    if (ctx->h_pinned)
-        hipHostFree(ctx->h_pinned);
-    if (ctx->ev_host)
-        hipEventDestroy(ctx->ev_host);
+            skm_pool_free(ctx, ctx->ws[i]);
+    skm_pinned_release(ctx->device, ctx->h_pinned);
+    skm_event_release(ctx->device, false, ctx->ev_host);
     for (auto e : ctx->sync_events)
-        hipEventDestroy(e);
+        skm_event_release(ctx->device, false, e);
     for (auto e : ctx->user_events)
-        if (e)
-            hipEventDestroy(e);
-    if (ctx->s_writer)
-        hipStreamDestroy(ctx->s_writer);
-    if (ctx->s_gram)
-        hipStreamDestroy(ctx->s_gram);
-    hipStreamDestroy(ctx->stream);
+        skm_event_release(ctx->device, false, e);
+    skm_stream_release(ctx->device, -1, -1, ctx->s_writer);
+    skm_stream_release(ctx->device, 0, 3, ctx->s_gram);
+    skm_stream_release(ctx->device, ctx->cu_first, ctx->cu_last, ctx->stream);
     delete ctx;
     return SKM_OK;
 }
@@ -242,9 +264,27 @@ extern "C" int skm_event_record(skm_ctx *ctx, int slot)
     SKM_HIP(hipSetDevice(ctx->device));
     if (ctx->user_events.empty())
         ctx->user_events.assign(SKM_EVENT_SLOTS, nullptr);
-    if (!ctx->user_events[slot])
-        SKM_HIP(hipEventCreateWithFlags(&ctx->user_events[slot], hipEventDisableTiming));
+    if (!ctx->user_events[slot]) {
+        ctx->user_events[slot] = skm_event_acquire(ctx->device, false);
+        SKM_REQUIRE(ctx->user_events[slot], SKM_E_HIP, "skm_event_record: no event");
+    }
     SKM_HIP(hipEventRecord(ctx->user_events[slot], ctx->stream));
+    return SKM_OK;
+}
+
+extern "C" int skm_event_query(skm_ctx *ctx, int slot, int *h_done)
+{
+    SKM_REQUIRE(ctx && h_done && slot >= 0 && slot < SKM_EVENT_SLOTS, SKM_E_BADARG, "skm_event_query: bad argument");
+    *h_done = 1;
+    if (ctx->user_events.empty() || !ctx->user_events[slot])
+        return SKM_OK;
+    const hipError_t e = hipEventQuery(ctx->user_events[slot]);
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        *h_done = 0;
+        return SKM_OK;
+    }
+    SKM_HIP(e);
     return SKM_OK;
 }
 
@@ -303,27 +343,19 @@ extern "C" int skm_malloc(skm_ctx *ctx, size_t bytes, void **out_dptr)
     SKM_REQUIRE(ctx && out_dptr, SKM_E_BADARG, "skm_malloc: null argument");
     *out_dptr = nullptr;
     SKM_HIP(hipSetDevice(ctx->device));
-    // 256 bytes of slack behind every array (round 5): a vector load that overruns a ragged end by a few elements then stays
-    // inside the allocation even when its size is a multiple of the 4 KiB page - behind it the address space may be a hole
-    // (scratch of a context that was closed), and a fault hangs the kernel on some hosts instead of ending the process.
-    // A precaution while the intermittent stop of long fuzz runs is unexplained; no known overrun.
-    hipError_t e = hipMalloc(out_dptr, (bytes ? bytes : 1) + 256);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        skm_set_error("hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
-        return SKM_E_NOMEM;
-    }
-    return SKM_OK;
+    return skm_pool_alloc(ctx, bytes, out_dptr);  // (skm_mem.hip: size classes, reuse behind completed events only)
 }
 
+// Never waits and never calls hipFree: the block is parked behind an event on every stream of the device that still has
+// work queued, and handed out again only once those have completed.  Letting an array go while kernels that read it are
+// queued is therefore safe by construction (it used to rest on hipFree's implicit device-wide wait).
 extern "C" int skm_free(skm_ctx *ctx, void *dptr)
 {
     SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
-    if (dptr) {
-        SKM_HIP(hipSetDevice(ctx->device));
-        SKM_HIP(hipFree(dptr));
-    }
-    return SKM_OK;
+    if (!dptr)
+        return SKM_OK;
+    SKM_HIP(hipSetDevice(ctx->device));
+    return skm_pool_free(ctx, dptr);
 }
 
 extern "C" int skm_host_alloc(skm_ctx *ctx, size_t bytes, void **out_hptr)
@@ -354,6 +386,7 @@ extern "C" int skm_host_free(skm_ctx *ctx, void *hptr)
     SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
     if (hptr) {
         SKM_HIP(hipSetDevice(ctx->device));
+        SKM_TRY(skm_quiesce_device(ctx->device));  // kernels read and write this memory in place; the wait is explicit
         SKM_HIP(hipHostFree(hptr));
     }
     return SKM_OK;
@@ -366,6 +399,16 @@ extern "C" int skm_memcpy_h2d(skm_ctx *ctx, void *d_dst, const void *h_src, size
         return SKM_OK;
     SKM_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     SKM_HIP(hipStreamSynchronize(ctx->stream));
+    return SKM_OK;
+}
+
+extern "C" int skm_memcpy_h2d_async(skm_ctx *ctx, void *d_dst, const void *h_src_pinned, size_t bytes)
+{
+    SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
+    if (!bytes)
+        return SKM_OK;
+    SKM_REQUIRE(d_dst && h_src_pinned, SKM_E_BADARG, "skm_memcpy_h2d_async: null array");
+    SKM_HIP(hipMemcpyAsync(d_dst, h_src_pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
     return SKM_OK;
 }
 
@@ -409,17 +452,18 @@ int skm_ws(skm_ctx *ctx, int slot, size_t bytes, void **out)
         }
         ++ctx->ws_generation;
         if (ctx->ws[slot]) {
-            SKM_HIP(hipStreamSynchronize(ctx->stream));
-            SKM_HIP(hipFree(ctx->ws[slot]));
+            // the old block is parked behind whatever is still queued on any stream (skm_mem.hip): no wait here
+            SKM_TRY(skm_pool_free(ctx, ctx->ws[slot]));
             ctx->ws[slot] = nullptr;
             ctx->ws_bytes[slot] = 0;
         }
         size_t want = bytes + bytes / 8;  // headroom so slightly larger batches do not realloc
-        hipError_t e = hipMalloc(&ctx->ws[slot], want);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            skm_set_error("scratch slot %d: hipMalloc(%zu bytes): %s", slot, want, hipGetErrorString(e));
-            return SKM_E_NOMEM;
+        {
+            const int rc = skm_pool_alloc(ctx, want, &ctx->ws[slot]);
+            if (rc != SKM_OK) {
+                ctx->ws[slot] = nullptr;
+                return rc;
+            }
         }
         ctx->ws_bytes[slot] = want;
         if (slot == WS_COS || slot == WS_ZERO)  // hold counters that every user leaves at zero (k_cosine_prologue, k_compact_rows)
@@ -437,6 +481,17 @@ struct skm_graph {
     skm_ctx *owner = nullptr;
     size_t nodes = 0;  // kernels, fills and copies the capture holds: the GPU operations of one replay
 };
+
+void skm_graph_release(skm_graph *gr)
+{
+    if (!gr)
+        return;
+    if (gr->exec)
+        (void)hipGraphExecDestroy(gr->exec);
+    if (gr->graph)
+        (void)hipGraphDestroy(gr->graph);
+    delete gr;
+}
 
 extern "C" int skm_graph_begin(skm_ctx *ctx)
 {
@@ -478,6 +533,7 @@ extern "C" int skm_graph_end(skm_ctx *ctx, skm_graph **out_graph)
     gr->ws_generation = ctx->ws_generation;
     gr->owner = ctx;
     (void)hipGraphGetNodes(g, nullptr, &gr->nodes);
+    ctx->graphs.push_back(gr);
     *out_graph = gr;
     return SKM_OK;
 }
@@ -507,13 +563,12 @@ extern "C" int skm_graph_destroy(skm_ctx *ctx, skm_graph *graph)
     SKM_REQUIRE(ctx, SKM_E_BADARG, "null context");
     if (!graph)
         return SKM_OK;
+    auto it = std::find(ctx->graphs.begin(), ctx->graphs.end(), graph);
+    SKM_REQUIRE(it != ctx->graphs.end(), SKM_E_BADARG, "skm_graph_destroy: not a live graph of this context");
     SKM_HIP(hipSetDevice(ctx->device));
     (void)hipStreamSynchronize(ctx->stream);  // a replay may still be running
-    if (graph->exec)
-        (void)hipGraphExecDestroy(graph->exec);
-    if (graph->graph)
-        (void)hipGraphDestroy(graph->graph);
-    delete graph;
+    ctx->graphs.erase(it);
+    skm_graph_release(graph);
     return SKM_OK;
 }
 
@@ -529,7 +584,7 @@ skm_prof_scope::skm_prof_scope(skm_ctx *c, const char *name, hipStream_t on) : c
             *ev = ctx->event_pool.back();
             ctx->event_pool.pop_back();
         } else {
-            hipEventCreate(ev);
+            *ev = skm_event_acquire(ctx->device, true);
         }
     };
     take(&ent.start);

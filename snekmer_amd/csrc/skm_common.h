@@ -42,6 +42,7 @@ struct skm_ctx {
     hipStream_t stream = nullptr;
     int num_cus = 0;
     int usable_cus = 0;  // compute units the context's stream may use (num_cus unless skm_create_confined masked some out)
+    int cu_first = -1, cu_last = -1;  // the CU groups of a confined context's stream (-1: unmasked): the key of the stream cache
     void *ws[WS_COUNT] = {};
     size_t ws_bytes[WS_COUNT] = {};
     void *h_pinned = nullptr;  // small pinned buffer for count read-backs
@@ -59,6 +60,7 @@ struct skm_ctx {
     bool count_fill_dirty = false;
     bool capturing = false;
     uint64_t ws_generation = 0;
+    std::vector<struct skm_graph *> graphs;  // live captures of this context (skm_graph_end .. skm_graph_destroy / skm_destroy)
     std::vector<skm_prof_entry> prof;
     std::vector<hipEvent_t> event_pool;
     // cosine stage: streams confined to disjoint CU sets (writer 3/4, sparse Gram 1/4) and the events
@@ -77,6 +79,21 @@ struct skm_ctx {
 };
 
 int skm_ws(skm_ctx *ctx, int slot, size_t bytes, void **out);
+// skm_mem.hip: everything the HIP runtime hands out is taken once and recycled (device memory in size classes behind
+// completed events, streams by CU mask, events, the contexts' pinned pages); no call of the library relies on the
+// implicit device-wide wait of hipFree.
+int skm_pool_alloc(skm_ctx *ctx, size_t bytes, void **out);
+int skm_pool_free(skm_ctx *ctx, void *ptr);
+void skm_registry_add(skm_ctx *ctx);
+void skm_registry_remove(skm_ctx *ctx);
+int skm_quiesce_device(int device);  // hipStreamSynchronize of every registered stream of the device (not of a capturing one)
+hipError_t skm_stream_acquire(int device, int first_group, int last_group, const uint32_t *mask, uint32_t words, hipStream_t *out);
+void skm_stream_release(int device, int first_group, int last_group, hipStream_t s);
+hipEvent_t skm_event_acquire(int device, bool timing);
+void skm_event_release(int device, bool timing, hipEvent_t e);
+hipError_t skm_pinned_acquire(int device, void **out_page4096);
+void skm_pinned_release(int device, void *page);
+void skm_graph_release(struct skm_graph *graph);
 constexpr int SKM_DEVERR_WORD = 768;  // byte 3072 of h_pinned
 constexpr uint32_t SKM_DEVERR_SEQ_TOO_LONG = 1u;
 // Call after a stream synchronise: reports (once) what kernels flagged since the last check.

@@ -1375,17 +1375,16 @@ int overlap_streams(skm_ctx *ctx)
         if ((i / 8) % 8 < 4)
             mg[i / 32] |= 1u << (i % 32);
     const uint32_t words = (uint32_t)((ncu + 31) / 32);
-    if (hipStreamCreateWithFlags(&ctx->s_writer, hipStreamNonBlocking) != hipSuccess ||
-        hipExtStreamCreateWithCUMask(&ctx->s_gram, words, mg) != hipSuccess) {
+    // (streams and events come from the device's caches and go back there with the context: skm_mem.hip)
+    if (skm_stream_acquire(ctx->device, -1, -1, nullptr, 0, &ctx->s_writer) != hipSuccess ||
+        skm_stream_acquire(ctx->device, 0, 3, mg, words, &ctx->s_gram) != hipSuccess) {
         (void)hipGetLastError();
         return SKM_E_UNSUPPORTED;
     }
     for (int i = 0; i < 16 + 3; ++i) {
-        hipEvent_t e;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
+        hipEvent_t e = skm_event_acquire(ctx->device, false);
+        if (!e)
             return SKM_E_UNSUPPORTED;
-        }
         ctx->sync_events.push_back(e);
     }
     ctx->overlap_state = 1;

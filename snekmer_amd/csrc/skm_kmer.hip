@@ -81,8 +81,8 @@ __global__ void k_classify(const uint8_t *__restrict__ seq, const int64_t *__res
         // longer than the bound the caller gave (which sized the launches and the scratch behind this kernel): the row
         // stays empty and the context's sticky error word says so at the next host wait (skm_check_device_error)
         w = 0;
-        if (err)
-            __hip_atomic_fetch_or(err, SKM_DEVERR_SEQ_TOO_LONG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (err)  // one bit is defined: a plain system-scope store (a read-modify-write on host memory needs PCIe atomics)
+            __hip_atomic_store(err, SKM_DEVERR_SEQ_TOO_LONG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (slen)
         slen[i] = (int32_t)len;
@@ -833,7 +833,7 @@ int count_csr_impl(skm_ctx *ctx, const skm_lut256 &lut, int nsym, int k, const u
     if (!bounded) {
         SKM_HIP(hipMemcpyAsync(h_fill, fill, sizeof(uint32_t) * NBUCKET, hipMemcpyDeviceToHost, st));
         if (!ctx->ev_host)
-            SKM_HIP(hipEventCreateWithFlags(&ctx->ev_host, hipEventDisableTiming));
+            SKM_REQUIRE((ctx->ev_host = skm_event_acquire(ctx->device, false)) != nullptr, SKM_E_HIP, "no event");
         SKM_HIP(hipEventRecord(ctx->ev_host, st));
     }
     {

@@ -329,16 +329,23 @@ class ShardedPipeline:
         # 1. entries grouped by owner rank (sized by the capacity; the entry count stays on the device).  The grouping is one
         # digit of the library's one-sweep sort, whose tile words hold 30-bit positions: a shard is limited to 2^30 - 1
         # residues (3.5 M sequences of 300 aa on ONE rank; include/snekmer_hip.h, skm_bucket_partition)
-        if cap >= 1 << 30:
-            raise ValueError(f"rank {me}: a shard of {cap - 1} residues; ShardedPipeline holds at most 2^30 - 1 per rank: use more ranks")
+        # The check is COLLECTIVE: a rank whose shard is too large sends -1 counts through the first size gather instead of
+        # raising alone, so that every rank raises (the others would otherwise wait for it inside the all-to-all).
+        too_large = cap >= 1 << 30
         owners = self.columns == "owners"
-        p_codes = self._need("p_codes", cap, self.code_dtype)
-        p_rc = self._need("p_rc", cap, np.uint64)
-        p_index = self._need("p_index", cap, np.uint32) if owners else None
-        ctx.call("skm_bucket_partition", self.code_bits, G, _i64(loc.n), _i64(cap), _p(loc.rowptr.ptr),
-                 _p(loc.codes.ptr), _p(loc.counts.ptr), _i64(lo), _p(p_codes.ptr), _p(p_rc.ptr), _p(d_counts.ptr), _p(None),
-                 _p(p_index.ptr if owners else None))
+        if too_large:
+            d_counts.upload(np.full(d_counts.size, -1, dtype=np.int64))
+        else:
+            p_codes = self._need("p_codes", cap, self.code_dtype)
+            p_rc = self._need("p_rc", cap, np.uint64)
+            p_index = self._need("p_index", cap, np.uint32) if owners else None
+            ctx.call("skm_bucket_partition", self.code_bits, G, _i64(loc.n), _i64(cap), _p(loc.rowptr.ptr),
+                     _p(loc.codes.ptr), _p(loc.counts.ptr), _i64(lo), _p(p_codes.ptr), _p(p_rc.ptr), _p(d_counts.ptr), _p(None),
+                     _p(p_index.ptr if owners else None))
         cmat = self._gather_sizes(d_counts, G)  # collective 1 + round trip 1: [src, dst] entry counts
+        if (cmat < 0).any():
+            bad = sorted(int(r) for r in np.nonzero((cmat < 0).any(axis=1))[0])
+            raise ValueError(f"rank(s) {bad}: a shard of 2^30 residues or more; ShardedPipeline holds at most 2^30 - 1 per rank: use more ranks")
         loc.nnz = int(cmat[me, :].sum())
         self.nnz_total = int(cmat.sum())
         nrecv = int(cmat[:, me].sum())

@@ -57,6 +57,8 @@ class SeqBatch:
         if self.total:
             ctx._h2d(self.d_seq.ptr, residues)
         self.d_off = ctx.to_device(offsets)
+        self.ready = None        # (context, event slot) of an upload that a consumer on another context must wait for
+        self.on_consumed = None  # called with (context, event slot) by a pipeline that has queued the batch's last reader
 
     @classmethod
     def from_strings(cls, ctx, seqs: Sequence[str]) -> "SeqBatch":
@@ -64,6 +66,85 @@ class SeqBatch:
 
         data, off = pack_sequences(seqs)
         return cls(ctx, data, off)
+
+    @classmethod
+    def _view(cls, ctx, n, total, h_offsets, max_len, d_seq, d_off) -> "SeqBatch":
+        self = cls.__new__(cls)
+        self.ctx, self.n, self.total, self.h_offsets, self.max_len = ctx, n, total, h_offsets, max_len
+        self.d_seq, self.d_off = d_seq, d_off
+        self.ready = self.on_consumed = None
+        return self
+
+
+class BatchUploader:
+    """A stream of batches that arrives from the host (every job of the reference starts from a file,
+    snekmer/rules/kmerize.smk:89-129): `slots` recycled pairs of device buffers and pinned staging buffers on a COPY
+    context of its own; `upload(residues, offsets)` packs a batch into the next staging buffer and queues two
+    asynchronous copies - no allocation, no fill, no host wait per batch - and returns a SeqBatch whose `ready` event a
+    consumer on another context waits for ON THE DEVICE (engine.OverlappedPipeline.prefetch does).  A slot is refilled
+    only behind the event the consumer recorded after queuing the slot's last reader (`on_consumed`), and its staging
+    buffer only once the copy out of it has run.
+
+        up = BatchUploader(ctx, max_residues, max_sequences, slots=3)
+        pipe.prefetch(up.upload(res0, off0))
+        for res, off in files:
+            out = pipe.step(up.upload(res, off))     # the copy of batch i + 1 runs beside batch i's kernels
+    """
+
+    PAD = 64  # zero bytes behind the residues: 16-byte vector loads of the tail stay in bounds and read zeros
+
+    def __init__(self, ctx: _hip.Context, max_residues: int, max_sequences: int, slots: int = 3):
+        if not 2 <= slots <= _hip.EVENT_SLOTS:
+            raise ValueError(f"slots: 2..{_hip.EVENT_SLOTS}")
+        self.ctx = ctx  # the device (and the context the batches nominally live on)
+        self.copy = _hip.Context(ctx.device)
+        self.cap_res, self.cap_n = int(max_residues), int(max_sequences)
+        self.slots = []
+        for _ in range(slots):
+            h_seq = self.copy.host_alloc(self.cap_res + self.PAD)
+            h_off = self.copy.host_alloc(8 * (self.cap_n + 1)).view(np.int64)
+            self.slots.append({"d_seq": self.copy.empty(self.cap_res + self.PAD, np.uint8), "d_off": self.copy.empty(self.cap_n + 1, np.int64),
+                               "h_seq": h_seq, "h_off": h_off, "consumed": None, "used": False})
+        self.nxt = 0
+        self.host_waits = 0  # times upload() had to wait for a staging buffer's previous copy (0 in a well-fed stream)
+
+    def upload(self, residues: np.ndarray, offsets: np.ndarray) -> SeqBatch:
+        residues = np.asarray(residues, dtype=np.uint8)
+        offsets = np.asarray(offsets, dtype=np.int64)
+        n, total = int(offsets.size - 1), int(residues.size)
+        if offsets.ndim != 1 or offsets.size < 1 or offsets[0] != 0 or int(offsets[-1]) != total or np.any(np.diff(offsets) < 0):
+            raise ValueError("offsets must start at 0, be non-decreasing and end at the number of residues")
+        if total > self.cap_res or n > self.cap_n:
+            raise ValueError(f"batch of {n} sequences / {total} residues exceeds the uploader's capacity ({self.cap_n} / {self.cap_res})")
+        j = self.nxt
+        self.nxt = (j + 1) % len(self.slots)
+        sl = self.slots[j]
+        if sl["used"] and not self.copy.event_done(j):  # the staging buffer's previous copy has not run yet
+            self.host_waits += 1
+            self.copy.sync()
+        if sl["consumed"] is not None:  # the device buffers' last reader (another context's kernels)
+            self.copy.wait_event(*sl["consumed"])
+            sl["consumed"] = None
+        sl["h_seq"][:total] = residues
+        sl["h_seq"][total:total + self.PAD] = 0
+        sl["h_off"][: n + 1] = offsets
+        self.copy.h2d_async(sl["d_seq"].ptr, sl["h_seq"], total + self.PAD)
+        self.copy.h2d_async(sl["d_off"].ptr, sl["h_off"], 8 * (n + 1))
+        self.copy.record_event(j)
+        sl["used"] = True
+        batch = SeqBatch._view(self.ctx, n, total, offsets, int(np.diff(offsets).max()) if n else 0, sl["d_seq"], sl["d_off"])
+        batch.ready = (self.copy, j)
+
+        def consumed(ctx, slot, sl=sl):
+            sl["consumed"] = (ctx, slot)
+
+        batch.on_consumed = consumed
+        return batch
+
+    def close(self):
+        self.copy.sync()
+        self.slots = []
+        self.copy.close()
 
 
 class CountsCSR:
@@ -800,11 +881,18 @@ class Pipeline:
             self.ctx.graph_begin()
             try:
                 out = self._step_eager(batch)
-            except Exception:
+            except Exception as err:
                 try:
                     self.ctx.graph_end().close()
                 except _hip.HipError:
                     pass
+                if isinstance(err, _hip.HipError) and err.code in (-5, -7):
+                    # a scratch slot wanted to grow inside the capture (e.g. the heavy-row panels, switched on by the previous
+                    # step's hint, size their blocks for the first time now): nothing was executed - the calls were being
+                    # recorded -, so run the step for real, outside a capture, and start over with this shape
+                    out = self._step_eager(batch)
+                    ent.update(graph=None, sig=self._signature(), state=self._state())
+                    return out
                 del self._graphs[key]
                 raise
             graph = self.ctx.graph_end()
@@ -932,6 +1020,8 @@ class OverlappedPipeline:
         side.wait_event(self.ctx, self.EV_COS + s)
         if batch.ctx is not self.ctx and all(batch.ctx is not c for c in self.sides):
             raise ValueError("the batch must live on the pipeline's device")
+        if getattr(batch, "ready", None) is not None:  # an asynchronous upload (BatchUploader): ordered on the device
+            side.wait_event(*batch.ready)
         csr, basis, rnorm = self.sets[s]
         self.sets[s] = list(vectorize_fused(side, batch, self.lut, self.k, csr=csr, basis=basis, rnorm=rnorm))
         n = self.sets[s][0].n
@@ -939,6 +1029,8 @@ class OverlappedPipeline:
         if r < n:
             self._block(side, s, r, n, 1, 0, (n + 3) // 4 * 4)
         side.record_event(self.EV_VEC + s)
+        if getattr(batch, "on_consumed", None) is not None:  # the batch's buffers may be refilled behind this event
+            batch.on_consumed(side, self.EV_VEC + s)
         self.queue.append(s)
         self.nxt = (s + 1) % len(self.sets)
 

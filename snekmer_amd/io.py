@@ -93,28 +93,41 @@ def read_kmers(filename: str) -> List[str]:
 # writes), and ``load_pickle`` reads either path, with or without Snekmer installed.
 REFERENCE_MODULE = "snekmer.vectorize"
 _PICKLED_CLASSES = ("KmerVec", "KmerBasis", "KmerSet")
-_alias_lock = threading.Lock()
 
 
 def _reference_classes():
-    """(classes to name in the stream, modules to restore afterwards).  With Snekmer importable the real classes are
-    named; otherwise a throw-away module object stands in for the duration of the dump, because pickle checks that
-    ``sys.modules[module].name`` is the class it is asked to name."""
+    """The classes to name in the stream: Snekmer's own when it is importable, otherwise stand-ins that only carry the
+    reference's module path and names (never registered in sys.modules: `_StandInPickler` writes their names itself)."""
     try:
         mod = importlib.import_module(REFERENCE_MODULE)
-        return {name: getattr(mod, name) for name in _PICKLED_CLASSES}, None
+        return {name: getattr(mod, name) for name in _PICKLED_CLASSES}, False
     except Exception:
         pass
-    saved = {k: sys.modules.get(k) for k in ("snekmer", REFERENCE_MODULE)}
-    pkg, mod = types.ModuleType("snekmer"), types.ModuleType(REFERENCE_MODULE)
-    pkg.__path__ = []
-    pkg.vectorize = mod
-    classes = {}
-    for name in _PICKLED_CLASSES:
-        classes[name] = type(name, (), {"__module__": REFERENCE_MODULE, "__qualname__": name})
-        setattr(mod, name, classes[name])
-    sys.modules["snekmer"], sys.modules[REFERENCE_MODULE] = pkg, mod
-    return classes, saved
+    return {name: type(name, (), {"__module__": REFERENCE_MODULE, "__qualname__": name}) for name in _PICKLED_CLASSES}, True
+
+
+class _StandInPickler(pickle._Pickler):
+    """pickle's Python implementation with one change: a stand-in class is written by NAME without the check that
+    sys.modules[module].name is that class (the C pickler cannot skip it, which is why round 5 put throw-away modules
+    into sys.modules for the duration of a dump, where a concurrent `import snekmer` in another thread could see them)."""
+
+    def __init__(self, file, protocol, standins):
+        super().__init__(file, protocol=protocol)
+        self._standins = set(standins)
+
+    def save_global(self, obj, name=None):
+        if obj not in self._standins:
+            return super().save_global(obj, name)
+        if self.proto >= 4:
+            self.save(obj.__module__)
+            self.save(obj.__qualname__)
+            self.write(pickle.STACK_GLOBAL)
+        else:
+            self.write(pickle.GLOBAL + obj.__module__.encode() + b"\n" + obj.__qualname__.encode() + b"\n")
+        self.memoize(obj)
+
+    dispatch = dict(pickle._Pickler.dispatch)
+    dispatch[type] = save_global
 
 
 def dump_kmers(obj: Any, file, protocol: int = 4, reference_pickle: bool = True) -> None:
@@ -127,27 +140,22 @@ def dump_kmers(obj: Any, file, protocol: int = 4, reference_pickle: bool = True)
     from . import vectorize as V
 
     mine = {getattr(V, name): name for name in _PICKLED_CLASSES}
-    with _alias_lock:
-        classes, saved = _reference_classes()
-        try:
-            def convert(o):
-                name = mine.get(type(o))
-                if name is None:
-                    return o
-                get = getattr(type(o), "__getstate__", None)
-                state = get(o) if get is not None and get is not getattr(object, "__getstate__", None) else dict(o.__dict__)
-                twin = object.__new__(classes[name])  # same state under the reference's class: pickle then writes what Snekmer writes
-                twin.__dict__.update({k: convert(v) for k, v in state.items()})
-                return twin
+    classes, standins = _reference_classes()
 
-            pickle.dump(convert(obj), file, protocol=protocol)
-        finally:
-            if saved is not None:
-                for k, v in saved.items():
-                    if v is None:
-                        sys.modules.pop(k, None)
-                    else:
-                        sys.modules[k] = v
+    def convert(o):
+        name = mine.get(type(o))
+        if name is None:
+            return o
+        get = getattr(type(o), "__getstate__", None)
+        state = get(o) if get is not None and get is not getattr(object, "__getstate__", None) else dict(o.__dict__)
+        twin = object.__new__(classes[name])  # same state under the reference's class: pickle then writes what Snekmer writes
+        twin.__dict__.update({k: convert(v) for k, v in state.items()})
+        return twin
+
+    if standins:
+        _StandInPickler(file, protocol, classes.values()).dump(convert(obj))
+    else:
+        pickle.dump(convert(obj), file, protocol=protocol)
 
 
 class _KmersUnpickler(pickle.Unpickler):

@@ -455,8 +455,11 @@ def _set_measure(feature_matrix, kind: int, ctx=None) -> np.ndarray:
     ones = ctx.to_device(np.ones(n + 4, dtype=np.float32))
     ld = (n + 3) // 4 * 4
 
+    keep = []  # every array a queued kernel reads stays referenced until the result has been copied back below
+
     def gram(x, width):  # exact integer Gram in float32 cells (< 2^24: checked by skm_setsim_f64)
         colptr, post = engine.transpose(ctx, n, x.nnz, width, x.rowptr, x.colidx, x.counts)
+        keep.extend((colptr, post))
         return engine.cosine_matrix(ctx, x, ones, n, width, colptr, post, ones, mode=0, ld=ld)
 
     both = gram(pattern, ncols)
@@ -466,4 +469,6 @@ def _set_measure(feature_matrix, kind: int, ctx=None) -> np.ndarray:
     ctx.call("skm_setsim_f64", kind, C.c_int64(n), C.c_int64(n), C.c_int64(ncols), C.c_void_p(d_nnz.ptr), C.c_void_p(d_nnz.ptr),
              C.c_void_p(both.ptr), C.c_void_p(equal.ptr if equal is not None else None), C.c_int64(ld), C.c_void_p(out.ptr),
              C.c_int64(n))
-    return out.download().reshape(n, n)
+    result = out.download().reshape(n, n)  # waits for the stream: everything in `keep` has been read
+    del keep[:]
+    return result

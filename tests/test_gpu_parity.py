@@ -1685,7 +1685,6 @@ def test_config3_full_size_100k_overlapped_pipeline_the_timed_object(ctx):
     for seed_idx in (2, 31):
         res, off = synth_families(n, 300, family=100, seed=20250523 + seed_idx)[:2]
         packed.append((res, off))
-        batches.append(engine.SeqBatch(ctx, res, off))
         o_rowptr, o_codes, o_counts, o_first = orc.count_csr(lut.rank, lut.nsym, k, res, off, threads=0)
         ob, odf, otot, ofk, ocol = orc.basis(o_rowptr, o_codes, o_counts, o_first, threads=0)
         _, o_sum, o_nnz = orc.cosine_all(o_rowptr, ocol, o_counts, len(ob), stats=True)
@@ -1694,11 +1693,16 @@ def test_config3_full_size_100k_overlapped_pipeline_the_timed_object(ctx):
         want.append((o_rowptr, o_codes, o_counts, len(ob), o_sum, o_nnz, rows, ref))
         del o_first, odf, otot, ofk, ocol
     assert not (want[0][5] == want[1][5]).all()  # two different batches
-    order = (0, 1, 0, 1)
-    pipe.prefetch(batches[order[0]])
+    # the batches ARRIVE FROM THE HOST inside the loop, as in bench.py's timed region: one asynchronous upload per step from
+    # pinned staging buffers into three recycled device buffers (engine.BatchUploader; rules/kmerize.smk:89-129: every job of
+    # the reference starts from host data), ordered against the side context's vectorize by events on the device
+    del batches
+    up = engine.BatchUploader(ctx, max(int(p[0].size) for p in packed), n, slots=3)
+    order = (0, 1, 0, 1, 1)
+    pipe.prefetch(up.upload(*packed[order[0]]))
     for step, which in enumerate(order):
-        nxt = batches[order[step + 1]] if step + 1 < len(order) else None
-        out = pipe.step(nxt)  # the next batch's vectorize + lists are queued beside this cosine, as in the bench
+        nxt = up.upload(*packed[order[step + 1]]) if step + 1 < len(order) else None
+        out = pipe.step(nxt)  # the next batch's upload, vectorize + lists are queued beside this cosine, as in the bench
         pipe.sync()
         o_rowptr, o_codes, o_counts, ncols, o_sum, o_nnz, rows, ref = want[which]
         ld = out.shape[1]
@@ -1712,6 +1716,7 @@ def test_config3_full_size_100k_overlapped_pipeline_the_timed_object(ctx):
         got = np.stack([out.download(n, offset=int(r) * ld) for r in rows])
         assert np.abs(got - ref).max() <= COS_TOL, step
     pipe.out = None
+    up.close()
 
 
 def test_heavy_panels_at_100k_skewed_rows_equal_the_walk(ctx, skm_option):
