@@ -63,14 +63,27 @@ struct device_pool {
 device_pool *g_pools[MAX_DEVICES] = {};
 std::mutex g_pools_mu;
 int g_guard = -1;
+bool g_exit_hook = false, g_shut_down = false;
 
+void shutdown_at_exit();
+
+// nullptr once the process is exiting (the callers then hand their objects straight back to the runtime)
 device_pool *pool_of(int device)
 {
     if (device < 0 || device >= MAX_DEVICES)
         return nullptr;
     std::lock_guard<std::mutex> lock(g_pools_mu);
+    if (g_shut_down)
+        return nullptr;
+    if (!g_exit_hook) {
+        // registered at the first use of the library, i.e. after the HIP runtime registered its own exit handlers: runs
+        // BEFORE them, while streams and memory can still be handed back in an orderly way (a profiler that walks the
+        // process's queues in its finaliser crashed on the cached CU-masked streams: rocprofv3 --pmc, ROCm 7.2)
+        g_exit_hook = true;
+        atexit(shutdown_at_exit);
+    }
     if (!g_pools[device])
-        g_pools[device] = new device_pool();  // never deleted: the runtime may be gone before static destructors run
+        g_pools[device] = new device_pool();  // never deleted: its mutex may be in use by a thread that outlives main()
     return g_pools[device];
 }
 
@@ -217,6 +230,47 @@ int64_t trim_locked(device_pool *p)
     return released;
 }
 
+void shutdown_at_exit()
+{
+    device_pool *pools[MAX_DEVICES];
+    {
+        std::lock_guard<std::mutex> lock(g_pools_mu);
+        g_shut_down = true;
+        memcpy(pools, g_pools, sizeof(pools));
+    }
+    for (int d = 0; d < MAX_DEVICES; ++d) {
+        device_pool *p = pools[d];
+        if (!p || !p->mu.try_lock_for(std::chrono::seconds(2)))
+            continue;
+        if (hipSetDevice(d) == hipSuccess) {
+            quiesce_locked(p);  // contexts the program never destroyed
+            for (auto &it : p->limbo)
+                (void)hipFree(it.first);
+            p->limbo.clear();
+            for (auto &it : p->parked) {
+                for (hipEvent_t e : it.second.pending)
+                    (void)hipEventDestroy(e);
+                (void)hipFree(it.second.ptr);
+            }
+            p->parked.clear();
+            p->parked_bytes = 0;
+            for (auto &cs : p->streams)
+                (void)hipStreamDestroy(cs.stream);
+            p->streams.clear();
+            for (int t = 0; t < 2; ++t) {
+                for (hipEvent_t e : p->events[t])
+                    (void)hipEventDestroy(e);
+                p->events[t].clear();
+            }
+            for (void *page : p->pinned_pages)
+                (void)hipHostFree(page);
+            p->pinned_pages.clear();
+        }
+        (void)hipGetLastError();
+        p->mu.unlock();
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------- registry
@@ -340,7 +394,10 @@ int skm_pool_alloc(skm_ctx *ctx, size_t bytes, void **out)
 {
     *out = nullptr;
     device_pool *p = pool_of(ctx->device);
-    SKM_REQUIRE(p, SKM_E_BADARG, "skm_malloc: device %d out of range", ctx->device);
+    if (!p) {  // the process is exiting (or an impossible device number)
+        SKM_HIP(hipMalloc(out, bytes ? bytes : 1));
+        return SKM_OK;
+    }
     const bool guard = guard_on();
     const size_t user = bytes ? bytes : 1;
     const size_t cls = size_class(user + (guard ? GUARD_BYTES : 0));
@@ -395,7 +452,12 @@ int skm_pool_free(skm_ctx *ctx, void *ptr)
     if (!ptr)
         return SKM_OK;
     device_pool *p = pool_of(ctx->device);
-    SKM_REQUIRE(p, SKM_E_BADARG, "skm_free: device %d out of range", ctx->device);
+    if (!p) {  // the process is exiting: the pool has been handed back
+        (void)hipDeviceSynchronize();
+        (void)hipFree(ptr);
+        (void)hipGetLastError();
+        return SKM_OK;
+    }
     live_block lb;
     {
         std::lock_guard<std::timed_mutex> lock(p->mu);
