@@ -990,10 +990,12 @@ def apply_chain(ctx, engine, alphabet, args, seed):
     res, off, fam = synth_families(n, args.length, family=100, seed=seed)
     batch = engine.SeqBatch(ctx, res, off)
     csr = engine.count_csr(ctx, batch, lut, args.k)
-    basis = engine.build_basis(ctx, csr, lut.nsym, args.k, postings=False)
+    # the count matrix by column as well (the postings every vectorize step builds for the cosine): the learn aggregation
+    # sums list by list there and never sorts (skm_group_postings)
+    basis = engine.build_basis(ctx, csr, lut.nsym, args.k, postings=True)
     nfam = int(fam.max()) + 1
     groups = fam.astype(np.uint32)
-    totals = skm_apply.group_sum(ctx, csr, groups, nfam)
+    totals = skm_apply.group_sum(ctx, csr, groups, nfam, basis=basis)
     # postings walked: sum over query entries of the column's document frequency in the totals matrix
     tcol = totals.colidx.download(totals.nnz)
     df = np.bincount(tcol, minlength=basis.ncols)
@@ -1017,8 +1019,20 @@ def apply_chain(ctx, engine, alphabet, args, seed):
         ctx.profile_enable(False)
         return wall, prof, r
 
+    w, pr, _ = timed(lambda: skm_apply.group_sum(ctx, csr, groups, nfam, basis=basis))
+    out["group_sum"] = {"ms_incl_host": w, "kernel_ms": {k: round(v, 4) for k, v in pr.items() if v > 0.002}, "device_ms": sum(pr.values()),
+                        "what": "totals by column from the count matrix's postings (skm_group_postings: what skm_apply_top2 reads) AND the "
+                                "[families x columns] CSR of learn.smk:385-408 from them (skm_postings_to_csr, the library's own one-sweep by family)"}
+    w, pr, _ = timed(lambda: skm_apply.group_totals(ctx, csr, groups, nfam, basis=basis))
+    gp_bytes = csr.nnz * 8 + basis.ncols * 12 + totals.nnz * 24
+    out["group_totals_by_column"] = {"ms_incl_host": w, "kernel_ms": {k: round(v, 4) for k, v in pr.items() if v > 0.002}, "device_ms": sum(pr.values()),
+                                     "roofline": {"bound": "hbm", "algorithmic_bytes": gp_bytes,
+                                                  "bytes_are": "8 B per posting read + 12 B per column (two column starts read, one written) + 24 B per total (written to the "
+                                                               "column's slot, read and written once more by the packing pass)",
+                                                  "frac": gp_bytes / (sum(pr.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS if sum(pr.values()) > 0 else None}}
     w, pr, _ = timed(lambda: skm_apply.group_sum(ctx, csr, groups, nfam))
-    out["group_sum"] = {"ms_incl_host": w, "kernel_ms": {k: round(v, 4) for k, v in pr.items() if v > 0.002}, "device_ms": sum(pr.values())}
+    out["group_sum_from_csr_only"] = {"ms_incl_host": w, "kernel_ms": {k: round(v, 4) for k, v in pr.items() if v > 0.002}, "device_ms": sum(pr.values()),
+                                      "what": "no postings given: the CSR is transposed first (one 24-bit vendor radix sort of all entries)"}
     w, pr, r = timed(lambda: skm_apply.apply_top2(ctx, csr, basis.ncols, totals))
     k_ms = pr.get("k_apply_top2", 0.0)
     dev_ms = sum(pr.values())
@@ -1029,7 +1043,8 @@ def apply_chain(ctx, engine, alphabet, args, seed):
                      "bytes_are": "8 B per posting walked + 16 B per query entry (column id, count, column start and end) + 40 B per row written",
                      "ms": k_ms, "achieved_GBps": (walked * 8 + csr.nnz * 16 + n * 40) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
                      "frac": (walked * 8 + csr.nnz * 16 + n * 40) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
-                     "note": "latency-bound: three dependent gathers per entry (column start, posting, accumulator)"}}
+                     "note": "wave per query row; one gather per entry (the column's word: family and total when one family holds the k-mer), "
+                             "sums in a per-wave LDS hash table keyed by the family; rows touching more than 384 families go to the dense form"}}
     out["top1_is_own_family_frac"] = float(np.mean(r[0][:, 0] == fam))
 
     def unfused():
@@ -1084,6 +1099,28 @@ def config4_one_rank_share(ctx, engine, alphabet, args):
             del nb
     t_vec, t_nb, t_top, prof, entries, ovf = rec
     same = float(np.mean(fam[idx[:, 0].astype(np.int64) % n] == fam[:block]))
+    # rooflines of this configuration's own kernels (the 1 M-row forms: other kernels than config 3's step)
+    import ctypes as C
+
+    pairs = C.c_uint64(0)
+    ctx.call("skm_pair_work", C.c_int64(b.ncols), C.c_void_p(b.colptr.ptr), C.byref(pairs))
+    nnz = pipe.csr.nnz
+    code_b = 4 if pipe.csr.code_bits == 32 else 8
+    shared = int(b.colptr.download(1, offset=b.ncols)[0])  # postings = entries of k-mers found in >= 2 sequences
+    block_pairs = int(pairs.value) // world  # the rows are shuffled: a row block holds 1/8 of the matrix's (row, posting) pairs
+    rooflines = []
+    for names, nbytes, what in (
+            (("k_gram_sparse", "k_gram_sparse_big", "k_gram_sparse_huge"), block_pairs * 8,
+             "every (row, posting) pair of the 125 k-row block reads one 8-byte posting: 1/8 of the sum over shared columns of df^2"),
+            (("k_neighbors_topk", "k_neighbors_topk_lds"), int(entries) * 8 + block * 10 * 8,
+             "8 B per list entry read + 10 x 8 B (index, score) written per row"),
+            (("k_basis_scatter", "k_basis_scatter_fused"), nnz * (code_b + 4) + shared * 20 + b.ncols * (code_b + 4),
+             "1 M rows: sorted keys / indices read; per shared entry: posting word gathered, colidx + posting written; per column: code + start")):
+        ms = sum(prof[k][1] for k in names if k in prof)
+        if ms > 0:
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            rooflines.append({"kernels": [k for k in names if k in prof], "bound": "hbm", "algorithmic_bytes": int(nbytes), "ms": ms,
+                              "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS, "bytes_are": what})
     # a rank of the 8-GPU job: vectorize of its 125 k sequences (1/8 of the vectorize measured here), the exchange (not
     # measurable on one GPU: DESIGN.md section 7 prices it), then exactly the pairwise share measured here
     est = t_vec / world + t_nb + t_top
@@ -1094,6 +1131,7 @@ def config4_one_rank_share(ctx, engine, alphabet, args):
         "neighbour_lists_125k_x_1m_ms": t_nb * 1e3, "list_entries": int(entries), "entries_per_row": entries / block, "overflow_rows": int(ovf),
         "top10_ms_incl_download": t_top * 1e3, "top1_same_family_frac": same,
         "kernel_ms": {k: round(v[1], 3) for k, v in prof.items() if v[1] > 0.05},
+        "stage_rooflines": rooflines,
         "ESTIMATE_8_gpu": {"ms_per_job": est * 1e3, "sequences_per_s": n / est,
                            "how": "vectorize_1m_ms / 8 + neighbour_lists_125k_x_1m_ms + top10_ms: every rank's device work if the postings "
                                   "exchange (0.38 GB out, 2.2 GB in per rank over xGMI) were free; an estimate from one GPU, NOT a measurement "

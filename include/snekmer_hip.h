@@ -378,10 +378,27 @@ int skm_row_top2(skm_ctx *ctx, int64_t n, int64_t m, const float *d_scores, int6
 /* Learn aggregation (snekmer/rules/learn.smk:385-408): sum the count rows of each group
  * (annotation).  Input CSR rows carry a group id < ngroups (d_group[n]); output is the CSR of the
  * [ngroups x ncols] totals matrix with columns ascending per row: d_out_rowptr[ngroups+1],
- * d_out_col / d_out_val with capacity nnz.  *h_out_nnz is host-synchronous. */
+ * d_out_col / d_out_val with capacity nnz.  *h_out_nnz is host-synchronous.  Since round 6 this is
+ * skm_csr_transpose + skm_group_postings + skm_postings_to_csr (below); a caller that already holds the
+ * count matrix by column (the postings the vectorize stage builds) calls the last two itself. */
 int skm_csr_group_sum(skm_ctx *ctx, int64_t n, int64_t nnz, const int64_t *d_rowptr, const uint32_t *d_colidx,
                       const uint32_t *d_counts, const uint32_t *d_group, int64_t ngroups, int64_t *d_out_rowptr,
                       uint32_t *d_out_col, uint32_t *d_out_val, int64_t *h_out_nnz);
+/* The same sums taken where the count matrix already lies by column.  Input: postings of the n x ncols count matrix
+ * (d_colptr[ncols+1], d_post[nnz] = row | count << 32, as skm_basis_build / skm_vectorize_csr / skm_csr_transpose
+ * write them) and a group id per row.  Output, by column as well - the layout skm_apply_top2 reads -:
+ * d_out_colptr[ncols+1], d_out_post[<= nnz] = group | total << 32 with groups ascending inside a column; optionally
+ * d_out_normsq[ngroups] (exact squared norm of every group's total row, uint64) and d_out_rowcount[ngroups] (entries
+ * per group).  *h_out_nnz (entries written) is host-synchronous.  Totals are uint32 like the counts.
+ * Replaces the pandas groupby-sum of snekmer/rules/learn.smk:385-408 on a dense N x B table. */
+int skm_group_postings(skm_ctx *ctx, int64_t n, int64_t ncols, const uint32_t *d_colptr, const uint64_t *d_post, int64_t nnz,
+                       const uint32_t *d_group, int64_t ngroups, uint32_t *d_out_colptr, uint64_t *d_out_post,
+                       uint64_t *d_out_normsq, uint32_t *d_out_rowcount, int64_t *h_out_nnz);
+/* A matrix held by column (d_colptr[ncols+1], d_post[nnz] = row | value << 32) as CSR with ascending columns:
+ * d_out_rowptr[nrows+1], d_out_col[nnz], d_out_val[nnz] (one stable counting sort by row).  The family-total table of
+ * snekmer/rules/learn.smk:385-408 in row order, from skm_group_postings' output. */
+int skm_postings_to_csr(skm_ctx *ctx, int64_t ncols, int64_t nnz, const uint32_t *d_colptr, const uint64_t *d_post,
+                        int64_t nrows, int64_t *d_out_rowptr, uint32_t *d_out_col, uint32_t *d_out_val);
 
 /* Exact sparse Gram rows ("neighbour lists"): for rows [row0,row1) of X, every row j of Y sharing at
  * least one column, with the exact int32 dot product.  This is the reduced output for problem sizes

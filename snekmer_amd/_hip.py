@@ -127,6 +127,8 @@ _SIGNATURES = {
     "skm_pairwise_f64": (C.c_int, [_p, C.c_int, C.c_double, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64]),
     "skm_row_top2": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p]),
     "skm_csr_group_sum": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _p, _p, C.POINTER(_i64)]),
+    "skm_group_postings": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, C.POINTER(_i64)]),
+    "skm_postings_to_csr": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _p, _p, _p]),
     "skm_gram_neighbors": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _p, _p, C.c_int, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)]),
     "skm_neighbors_topk": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p, _p]),
     "skm_jaccard_distance_from_gram": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64]),

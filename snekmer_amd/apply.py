@@ -19,10 +19,19 @@ _p = C.c_void_p
 _i64 = C.c_int64
 
 
-def group_sum(ctx, csr: engine.CountsCSR, groups: Sequence[int], ngroups: int) -> engine.CountsCSR:
-    """Sum the count rows of each group.  `csr.colidx` must be set (engine.build_basis); the
-    result is a CountsCSR over the same column space whose `colidx` (ascending per row) and
-    `counts` are filled and whose `codes` are unused."""
+class ColumnTotals:
+    """The family-total matrix by column (skm_group_postings): colptr uint32[ncols+1], post uint64 = family | total << 32
+    (families ascending inside a column), normsq uint64[families] (exact squared norms of the total rows).  The layout
+    skm_apply_top2 reads; `group_sum` hangs it on the CSR it returns so that `apply_top2` does not sort the totals again."""
+
+    def __init__(self, n, ncols, nnz, colptr, post, normsq):
+        self.n, self.ncols, self.nnz, self.colptr, self.post, self.normsq = n, ncols, nnz, colptr, post, normsq
+
+
+def group_totals(ctx, csr: engine.CountsCSR, groups: Sequence[int], ngroups: int, basis=None, ncols: Optional[int] = None) -> ColumnTotals:
+    """Per-annotation sums of the count rows (snekmer/rules/learn.smk:385-408) BY COLUMN.  `basis`: the engine.Basis of
+    `csr` with its postings (engine.build_basis / the vectorize stage leave the count matrix by column: no sort is needed
+    then); without it the CSR is transposed first (skm_csr_transpose; `ncols` or one look at the column ids)."""
     if csr.colidx is None:
         raise ValueError("group_sum needs column ids: call engine.build_basis first")
     if getattr(csr, "elided", False):
@@ -34,14 +43,38 @@ def group_sum(ctx, csr: engine.CountsCSR, groups: Sequence[int], ngroups: int) -
     if g.size and int(g.max()) >= ngroups:
         raise ValueError("group id out of range")
     d_g = ctx.to_device(g if g.size else np.zeros(1, np.uint32))
-    cap = max(csr.nnz, 1)
-    out = engine.CountsCSR(ctx, ngroups, 0, 32, ctx.empty(ngroups + 1, np.int64), ctx.empty(1, np.uint32),
+    nnz = csr.nnz
+    if basis is not None and basis.colptr is not None and basis.post is not None and basis.post_bits == 64:
+        ncols, colptr, post = basis.ncols, basis.colptr, basis.post
+    else:
+        if ncols is None:
+            if basis is not None:
+                ncols = basis.ncols
+            else:
+                ncols = (int(csr.colidx.download(nnz).max()) + 1) if nnz else 0
+        colptr, post = engine.transpose(ctx, csr.n, nnz, ncols, csr.rowptr, csr.colidx, csr.counts)
+    out_colptr = ctx.empty(ncols + 1, np.uint32)
+    out_post = ctx.empty(max(nnz, 1), np.uint64)
+    normsq = ctx.empty(max(ngroups, 1), np.uint64)
+    got = _i64(0)
+    ctx.call("skm_group_postings", _i64(csr.n), _i64(ncols), _p(colptr.ptr), _p(post.ptr), _i64(nnz), _p(d_g.ptr), _i64(ngroups),
+             _p(out_colptr.ptr), _p(out_post.ptr), _p(normsq.ptr), _p(None), C.byref(got))
+    return ColumnTotals(ngroups, ncols, int(got.value), out_colptr, out_post, normsq)
+
+
+def group_sum(ctx, csr: engine.CountsCSR, groups: Sequence[int], ngroups: int, basis=None, ncols: Optional[int] = None) -> engine.CountsCSR:
+    """Sum the count rows of each group.  `csr.colidx` must be set (engine.build_basis); the
+    result is a CountsCSR over the same column space whose `colidx` (ascending per row) and
+    `counts` are filled and whose `codes` are unused.  Its `columns` attribute holds the same totals by column
+    (ColumnTotals), which `apply_top2` uses as they are.  `basis` (with postings): see `group_totals`."""
+    cols = group_totals(ctx, csr, groups, ngroups, basis=basis, ncols=ncols)
+    cap = max(cols.nnz, 1)
+    out = engine.CountsCSR(ctx, ngroups, cols.nnz, 32, ctx.empty(ngroups + 1, np.int64), ctx.empty(1, np.uint32),
                            ctx.empty(cap, np.uint32), None)
     out.colidx = ctx.empty(cap, np.uint32)
-    nnz = _i64(0)
-    ctx.call("skm_csr_group_sum", _i64(csr.n), _i64(csr.nnz), _p(csr.rowptr.ptr), _p(csr.colidx.ptr), _p(csr.counts.ptr),
-             _p(d_g.ptr), _i64(ngroups), _p(out.rowptr.ptr), _p(out.colidx.ptr), _p(out.counts.ptr), C.byref(nnz))
-    out.nnz = int(nnz.value)
+    ctx.call("skm_postings_to_csr", _i64(cols.ncols), _i64(cols.nnz), _p(cols.colptr.ptr), _p(cols.post.ptr), _i64(ngroups),
+             _p(out.rowptr.ptr), _p(out.colidx.ptr), _p(out.counts.ptr))
+    out.columns = cols
     return out
 
 
@@ -78,13 +111,18 @@ def apply_top2(ctx, csr: engine.CountsCSR, ncols: int, totals: engine.CountsCSR,
     if getattr(csr, "elided", False) or getattr(totals, "elided", False):
         raise ValueError("apply_top2 needs real column ids on both sides (no elide_singletons)")
     xsq = engine.row_normsq(ctx, csr.n, csr.rowptr, csr.counts)
-    ysq = engine.row_normsq(ctx, totals.n, totals.rowptr, totals.counts)
-    colptr, post = engine.transpose(ctx, totals.n, totals.nnz, ncols, totals.rowptr, totals.colidx, totals.counts)
+    cols = totals if isinstance(totals, ColumnTotals) else getattr(totals, "columns", None)
+    if cols is not None and cols.ncols == ncols:  # the totals by column already (group_sum / group_totals): nothing to sort
+        colptr, post, ysq, m = cols.colptr, cols.post, cols.normsq, cols.n
+    else:
+        ysq = engine.row_normsq(ctx, totals.n, totals.rowptr, totals.counts)
+        colptr, post = engine.transpose(ctx, totals.n, totals.nnz, ncols, totals.rowptr, totals.colidx, totals.counts)
+        m = totals.n
     idx = ctx.empty(max(2 * rows, 1), np.uint32)
     score = ctx.empty(max(2 * rows, 1), np.float64)
     dot = ctx.empty(max(2 * rows, 1), np.int64)
     ctx.call("skm_apply_top2", _i64(csr.n), _p(csr.rowptr.ptr), _p(csr.colidx.ptr), _p(csr.counts.ptr), _p(xsq.ptr),
-             _i64(totals.n), _i64(ncols), _p(colptr.ptr), _p(post.ptr), _p(ysq.ptr), _i64(row0), _i64(row1),
+             _i64(m), _i64(ncols), _p(colptr.ptr), _p(post.ptr), _p(ysq.ptr), _i64(row0), _i64(row1),
              _p(idx.ptr), _p(score.ptr), _p(dot.ptr))
     return (idx.download(2 * rows).reshape(rows, 2), score.download(2 * rows).reshape(rows, 2),
             dot.download(2 * rows).reshape(rows, 2))
@@ -117,12 +155,12 @@ def predict(ctx, csr: engine.CountsCSR, ncols: int, totals: engine.CountsCSR, la
     return out
 
 
-def learn_apply(ctx, csr: engine.CountsCSR, ncols: int, groups: Sequence[int], ngroups: int, materialize: bool = False):
+def learn_apply(ctx, csr: engine.CountsCSR, ncols: int, groups: Sequence[int], ngroups: int, materialize: bool = False, basis=None):
     """Self-evaluation chain of rules/learn.smk: totals per annotation, cosine of every sequence
     against every annotation, top-2 and delta (rounded to 2 decimals as learn.smk:842/apply.smk:325).
     The N x A score block is only produced when `materialize` is set (the save_apply_associations
     branch of apply.smk:298-301 writes it out)."""
-    totals = group_sum(ctx, csr, groups, ngroups)
+    totals = group_sum(ctx, csr, groups, ngroups, basis=basis, ncols=ncols)
     idx, score, dot = apply_top2(ctx, csr, ncols, totals)
     out = {"totals": totals, "top2_index": idx, "top2_score": score, "top2_dot": dot,
            "delta": np.round(score[:, 0] - score[:, 1], 2)}

@@ -8,11 +8,19 @@
 //                                          snekmer/score.py:149-172 (e.g. length-normalised rows of
 //                                          snekmer/utils.py:183-203)
 //
-//   k_apply_top2          workgroup per query row: the row's exact integer dot products with every
-//                         family (row of Y) are accumulated in LDS straight from Y's posting lists, the
-//                         float64 scores dot / (|x| |y|) are formed from those exact integers, and only
-//                         the two best (score desc, column asc) leave the kernel: the N x A block of
-//                         rules/apply.smk:282-289 is never stored.
+//   k_apply_columns       one word per column of the family-total matrix: (family, total) when exactly one family
+//                         holds the k-mer (nine columns in ten), a marker otherwise.  Built per call (one pass
+//                         over the column starts).
+//   k_apply_top2          WAVE per query row: a lane reads an entry's column id and count (coalesced), then ONE
+//                         gather - the column's word - gives it the family and the total; columns shared by
+//                         several families go on to the posting list.  The exact integer dot products are summed
+//                         in a 512-slot LDS hash table per wave keyed by the family (a query touches a handful
+//                         of families, whatever their number), the float64 scores dot / (|x| |y|) are formed
+//                         from those exact integers, and only the two best (score desc, column asc) leave the
+//                         kernel: the N x A block of rules/apply.smk:282-289 is never stored.  (Until round 5: a
+//                         workgroup per row with dense accumulators over all families, three dependent gathers
+//                         per entry and a scan of every family per row: 1.23 ms for 100 k queries x 1000 families.)
+//   k_apply_top2_dense    that workgroup-per-row form, for the rows that touch more than 384 families.
 //   k_cosine_dense_f64    dense float64 GEMM of row-normalised operands on the f64 matrix cores
 //                         (v_mfma_f64_16x16x4_f64): sklearn semantics (normalise in float64, zero
 //                         norms -> 1, then dot) for feature matrices that are not counts.
@@ -55,22 +63,27 @@ __global__ void k_norms_f64(int64_t m, const uint64_t *__restrict__ normsq, doub
         out[j] = normsq[j] ? sqrt((double)normsq[j]) : 1.0;
 }
 
-__global__ __launch_bounds__(ATB) void k_apply_top2(const int64_t *__restrict__ xrowptr,
-                                                    const uint32_t *__restrict__ xcolidx,
-                                                    const uint32_t *__restrict__ xcounts,
-                                                    const uint64_t *__restrict__ xnormsq, int64_t m,
-                                                    const uint32_t *__restrict__ ycolptr,
-                                                    const uint64_t *__restrict__ ypost,
-                                                    const double *__restrict__ ynorm, int64_t row0, int64_t nrows,
-                                                    int ach, uint32_t *__restrict__ out_idx,
-                                                    double *__restrict__ out_score, long long *__restrict__ out_dot)
+// rows: those listed in row_list[0 .. *row_count) (positions in the launch's row range)
+__global__ __launch_bounds__(ATB) void k_apply_top2_dense(const int64_t *__restrict__ xrowptr,
+                                                          const uint32_t *__restrict__ xcolidx,
+                                                          const uint32_t *__restrict__ xcounts,
+                                                          const uint64_t *__restrict__ xnormsq, int64_t m,
+                                                          const uint32_t *__restrict__ ycolptr,
+                                                          const uint64_t *__restrict__ ypost,
+                                                          const double *__restrict__ ynorm, int64_t row0,
+                                                          const uint32_t *__restrict__ row_list,
+                                                          const uint32_t *__restrict__ row_count,
+                                                          int ach, uint32_t *__restrict__ out_idx,
+                                                          double *__restrict__ out_score, long long *__restrict__ out_dot)
 {
     // `ach` accumulators (families per pass) of dynamic LDS: sized to the problem so that a handful of
     // families does not cost the occupancy of 8192
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_acc[];
     __shared__ top2 s_t[ATB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const uint32_t nlisted = *row_count;
+    for (uint32_t it = blockIdx.x; it < nlisted; it += gridDim.x) {
+        const int64_t r = row_list[it];
         const int64_t i = row0 + r;
         const int64_t b = xrowptr[i], e = xrowptr[i + 1];
         const uint64_t nx = xnormsq[i];
@@ -135,6 +148,160 @@ __global__ __launch_bounds__(ATB) void k_apply_top2(const int64_t *__restrict__ 
             out_dot[2 * r + 1] = t.i2 == NONE ? 0 : t.d2;
         }
         __syncthreads();
+    }
+}
+
+// ---- the wave-per-row form
+constexpr uint32_t COL_MULTI = 0xFFFFFFFEu;  // family field of a column word: several families hold the k-mer
+constexpr int AHS = 512, AHCAP = 384;        // hash slots per wave / families a wave holds
+
+__global__ __launch_bounds__(256) void k_apply_columns(int64_t ncols, const uint32_t *__restrict__ ycolptr,
+                                                       const uint64_t *__restrict__ ypost, uint64_t *__restrict__ desc)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncols)
+        return;
+    const uint32_t pb = ycolptr[c], pe = ycolptr[c + 1];
+    uint64_t w = ~0ull;  // no family holds it
+    if (pe - pb == 1u)
+        w = ypost[pb];   // family | total << 32
+    else if (pe > pb)
+        w = (uint64_t)COL_MULTI;
+    desc[c] = w;
+}
+
+__global__ __launch_bounds__(ATB) void k_apply_top2(const int64_t *__restrict__ xrowptr,
+                                                    const uint32_t *__restrict__ xcolidx,
+                                                    const uint32_t *__restrict__ xcounts,
+                                                    const uint64_t *__restrict__ xnormsq, int64_t m,
+                                                    const uint64_t *__restrict__ ydesc,
+                                                    const uint32_t *__restrict__ ycolptr,
+                                                    const uint64_t *__restrict__ ypost,
+                                                    const double *__restrict__ ynorm, int64_t row0, int64_t nrows,
+                                                    uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_count,
+                                                    uint32_t *__restrict__ out_idx,
+                                                    double *__restrict__ out_score, long long *__restrict__ out_dot)
+{
+    constexpr int NW = ATB / 64;
+    __shared__ uint32_t s_key[NW][AHS];
+    __shared__ unsigned long long s_val[NW][AHS];
+    __shared__ uint32_t s_distinct[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint32_t *keys = s_key[wid];
+    unsigned long long *vals = s_val[wid];
+    for (int z = lane; z < AHS; z += 64) {
+        keys[z] = NONE;
+        vals[z] = 0ull;
+    }
+    if (lane == 0)
+        s_distinct[wid] = 0u;
+    __threadfence_block();
+    auto add = [&](uint32_t fam, unsigned long long prod) {
+        uint32_t h = (fam * 2654435761u) >> (32 - 9);
+        for (int probe = 0; probe < AHS; ++probe) {
+            uint32_t seen = __atomic_load_n(&keys[h], __ATOMIC_RELAXED);
+            if (seen == NONE) {
+                seen = atomicCAS(&keys[h], NONE, fam);
+                if (seen == NONE) {
+                    seen = fam;
+                    atomicAdd(&s_distinct[wid], 1u);
+                }
+            }
+            if (seen == fam) {
+                atomicAdd(&vals[h], prod);
+                break;
+            }
+            h = (h + 1) & (AHS - 1);
+        }
+    };
+    const int64_t wave = (int64_t)blockIdx.x * NW + wid, nwaves = (int64_t)gridDim.x * NW;
+    for (int64_t r = wave; r < nrows; r += nwaves) {
+        const int64_t i = row0 + r;
+        const int64_t b = xrowptr[i], e = xrowptr[i + 1];
+        // four entries per lane and step: the coalesced loads, then the four gathers, are issued together
+        for (int64_t q0 = b; q0 < e; q0 += 256) {
+            uint32_t c[4], v[4];
+            uint64_t w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t q = q0 + u * 64 + lane;
+                c[u] = q < e ? xcolidx[q] : NONE;
+                v[u] = q < e ? xcounts[q] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                w[u] = (ydesc && c[u] != NONE) ? ydesc[c[u]] : ~0ull;  // (ydesc == nullptr: Y has no column or no row)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t fam = (uint32_t)w[u];
+                if (fam == NONE)
+                    continue;
+                if (fam != COL_MULTI) {
+                    add(fam, (unsigned long long)v[u] * (unsigned long long)(w[u] >> 32));
+                    continue;
+                }
+                const uint32_t pb = ycolptr[c[u]], pe = ycolptr[c[u] + 1];
+                for (uint32_t p = pb; p < pe; ++p) {
+                    const uint64_t pw = ypost[p];
+                    add((uint32_t)pw, (unsigned long long)v[u] * (unsigned long long)(pw >> 32));
+                }
+            }
+        }
+        __threadfence_block();
+        const uint32_t distinct = __atomic_load_n(&s_distinct[wid], __ATOMIC_RELAXED);  // wave-uniform
+        const uint64_t nx = xnormsq[i];
+        const double sx = nx ? sqrt((double)nx) : 1.0;
+        top2 t = {-INFINITY, -INFINITY, 0, 0, NONE, NONE};
+        for (int z = 0; z < AHS / 64; ++z) {  // the table's entries (and the table cleared for the next row)
+            const int slot = z * 64 + lane;
+            const uint32_t fam = keys[slot];
+            if (fam != NONE) {
+                const long long d = (long long)vals[slot];
+                if (distinct <= (uint32_t)AHCAP)
+                    top2_push(t, (double)d / (sx * ynorm[fam]), fam, d);
+                keys[slot] = NONE;
+                vals[slot] = 0ull;
+            }
+        }
+        if (lane == 0)
+            s_distinct[wid] = 0u;
+        __threadfence_block();
+        if (distinct > (uint32_t)AHCAP) {  // more families than the table may hold: the dense form takes the row
+            if (lane == 0)
+                over_list[atomicAdd(over_count, 1u)] = (uint32_t)r;
+            continue;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            top2 u;
+            u.v1 = __shfl_down(t.v1, o), u.v2 = __shfl_down(t.v2, o);
+            u.d1 = __shfl_down(t.d1, o), u.d2 = __shfl_down(t.d2, o);
+            u.i1 = __shfl_down(t.i1, o), u.i2 = __shfl_down(t.i2, o);
+            if (u.i1 != NONE)
+                top2_push(t, u.v1, u.i1, u.d1);
+            if (u.i2 != NONE)
+                top2_push(t, u.v2, u.i2, u.d2);
+        }
+        if (lane == 0) {
+            // families the row shares nothing with score 0.0 and rank by their index (np.argsort(-S) on equal scores,
+            // ties towards the lower column): the smallest indices not taken yet fill what is left of the two slots
+            if (t.i1 == NONE) {
+                t.i1 = m > 0 ? 0u : NONE;
+                t.v1 = 0.0, t.d1 = 0;
+            }
+            if (t.i2 == NONE && t.i1 != NONE) {
+                const uint32_t cand = t.i1 == 0u ? 1u : 0u;
+                if ((int64_t)cand < m) {
+                    t.i2 = cand;
+                    t.v2 = 0.0, t.d2 = 0;
+                }
+            }
+            out_idx[2 * r] = t.i1;
+            out_idx[2 * r + 1] = t.i2;
+            out_score[2 * r] = t.i1 == NONE ? 0.0 : t.v1;
+            out_score[2 * r + 1] = t.i2 == NONE ? 0.0 : t.v2;
+            out_dot[2 * r] = t.i1 == NONE ? 0 : t.d1;
+            out_dot[2 * r + 1] = t.i2 == NONE ? 0 : t.d2;
+        }
     }
 }
 
@@ -326,16 +493,36 @@ extern "C" int skm_apply_top2(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         k_norms_f64<<<(unsigned)skm_ceil_div(m, 256), 256, 0, ctx->stream>>>(m, d_ynormsq, ynorm);
         SKM_TRY(skm_check_launch("k_norms_f64"));
     }
+    SKM_TRY(skm_ws(ctx, WS_I, sizeof(uint64_t) * (size_t)(ncols + 1), &p));
+    uint64_t *desc = (uint64_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_H, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
+    uint32_t *over_list = (uint32_t *)p + 8, *over_count = (uint32_t *)p;
+    SKM_HIP(hipMemsetAsync(over_count, 0, 4, ctx->stream));
+    if (ncols && m) {
+        SKM_REQUIRE(d_ypost, SKM_E_BADARG, "skm_apply_top2: null postings");
+        SKM_PROF(ctx, "k_apply_columns");
+        k_apply_columns<<<(unsigned)skm_ceil_div(ncols, 256), 256, 0, ctx->stream>>>(ncols, d_ycolptr, d_ypost, desc);
+        SKM_TRY(skm_check_launch("k_apply_columns"));
+    }
+    {
+        // (with no column or no family every entry is skipped: xcolidx may then only hold 0xFFFFFFFF)
+        SKM_PROF(ctx, "k_apply_top2");
+        k_apply_top2<<<skm_grid_cap(ctx, skm_ceil_div(nrows, ATB / 64), 16), ATB, 0, ctx->stream>>>(
+            d_xrowptr, d_xcolidx, d_xcounts, d_xnormsq, m, (ncols && m) ? desc : nullptr, d_ycolptr, d_ypost, ynorm, row0, nrows, over_list,
+            over_count, d_idx, d_score, (long long *)d_dot);
+        SKM_TRY(skm_check_launch("k_apply_top2"));
+    }
     int ach = 256;  // power of two >= m, at most ACH
     while (ach < ACH && ach < m)
         ach <<= 1;
     const size_t lds = sizeof(unsigned long long) * (size_t)ach;
-    SKM_HIP(hipFuncSetAttribute((const void *)k_apply_top2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SKM_PROF(ctx, "k_apply_top2");
-    k_apply_top2<<<skm_grid_cap(ctx, nrows, 32), ATB, lds, ctx->stream>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xnormsq, m,
-                                                                          d_ycolptr, d_ypost, ynorm, row0, nrows, ach, d_idx,
-                                                                          d_score, (long long *)d_dot);
-    return skm_check_launch("k_apply_top2");
+    SKM_HIP(hipFuncSetAttribute((const void *)k_apply_top2_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SKM_PROF(ctx, "k_apply_top2_dense");
+    // rows that touch more than 384 families (listed on the device; usually none: the workgroups find an empty list)
+    k_apply_top2_dense<<<skm_grid_cap(ctx, nrows, 4), ATB, lds, ctx->stream>>>(d_xrowptr, d_xcolidx, d_xcounts, d_xnormsq, m, d_ycolptr,
+                                                                              d_ypost, ynorm, row0, over_list, over_count, ach,
+                                                                              d_idx, d_score, (long long *)d_dot);
+    return skm_check_launch("k_apply_top2_dense");
 }
 
 extern "C" int skm_cosine_dense_f64(skm_ctx *ctx, int64_t n, int64_t m, int64_t k, const double *d_x, int64_t ldx,

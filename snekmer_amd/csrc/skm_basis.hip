@@ -171,49 +171,6 @@ __global__ __launch_bounds__(BLK) void k_row_top2(int64_t n, int64_t m, const fl
     }
 }
 
-__global__ void k_group_keys(int64_t n, const int64_t *__restrict__ rowptr, const uint32_t *__restrict__ colidx,
-                             const uint32_t *__restrict__ group, uint64_t *__restrict__ keys)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t i = wave; i < n; i += nwaves) {
-        const uint64_t g = (uint64_t)group[i] << 32;
-        for (int64_t t = rowptr[i] + lane; t < rowptr[i + 1]; t += 64)
-            keys[t] = g | colidx[t];
-    }
-}
-
-struct head_flag_u64 {
-    const uint64_t *keys;
-    __device__ uint32_t operator()(uint32_t t) const { return (t == 0 || keys[t] != keys[t - 1]) ? 1u : 0u; }
-};
-
-__global__ void k_group_emit(int64_t nnz, const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ svals,
-                             const uint32_t *__restrict__ slot1, uint32_t *__restrict__ out_col,
-                             uint32_t *__restrict__ out_val, int64_t *__restrict__ out_rowptr, int64_t ngroups)
-{
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; t < nnz; t += stride) {
-        const uint64_t key = skeys[t];
-        const uint32_t slot = slot1[t] - 1u;
-        const bool head = t == 0 || skeys[t - 1] != key;
-        if (head)
-            out_col[slot] = (uint32_t)key;
-        atomicAdd(&out_val[slot], svals[t]);
-        // first entry of a group: rows g' in (previous group, this group] start at this slot
-        const uint32_t g = (uint32_t)(key >> 32);
-        const int64_t gprev = t == 0 ? -1 : (int64_t)(skeys[t - 1] >> 32);
-        if ((int64_t)g != gprev)
-            for (int64_t q = gprev + 1; q <= (int64_t)g; ++q)
-                out_rowptr[q] = slot;
-        if (t == nnz - 1)
-            for (int64_t q = (int64_t)g + 1; q <= ngroups; ++q)
-                out_rowptr[q] = (int64_t)slot + 1;
-    }
-}
-
 // KIND 0: 1 - hamming distance; KIND 1: Jaccard distance.  In place over the intersection sizes.
 template <int KIND>
 __global__ void k_setsim_from_gram(int64_t n, int64_t m, float inv_cols, const float *__restrict__ xc,
@@ -820,65 +777,7 @@ extern "C" int skm_row_top2(skm_ctx *ctx, int64_t n, int64_t m, const float *d_s
     return skm_check_launch("k_row_top2");
 }
 
-extern "C" int skm_csr_group_sum(skm_ctx *ctx, int64_t n, int64_t nnz, const int64_t *d_rowptr, const uint32_t *d_colidx,
-                                 const uint32_t *d_counts, const uint32_t *d_group, int64_t ngroups,
-                                 int64_t *d_out_rowptr, uint32_t *d_out_col, uint32_t *d_out_val, int64_t *h_out_nnz)
-{
-    SKM_REQUIRE(ctx && n >= 0 && nnz >= 0 && ngroups >= 0 && d_out_rowptr && h_out_nnz, SKM_E_BADARG,
-                "skm_csr_group_sum: bad argument");
-    SKM_REQUIRE(nnz < ((int64_t)1 << 32) - 1 && ngroups < ((int64_t)1 << 32), SKM_E_OVERFLOW, "skm_csr_group_sum: too large");
-    SKM_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    *h_out_nnz = 0;
-    if (nnz == 0) {
-        SKM_HIP(hipMemsetAsync(d_out_rowptr, 0, sizeof(int64_t) * (size_t)(ngroups + 1), st));
-        return SKM_OK;
-    }
-    SKM_REQUIRE(d_rowptr && d_colidx && d_counts && d_group && d_out_col && d_out_val, SKM_E_BADARG,
-                "skm_csr_group_sum: null array");
-    void *p;
-    SKM_TRY(skm_ws(ctx, WS_A, sizeof(uint64_t) * (size_t)nnz, &p));
-    uint64_t *keys = (uint64_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_B, sizeof(uint64_t) * (size_t)nnz, &p));
-    uint64_t *skeys = (uint64_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_C, sizeof(uint32_t) * (size_t)nnz, &p));
-    uint32_t *svals = (uint32_t *)p;
-    SKM_TRY(skm_ws(ctx, WS_D, sizeof(uint32_t) * (size_t)nnz, &p));
-    uint32_t *slot1 = (uint32_t *)p;
-    {
-        SKM_PROF(ctx, "k_group_keys");
-        k_group_keys<<<skm_grid_cap(ctx, skm_ceil_div(n, BLK / 64), 16), BLK, 0, st>>>(n, d_rowptr, d_colidx, d_group, keys);
-    }
-    SKM_TRY(skm_check_launch("k_group_keys"));
-    int gbits = 1;
-    while (gbits < 32 && ((int64_t)1 << gbits) < ngroups)
-        ++gbits;
-    {
-        size_t tmp = 0;
-        SKM_HIP(rocprim::radix_sort_pairs(nullptr, tmp, keys, skeys, d_counts, svals, (size_t)nnz, 0u, (unsigned)(32 + gbits), st));
-        SKM_TRY(skm_ws(ctx, WS_ROCPRIM, tmp, &p));
-        SKM_PROF(ctx, "rocprim_radix_sort_groups");
-        SKM_HIP(rocprim::radix_sort_pairs(p, tmp, keys, skeys, d_counts, svals, (size_t)nnz, 0u, (unsigned)(32 + gbits), st));
-    }
-    {
-        size_t tmp = 0;
-        auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), head_flag_u64{skeys});
-        SKM_HIP(rocprim::inclusive_scan(nullptr, tmp, in, slot1, (size_t)nnz, rocprim::plus<uint32_t>(), st));
-        SKM_TRY(skm_ws(ctx, WS_ROCPRIM, tmp, &p));
-        SKM_HIP(rocprim::inclusive_scan(p, tmp, in, slot1, (size_t)nnz, rocprim::plus<uint32_t>(), st));
-    }
-    SKM_HIP(hipMemsetAsync(d_out_val, 0, sizeof(uint32_t) * (size_t)nnz, st));
-    {
-        SKM_PROF(ctx, "k_group_emit");
-        k_group_emit<<<skm_grid_cap(ctx, skm_ceil_div(nnz, BLK), 16), BLK, 0, st>>>(nnz, skeys, svals, slot1, d_out_col,
-                                                                                    d_out_val, d_out_rowptr, ngroups);
-    }
-    SKM_TRY(skm_check_launch("k_group_emit"));
-    SKM_HIP(hipMemcpyAsync(ctx->h_pinned, slot1 + (nnz - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    SKM_HIP(hipStreamSynchronize(st));
-    *h_out_nnz = (int64_t)*(uint32_t *)ctx->h_pinned;
-    return SKM_OK;
-}
+// skm_csr_group_sum (learn aggregation): skm_learn.hip
 
 extern "C" int skm_hamming_similarity_from_gram(skm_ctx *ctx, int64_t n, int64_t m, int64_t ncols, const float *d_xcount,
                                                 const float *d_ycount, float *d_out, int64_t ld)

@@ -2587,3 +2587,113 @@ def test_fuzz_short(ctx):
         fz.score_round(ctx, seed)
     for seed in range(20):
         fz.surface_round(ctx, seed)
+
+
+# ------------------------------------------------------------------ f1 / f2 (round 6): the column-major learn / apply chain
+def _dev_csr(ctx, M):
+    from snekmer_amd import engine
+
+    M = M.tocsr()
+    M.sort_indices()
+    c = engine.CountsCSR(ctx, M.shape[0], M.nnz, 32, ctx.to_device(M.indptr.astype(np.int64)),
+                         ctx.to_device(np.zeros(max(M.nnz, 1), np.uint32)), ctx.to_device(M.data.astype(np.uint32) if M.nnz else np.zeros(1, np.uint32)), None)
+    c.colidx = ctx.to_device(M.indices.astype(np.uint32) if M.nnz else np.zeros(1, np.uint32))
+    return c
+
+
+@pytest.mark.parametrize("n,K,ngroups,density,hot", [(5000, 3000, 40, 0.01, 3), (9000, 500, 700, 0.02, 2), (300, 64, 5, 0.3, 0), (40, 7, 60, 0.5, 1)])
+def test_group_sum_by_column_every_list_class_equals_numpy(ctx, n, K, ngroups, density, hot):
+    """Learn aggregation (snekmer/rules/learn.smk:385-408) by column: lists of at most 8 postings (registers), up to 4096
+    (per-wave hash table), longer ones and lists with more than 384 distinct groups (dense counters) - `hot` columns are
+    held by every row -; the CSR by group from it; the C entry point skm_csr_group_sum on the same input; all equal to the
+    dense numpy sums, columns ascending."""
+    import ctypes as C
+
+    import scipy.sparse as sp
+
+    from snekmer_amd import apply as skm_apply
+    from snekmer_amd import engine
+
+    rng = np.random.default_rng(n + K)
+    X = sp.random(n, K, density=density, random_state=3, data_rvs=lambda s: rng.integers(1, 50, size=s)).tolil()
+    for c in range(hot):
+        X[:, c] = rng.integers(1, 9, size=(n, 1))
+    X = X.tocsr().astype(np.int64)
+    groups = rng.integers(0, ngroups, size=n).astype(np.uint32)
+    if ngroups > 2:
+        groups[groups == 1] = 0  # an empty group in the middle
+    x = _dev_csr(ctx, X)
+    want = np.zeros((ngroups, K), dtype=np.int64)
+    np.add.at(want, groups, X.toarray())
+
+    def dense_of(t):
+        rp = t.rowptr.download(ngroups + 1)
+        col, val = t.colidx.download(t.nnz), t.counts.download(t.nnz)
+        assert int(rp[-1]) == t.nnz
+        for g in range(ngroups):
+            assert (np.diff(col[rp[g] : rp[g + 1]].astype(np.int64)) > 0).all(), "columns must ascend inside a row"
+        D = np.zeros((ngroups, K), dtype=np.int64)
+        D[np.repeat(np.arange(ngroups), np.diff(rp)), col] = val
+        return D
+
+    # 1. postings supplied (what the vectorize stage leaves): no sort of the input
+    colptr, post = engine.transpose(ctx, n, X.nnz, K, x.rowptr, x.colidx, x.counts)
+    basis = engine.Basis()
+    basis.ncols, basis.colptr, basis.post = K, colptr, post
+    t = skm_apply.group_sum(ctx, x, groups, ngroups, basis=basis)
+    assert (dense_of(t) == want).all()
+    cols = t.columns
+    cp, pw = cols.colptr.download(K + 1).astype(np.int64), cols.post.download(cols.nnz)
+    assert int(cp[-1]) == cols.nnz == int((want != 0).sum())
+    for c in range(K):
+        fam = (pw[cp[c] : cp[c + 1]] & 0xFFFFFFFF).astype(np.int64)
+        assert (np.diff(fam) > 0).all() and (want[fam, c] == (pw[cp[c] : cp[c + 1]] >> 32).astype(np.int64)).all()
+    assert (cols.normsq.download(ngroups) == (want.astype(object) ** 2).sum(axis=1).astype(np.uint64)).all()
+    # 2. from the CSR alone (one transposition inside)
+    assert (dense_of(skm_apply.group_sum(ctx, x, groups, ngroups)) == want).all()
+    # 3. the C entry point
+    out = engine.CountsCSR(ctx, ngroups, 0, 32, ctx.empty(ngroups + 1, np.int64), ctx.empty(1, np.uint32), ctx.empty(max(X.nnz, 1), np.uint32), None)
+    out.colidx = ctx.empty(max(X.nnz, 1), np.uint32)
+    got = C.c_int64(0)
+    d_g = ctx.to_device(groups)
+    ctx.call("skm_csr_group_sum", C.c_int64(n), C.c_int64(X.nnz), C.c_void_p(x.rowptr.ptr), C.c_void_p(x.colidx.ptr), C.c_void_p(x.counts.ptr),
+             C.c_void_p(d_g.ptr), C.c_int64(ngroups), C.c_void_p(out.rowptr.ptr), C.c_void_p(out.colidx.ptr), C.c_void_p(out.counts.ptr), C.byref(got))
+    out.nnz = int(got.value)
+    assert (dense_of(out) == want).all()
+
+
+def test_apply_top2_wave_per_row_equals_numpy_and_the_dense_form(ctx):
+    """skm_apply_top2 (rules/apply.smk:278-328): rows that touch a handful of families (the per-wave hash table), rows
+    that touch more than 384 (handed to the dense workgroup form), totals given by column (ColumnTotals from group_sum)
+    and as a CSR; indices, exact dots and float64 scores equal to numpy's argsort on the dense score block."""
+    import scipy.sparse as sp
+
+    from snekmer_amd import apply as skm_apply
+
+    rng = np.random.default_rng(77)
+    n, A_, K = 4000, 600, 5000
+    X = sp.random(n, K, density=0.01, random_state=5, data_rvs=lambda s: rng.integers(1, 9, size=s)).tocsr().astype(np.int64)
+    member = rng.integers(0, A_, size=n).astype(np.uint32)
+    # a few rows share columns with nearly every family (wide rows), most with a few
+    wide = sp.random(12, K, density=0.5, random_state=6, data_rvs=lambda s: rng.integers(1, 5, size=s)).tocsr().astype(np.int64)
+    X = sp.vstack([X, wide]).tocsr()
+    member = np.concatenate([member, rng.integers(0, A_, size=12).astype(np.uint32)])
+    x = _dev_csr(ctx, X)
+    totals = skm_apply.group_sum(ctx, x, member, A_)
+    T = np.zeros((A_, K), dtype=np.int64)
+    np.add.at(T, member, X.toarray())
+    G = X.toarray() @ T.T
+    xs = np.sqrt((X.toarray() ** 2).sum(axis=1).astype(np.float64))
+    ts = np.sqrt((T ** 2).sum(axis=1).astype(np.float64))
+    xs[xs == 0] = 1.0
+    ts[ts == 0] = 1.0
+    S = np.where(G != 0, G / (xs[:, None] * ts[None, :]), 0.0)
+    order = np.argsort(-S, axis=1, kind="stable")[:, :2]
+    for tot in (totals, totals.columns):
+        idx, score, dot = skm_apply.apply_top2(ctx, x, K, tot)
+        assert (idx == order).all()
+        assert (dot == np.take_along_axis(G, order, axis=1)).all()
+        assert (score == np.take_along_axis(S, order, axis=1)).all()
+    plain = _dev_csr(ctx, sp.csr_matrix(T))  # no `columns`: transposed inside, as before
+    idx, score, dot = skm_apply.apply_top2(ctx, x, K, plain)
+    assert (idx == order).all() and (dot == np.take_along_axis(G, order, axis=1)).all()
