@@ -397,11 +397,17 @@ __global__ __launch_bounds__(BLK) void k_row_norms(int64_t n, const int64_t *__r
 // column-id array written and re-read, no host round trip.  Singletons are elided (cosine pipeline form).
 constexpr int HB = 2048;  // sorted positions per block: 256 threads x 8 consecutive positions
 
-template <typename K>
+// SCAN: the last workgroup to finish (atomic ticket in a word that is zero between launches) also turns the per-block
+// counts into exclusive prefixes, the number of columns and the closing colptr entry - what k_scan_blocks does in a launch
+// of its own.  Taken for small inputs, where a step is a chain of launch-bound kernels (one dependent dispatch less).
+template <typename K, bool SCAN>
 __global__ __launch_bounds__(256) void k_head_count(const int64_t *__restrict__ d_nnz, const K *__restrict__ skeys,
-                                                    uint32_t *__restrict__ blockheads)
+                                                    uint32_t *__restrict__ blockheads, uint32_t *__restrict__ ticket,
+                                                    int64_t *__restrict__ d_ncols, uint32_t *__restrict__ colptr)
 {
     __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_carry;
+    __shared__ int s_last;
     const int64_t nnz = *d_nnz;
     const int64_t base = (int64_t)blockIdx.x * HB;
     uint32_t heads = 0;
@@ -416,8 +422,56 @@ __global__ __launch_bounds__(256) void k_head_count(const int64_t *__restrict__ 
     if ((threadIdx.x & 63) == 0)
         s_w[threadIdx.x >> 6] = heads;
     __syncthreads();
-    if (threadIdx.x == 0)
-        blockheads[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (!SCAN) {
+        if (threadIdx.x == 0)
+            blockheads[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        return;
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&blockheads[blockIdx.x], s_w[0] + s_w[1] + s_w[2] + s_w[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
+        s_carry = 0;
+    }
+    __syncthreads();
+    if (!s_last)
+        return;
+    __threadfence();
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t nblocks = gridDim.x;
+    for (int64_t b0 = 0; b0 < nblocks; b0 += 256) {
+        const int64_t b = b0 + tid;
+        const uint32_t v = b < nblocks ? __hip_atomic_load(&blockheads[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o)
+                incl += up;
+        }
+        __syncthreads();  // the previous round's s_w is no longer read
+        if (lane == 63)
+            s_w[wid] = incl;
+        __syncthreads();
+        uint32_t before = s_carry, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            before += w < wid ? s_w[w] : 0u;
+            total += s_w[w];
+        }
+        if (b < nblocks)
+            blockheads[b] = before + incl - v;
+        __syncthreads();
+        if (tid == 0)
+            s_carry += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *d_ncols = (int64_t)s_carry;
+        if (colptr)
+            colptr[s_carry] = (uint32_t)nnz;
+        *ticket = 0u;
+    }
 }
 
 // exclusive prefix of the per-block head counts (one workgroup), the number of columns and the closing colptr entry
@@ -998,11 +1052,20 @@ int skm_basis_stage_async(skm_ctx *ctx, int code_bits, int key_bits, int64_t cap
     }
     {
         SKM_PROF(ctx, "k_head_count");
-        if (code_bits == 32)
-            k_head_count<uint32_t><<<(unsigned)nblocks, 256, 0, st>>>(d_nnz, (const uint32_t *)skeys, blockheads);
-        else
-            k_head_count<uint64_t><<<(unsigned)nblocks, 256, 0, st>>>(d_nnz, (const uint64_t *)skeys, blockheads);
-        k_scan_blocks<<<1, 1024, 0, st>>>(nblocks, blockheads, d_nnz, d_ncols, d_colptr);
+        if (nblocks <= 4096) {  // small inputs: the scan over the blocks rides on the last workgroup of the count (one launch less)
+            SKM_TRY(skm_ws(ctx, WS_ZERO, 256, &p));
+            uint32_t *ticket = (uint32_t *)p + 32;  // (words 0-6: the count stage's size-class counters; zero between launches)
+            if (code_bits == 32)
+                k_head_count<uint32_t, true><<<(unsigned)nblocks, 256, 0, st>>>(d_nnz, (const uint32_t *)skeys, blockheads, ticket, d_ncols, d_colptr);
+            else
+                k_head_count<uint64_t, true><<<(unsigned)nblocks, 256, 0, st>>>(d_nnz, (const uint64_t *)skeys, blockheads, ticket, d_ncols, d_colptr);
+        } else {
+            if (code_bits == 32)
+                k_head_count<uint32_t, false><<<(unsigned)nblocks, 256, 0, st>>>(d_nnz, (const uint32_t *)skeys, blockheads, nullptr, nullptr, nullptr);
+            else
+                k_head_count<uint64_t, false><<<(unsigned)nblocks, 256, 0, st>>>(d_nnz, (const uint64_t *)skeys, blockheads, nullptr, nullptr, nullptr);
+            k_scan_blocks<<<1, 1024, 0, st>>>(nblocks, blockheads, d_nnz, d_ncols, d_colptr);
+        }
     }
     SKM_TRY(skm_check_launch("k_head_count"));
     {

@@ -237,6 +237,8 @@ class _ColumnMajor:
 class ShardedPipeline:
     """vectorize the local shard, exchange, then cosine (or top-k) for the local row block."""
 
+    MAX_SHARD_RESIDUES = (1 << 30) - 1  # one digit of the one-sweep sort groups a shard by owner: 30-bit positions
+
     def __init__(self, ctx, lut, k: int, exchange, bounds: Sequence[Tuple[int, int]], total_residues: int,
                  basis: Optional[str] = None, columns: Optional[str] = None):
         import os
@@ -331,7 +333,7 @@ class ShardedPipeline:
         # residues (3.5 M sequences of 300 aa on ONE rank; include/snekmer_hip.h, skm_bucket_partition)
         # The check is COLLECTIVE: a rank whose shard is too large sends -1 counts through the first size gather instead of
         # raising alone, so that every rank raises (the others would otherwise wait for it inside the all-to-all).
-        too_large = cap >= 1 << 30
+        too_large = cap > self.MAX_SHARD_RESIDUES
         owners = self.columns == "owners"
         if too_large:
             d_counts.upload(np.full(d_counts.size, -1, dtype=np.int64))

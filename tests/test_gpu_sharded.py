@@ -228,3 +228,27 @@ def _config4_body(ctx, lut, k, n, world, topk, check):
     # the exchange moved what the design says it moves: every entry once (12 B, 7/8 of them off-rank) in the
     # all-to-all, then 7 copies of every owner's arrays in the all-gather
     assert tw.bytes_moved > ref.csr.nnz * 12 * 7 // 8
+
+
+def test_oversized_shard_is_refused_by_every_rank(ctx):
+    """A shard beyond the per-rank limit must not leave the other ranks waiting inside the next collective: the rank that
+    finds it sends -1 counts through the first size gather and EVERY rank raises (here the limit is lowered on rank 1 only)."""
+    from snekmer_amd import alphabet as A
+    from snekmer_amd.dist import shard_bounds
+    from snekmer_amd.synth import synth_families
+
+    lut, k, world, n = A.build_lut("red6"), 12, 3, 600
+    res, off, _ = synth_families(n, 300, family=20, seed=5)
+    bounds = shard_bounds(n, world)
+
+    def extra(rank, rctx, sp, shard):
+        if rank == 1:
+            sp.MAX_SHARD_RESIDUES = 1000
+        try:
+            sp.step(shard)
+        except ValueError as exc:
+            return str(exc)
+        return None
+
+    results, _ = _run_sharded(world, lut, k, res, off, bounds, extra)
+    assert all(r is not None and "rank(s) [1]" in r for r in results), results
