@@ -426,6 +426,10 @@ class Context:
         return DeviceArray(self, host.shape, host.dtype).upload(host)
 
     def sync(self):
+        """Wait for the context's stream.  Errors that only the device can detect are reported HERE (and by downloads), i.e.
+        possibly calls later than their cause: a HipError SKM_E_BADARG from sync() / download() naming `max_seq_len` refers
+        to an earlier count_csr / vectorize call on this context whose bound was smaller than one of its sequences (those
+        rows were left empty); the word is sticky until reported once."""
         _check(self.lib, self.lib.skm_sync(self.handle))
 
     # -- HIP graphs (skm_graph_*): record a fixed sequence of calls once, replay it with one launch

@@ -8,12 +8,11 @@
 //                                          snekmer/score.py:149-172 (e.g. length-normalised rows of
 //                                          snekmer/utils.py:183-203)
 //
-//   k_apply_columns       one word per column of the family-total matrix: (family, total) when exactly one family
-//                         holds the k-mer (nine columns in ten), a marker otherwise.  Built per call (one pass
-//                         over the column starts).
+//   k_apply_columns       two words per column of the family-total matrix: up to two (family, total) postings inline,
+//                         or a marker and the posting range.  Built per call (one pass over the column starts).
 //   k_apply_top2          WAVE per query row: a lane reads an entry's column id and count (coalesced), then ONE
-//                         gather - the column's word - gives it the family and the total; columns shared by
-//                         several families go on to the posting list.  The exact integer dot products are summed
+//                         16-byte gather - the column's words - gives it the families and totals; columns shared by
+//                         three or more families go on to the posting list.  The exact integer dot products are summed
 //                         in a 512-slot LDS hash table per wave keyed by the family (a query touches a handful
 //                         of families, whatever their number), the float64 scores dot / (|x| |y|) are formed
 //                         from those exact integers, and only the two best (score desc, column asc) leave the
@@ -155,18 +154,26 @@ __global__ __launch_bounds__(ATB) void k_apply_top2_dense(const int64_t *__restr
 constexpr uint32_t COL_MULTI = 0xFFFFFFFEu;  // family field of a column word: several families hold the k-mer
 constexpr int AHS = 512, AHCAP = 384;        // hash slots per wave / families a wave holds
 
+// Two words per column: up to two (family | total << 32) postings inline (0xFFFFFFFF... = none), or the marker and the
+// column's posting range (start | end << 32) when three or more families hold the k-mer.  One 16-byte gather per query
+// entry then covers every column with at most two families, and longer ones need no look at the column starts.
 __global__ __launch_bounds__(256) void k_apply_columns(int64_t ncols, const uint32_t *__restrict__ ycolptr,
-                                                       const uint64_t *__restrict__ ypost, uint64_t *__restrict__ desc)
+                                                       const uint64_t *__restrict__ ypost, ulonglong2 *__restrict__ desc)
 {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= ncols)
         return;
     const uint32_t pb = ycolptr[c], pe = ycolptr[c + 1];
-    uint64_t w = ~0ull;  // no family holds it
-    if (pe - pb == 1u)
-        w = ypost[pb];   // family | total << 32
-    else if (pe > pb)
-        w = (uint64_t)COL_MULTI;
+    ulonglong2 w = make_ulonglong2(~0ull, ~0ull);  // no family holds it
+    if (pe - pb == 1u) {
+        w.x = ypost[pb];
+    } else if (pe - pb == 2u) {
+        w.x = ypost[pb];
+        w.y = ypost[pb + 1];
+    } else if (pe > pb) {
+        w.x = (uint64_t)COL_MULTI;
+        w.y = (uint64_t)pb | ((uint64_t)pe << 32);
+    }
     desc[c] = w;
 }
 
@@ -174,8 +181,7 @@ __global__ __launch_bounds__(ATB) void k_apply_top2(const int64_t *__restrict__ 
                                                     const uint32_t *__restrict__ xcolidx,
                                                     const uint32_t *__restrict__ xcounts,
                                                     const uint64_t *__restrict__ xnormsq, int64_t m,
-                                                    const uint64_t *__restrict__ ydesc,
-                                                    const uint32_t *__restrict__ ycolptr,
+                                                    const ulonglong2 *__restrict__ ydesc,
                                                     const uint64_t *__restrict__ ypost,
                                                     const double *__restrict__ ynorm, int64_t row0, int64_t nrows,
                                                     uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_count,
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(ATB) void k_apply_top2(const int64_t *__restrict__ 
         // four entries per lane and step: the coalesced loads, then the four gathers, are issued together
         for (int64_t q0 = b; q0 < e; q0 += 256) {
             uint32_t c[4], v[4];
-            uint64_t w[4];
+            ulonglong2 w[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t q = q0 + u * 64 + lane;
@@ -229,18 +235,20 @@ __global__ __launch_bounds__(ATB) void k_apply_top2(const int64_t *__restrict__ 
                 v[u] = q < e ? xcounts[q] : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                w[u] = (ydesc && c[u] != NONE) ? ydesc[c[u]] : ~0ull;  // (ydesc == nullptr: Y has no column or no row)
+            for (int u = 0; u < 4; ++u)  // (ydesc == nullptr: Y has no column or no row)
+                w[u] = (ydesc && c[u] != NONE) ? ydesc[c[u]] : make_ulonglong2(~0ull, ~0ull);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint32_t fam = (uint32_t)w[u];
+                const uint32_t fam = (uint32_t)w[u].x;
                 if (fam == NONE)
                     continue;
                 if (fam != COL_MULTI) {
-                    add(fam, (unsigned long long)v[u] * (unsigned long long)(w[u] >> 32));
+                    add(fam, (unsigned long long)v[u] * (unsigned long long)(w[u].x >> 32));
+                    if ((uint32_t)w[u].y != NONE)
+                        add((uint32_t)w[u].y, (unsigned long long)v[u] * (unsigned long long)(w[u].y >> 32));
                     continue;
                 }
-                const uint32_t pb = ycolptr[c[u]], pe = ycolptr[c[u] + 1];
+                const uint32_t pb = (uint32_t)w[u].y, pe = (uint32_t)(w[u].y >> 32);
                 for (uint32_t p = pb; p < pe; ++p) {
                     const uint64_t pw = ypost[p];
                     add((uint32_t)pw, (unsigned long long)v[u] * (unsigned long long)(pw >> 32));
@@ -493,8 +501,8 @@ extern "C" int skm_apply_top2(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         k_norms_f64<<<(unsigned)skm_ceil_div(m, 256), 256, 0, ctx->stream>>>(m, d_ynormsq, ynorm);
         SKM_TRY(skm_check_launch("k_norms_f64"));
     }
-    SKM_TRY(skm_ws(ctx, WS_I, sizeof(uint64_t) * (size_t)(ncols + 1), &p));
-    uint64_t *desc = (uint64_t *)p;
+    SKM_TRY(skm_ws(ctx, WS_I, sizeof(ulonglong2) * (size_t)(ncols + 1), &p));
+    ulonglong2 *desc = (ulonglong2 *)p;
     SKM_TRY(skm_ws(ctx, WS_H, sizeof(uint32_t) * (size_t)(nrows + 8), &p));
     uint32_t *over_list = (uint32_t *)p + 8, *over_count = (uint32_t *)p;
     SKM_HIP(hipMemsetAsync(over_count, 0, 4, ctx->stream));
@@ -508,7 +516,7 @@ extern "C" int skm_apply_top2(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         // (with no column or no family every entry is skipped: xcolidx may then only hold 0xFFFFFFFF)
         SKM_PROF(ctx, "k_apply_top2");
         k_apply_top2<<<skm_grid_cap(ctx, skm_ceil_div(nrows, ATB / 64), 16), ATB, 0, ctx->stream>>>(
-            d_xrowptr, d_xcolidx, d_xcounts, d_xnormsq, m, (ncols && m) ? desc : nullptr, d_ycolptr, d_ypost, ynorm, row0, nrows, over_list,
+            d_xrowptr, d_xcolidx, d_xcounts, d_xnormsq, m, (ncols && m) ? desc : nullptr, d_ypost, ynorm, row0, nrows, over_list,
             over_count, d_idx, d_score, (long long *)d_dot);
         SKM_TRY(skm_check_launch("k_apply_top2"));
     }

@@ -266,8 +266,10 @@ __global__ __launch_bounds__(BLK) void k_gp_compact(int64_t ncols, int64_t cols_
             const uint32_t g = (uint32_t)w;
             const unsigned long long v = w >> 32;
             if (local) {
-                atomicAdd(&s_sq[g], v * v);
-                atomicAdd(&s_n[g], 1u);
+                if (out_normsq)
+                    atomicAdd(&s_sq[g], v * v);
+                if (out_rowcount)
+                    atomicAdd(&s_n[g], 1u);
             } else {
                 if (out_normsq)
                     atomicAdd(&out_normsq[g], v * v);
@@ -279,12 +281,10 @@ __global__ __launch_bounds__(BLK) void k_gp_compact(int64_t ncols, int64_t cols_
     if (local) {
         __syncthreads();
         for (int z = tid; z < (int)ngroups; z += BLK) {
-            if (s_n[z]) {
-                if (out_normsq)
-                    atomicAdd(&out_normsq[z], s_sq[z]);
-                if (out_rowcount)
-                    atomicAdd(&out_rowcount[z], s_n[z]);
-            }
+            if (out_normsq && s_sq[z])
+                atomicAdd(&out_normsq[z], s_sq[z]);
+            if (out_rowcount && s_n[z])
+                atomicAdd(&out_rowcount[z], s_n[z]);
         }
     }
 }

@@ -364,3 +364,24 @@ def test_threaded_npz_writer_matches_numpy_savez(tmp_path):
         sio.save_npz(str(tmp_path / "obj"), {"o": np.array([{}], dtype=object)})
     with pytest.raises(_hip.HipError):
         sio.save_npz(str(tmp_path / "no" / "dir" / "x.npz"), arrays)
+
+
+def test_runtime_resources_are_only_taken_in_the_pool_module():
+    """Design rule of round 6: device memory, streams and events are taken from the HIP runtime in
+    ONE translation unit (csrc/skm_mem.hip) and recycled; no other source calls hipMalloc / hipFree / hipStreamCreate* /
+    hipStreamDestroy / hipEventCreate* / hipEventDestroy (three long fuzz runs of round 5 stopped inside a hipFree that met a
+    busy device).  Pinned staging memory of the per-record API (skm_host_alloc) is the one exception, in skm_api.hip."""
+    import glob
+    import re
+
+    csrc = os.path.join(ROOT, "snekmer_amd", "csrc")
+    pat = re.compile(r"\b(hipMalloc|hipFree|hipStreamCreate\w*|hipExtStreamCreate\w*|hipStreamDestroy|hipEventCreate\w*|hipEventDestroy|hipMallocAsync|hipFreeAsync)\s*\(")
+    bad = []
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp"))):
+        if os.path.basename(path) == "skm_mem.hip":
+            continue
+        for no, line in enumerate(open(path), 1):
+            code = line.split("//")[0]
+            if pat.search(code):
+                bad.append(f"{os.path.basename(path)}:{no}: {line.strip()}")
+    assert not bad, bad

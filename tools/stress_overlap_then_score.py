@@ -34,6 +34,11 @@ def watchdog():
             for name, cid, ints in list(_hip.CALL_TRACE):
                 print(f"  ctx {cid % 100000:5d} {name} {[v for v in ints if v is not None][:10]}", flush=True)
             faulthandler.dump_traceback(all_threads=True)
+            threading.Timer(60.0, lambda: os._exit(4)).start()
+            try:  # which stream is busy, which timed kernel started and did not finish, what the pool holds
+                print(_hip.debug_report(), flush=True)
+            except Exception as exc:  # noqa: BLE001
+                print(f"debug_report: {exc}", flush=True)
             try:  # is the device busy (a kernel that never ends) or idle (the host waits for something that is not coming)?
                 import subprocess
 
@@ -79,4 +84,4 @@ for it in range(iters):
         skm.score.connection_matrix_from_features(X.astype(np.float64) * 1.5, metric="cosine")
     if it % 500 == 0:
         print(f"iteration {it}: {time.perf_counter() - t0:.0f} s", flush=True)
-print(f"stress ok: {iters} iterations in {time.perf_counter() - t0:.0f} s", flush=True)
+print(f"stress ok: {iters} iterations in {time.perf_counter() - t0:.0f} s; pool {_hip.default_context().mem_stats()}", flush=True)
