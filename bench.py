@@ -1046,6 +1046,14 @@ def apply_chain(ctx, engine, alphabet, args, seed):
                      "note": "wave per query row; one gather per entry (the column's word: family and total when one family holds the k-mer), "
                              "sums in a per-wave LDS hash table keyed by the family; rows touching more than 384 families go to the dense form"}}
     out["top1_is_own_family_frac"] = float(np.mean(r[0][:, 0] == fam))
+    # the same call with the rows PROCESSED in label order (learn.smk's self-evaluation knows the labels; real inputs arrive
+    # one family per FASTA file): the kernel's one random 128-byte line per query entry then hits in L2.  Same results.
+    by_label = np.argsort(fam, kind="stable").astype(np.uint32)
+    w2, pr2, r2o = timed(lambda: skm_apply.apply_top2(ctx, csr, basis.ncols, totals, order=by_label))
+    out["fused_apply_top2_rows_in_label_order"] = {
+        "ms_incl_host": w2, "device_ms": sum(pr2.values()), "kernel_ms": {k: round(v, 4) for k, v in pr2.items() if v > 0.002},
+        "equal_to_the_shuffled_order": bool((r2o[0] == r[0]).all() and (r2o[1] == r[1]).all() and (r2o[2] == r[2]).all()),
+        "k_apply_top2_frac": (walked * 8 + csr.nnz * 16 + n * 40) / (pr2.get("k_apply_top2", 0.0) * 1e-3) / 1e9 / HBM_PEAK_GBS if pr2.get("k_apply_top2") else None}
 
     def unfused():
         S, ld = skm_apply.cosine_rows_vs_totals(ctx, csr, basis.ncols, totals)

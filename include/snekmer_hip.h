@@ -494,11 +494,15 @@ int skm_matrix_row_stats(skm_ctx *ctx, int64_t n, int64_t m, const float *d_in, 
  *                      counting as 1 (sklearn's rule), formed from the EXACT integer dot and norms
  *   d_dot[2r+{0,1}]    those exact dot products (int64)
  * so Score = d_score[2r], delta = round(d_score[2r] - d_score[2r+1], 2) and the confidence lookup of
- * rules/apply.smk:325-326 are reproducible on the host from integers alone. */
+ * rules/apply.smk:325-326 are reproducible on the host from integers alone.
+ * d_row_order (may be NULL): a permutation of [0, row1 - row0) giving the ORDER in which the rows are processed (results
+ * stay at their rows' positions).  The kernel is bound by one random 128-byte line per query entry; an order that puts
+ * similar rows next to each other (the training labels in learn.smk's self-evaluation, the records of one family's FASTA
+ * file) lets the rows in flight find the columns' words in L2. */
 int skm_apply_top2(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
                    const uint32_t *d_xcounts, const uint64_t *d_xnormsq, int64_t m, int64_t ncols,
                    const uint32_t *d_ycolptr, const uint64_t *d_ypost, const uint64_t *d_ynormsq, int64_t row0,
-                   int64_t row1, uint32_t *d_idx, double *d_score, int64_t *d_dot);
+                   int64_t row1, const uint32_t *d_row_order, uint32_t *d_idx, double *d_score, int64_t *d_dot);
 
 /* ---- multi-GPU (RCCL over xGMI; one context per rank) --------------------------------------- */
 #define SKM_COMM_ID_BYTES 128

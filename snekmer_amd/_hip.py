@@ -139,7 +139,7 @@ _SIGNATURES = {
     "skm_row_norms_i8": (C.c_int, [_p, _i64, _i64, _p, _p, _p]),
     "skm_cosine_dense_f64": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, C.c_int, _p, _i64]),
     "skm_matrix_row_stats": (C.c_int, [_p, _i64, _i64, _p, _i64, _p, _p]),
-    "skm_apply_top2": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p]),
+    "skm_apply_top2": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "skm_fasta_index": (C.c_int, [_p, _i64, C.c_int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_int)]),
     "skm_fasta_parse": (C.c_int, [_p, _i64, C.c_int, _i64, _i64, _p, _p, _p, _p]),
     "skm_csr_to_dense_i8": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _p]),

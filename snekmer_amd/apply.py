@@ -100,14 +100,23 @@ def row_top2(ctx, scores, n: int, m: int, ld: int) -> Tuple[np.ndarray, np.ndarr
 
 
 def apply_top2(ctx, csr: engine.CountsCSR, ncols: int, totals: engine.CountsCSR,
-               row0: int = 0, row1: Optional[int] = None):
+               row0: int = 0, row1: Optional[int] = None, order: Optional[Sequence[int]] = None):
     """The apply epilogue fused with the cosine (skm_apply_top2): for every query row the two
     best-scoring rows of `totals`, without materialising the N x A score block of
     rules/apply.smk:282-289.  Returns (idx uint32[rows,2], score float64[rows,2], dot int64[rows,2]);
     scores are formed in float64 from the exact integer dot products and squared norms, so
-    ``round(score[:,0] - score[:,1], 2)`` is the reference's ``delta`` (apply.smk:320-325)."""
+    ``round(score[:,0] - score[:,1], 2)`` is the reference's ``delta`` (apply.smk:320-325).
+    `order`: a permutation of the rows [0, row1 - row0) in which to PROCESS them (results stay in row order): rows that
+    share k-mers next to each other - e.g. ``np.argsort(labels, kind="stable")`` in learn.smk's self-evaluation - make the
+    kernel's one random access per entry hit in L2."""
     row1 = csr.n if row1 is None else row1
     rows = row1 - row0
+    d_order = None
+    if order is not None:
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+        if order.size != rows or (rows and not (np.sort(order) == np.arange(rows, dtype=np.uint32)).all()):
+            raise ValueError("order must be a permutation of the rows")
+        d_order = ctx.to_device(order if rows else np.zeros(1, np.uint32))
     if getattr(csr, "elided", False) or getattr(totals, "elided", False):
         raise ValueError("apply_top2 needs real column ids on both sides (no elide_singletons)")
     xsq = engine.row_normsq(ctx, csr.n, csr.rowptr, csr.counts)
@@ -123,7 +132,7 @@ def apply_top2(ctx, csr: engine.CountsCSR, ncols: int, totals: engine.CountsCSR,
     dot = ctx.empty(max(2 * rows, 1), np.int64)
     ctx.call("skm_apply_top2", _i64(csr.n), _p(csr.rowptr.ptr), _p(csr.colidx.ptr), _p(csr.counts.ptr), _p(xsq.ptr),
              _i64(m), _i64(ncols), _p(colptr.ptr), _p(post.ptr), _p(ysq.ptr), _i64(row0), _i64(row1),
-             _p(idx.ptr), _p(score.ptr), _p(dot.ptr))
+             _p(d_order.ptr if d_order is not None else None), _p(idx.ptr), _p(score.ptr), _p(dot.ptr))
     return (idx.download(2 * rows).reshape(rows, 2), score.download(2 * rows).reshape(rows, 2),
             dot.download(2 * rows).reshape(rows, 2))
 
@@ -161,7 +170,8 @@ def learn_apply(ctx, csr: engine.CountsCSR, ncols: int, groups: Sequence[int], n
     The N x A score block is only produced when `materialize` is set (the save_apply_associations
     branch of apply.smk:298-301 writes it out)."""
     totals = group_sum(ctx, csr, groups, ngroups, basis=basis, ncols=ncols)
-    idx, score, dot = apply_top2(ctx, csr, ncols, totals)
+    # rows of one annotation next to each other: they share their family's k-mers (see apply_top2)
+    idx, score, dot = apply_top2(ctx, csr, ncols, totals, order=np.argsort(np.asarray(groups), kind="stable"))
     out = {"totals": totals, "top2_index": idx, "top2_score": score, "top2_dot": dot,
            "delta": np.round(score[:, 0] - score[:, 1], 2)}
     if materialize:

@@ -184,6 +184,7 @@ __global__ __launch_bounds__(ATB) void k_apply_top2(const int64_t *__restrict__ 
                                                     const ulonglong2 *__restrict__ ydesc,
                                                     const uint64_t *__restrict__ ypost,
                                                     const double *__restrict__ ynorm, int64_t row0, int64_t nrows,
+                                                    const uint32_t *__restrict__ row_order,
                                                     uint32_t *__restrict__ over_list, uint32_t *__restrict__ over_count,
                                                     uint32_t *__restrict__ out_idx,
                                                     double *__restrict__ out_score, long long *__restrict__ out_dot)
@@ -220,8 +221,15 @@ __global__ __launch_bounds__(ATB) void k_apply_top2(const int64_t *__restrict__ 
             h = (h + 1) & (AHS - 1);
         }
     };
-    const int64_t wave = (int64_t)blockIdx.x * NW + wid, nwaves = (int64_t)gridDim.x * NW;
-    for (int64_t r = wave; r < nrows; r += nwaves) {
+    // Position p of the launch is row row_order[p] (or p).  Every XCD (workgroups go to the eight XCDs round-robin) owns
+    // one contiguous eighth of the positions and its resident waves walk it side by side: with an order that puts
+    // similar rows next to each other - the caller's labels, the records of one FASTA file - the rows in flight on an
+    // XCD read the same columns' words and find them in that XCD's L2.
+    const int64_t xcd = blockIdx.x & 7, wg_in = blockIdx.x >> 3;
+    const int64_t wgs_here = ((int64_t)gridDim.x + 7 - xcd) >> 3;  // workgroups of this launch on this XCD
+    const int64_t share = (nrows + 7) >> 3, pos_end = min(nrows, (xcd + 1) * share);
+    for (int64_t pos = xcd * share + wg_in * NW + wid; pos < pos_end; pos += wgs_here * NW) {
+        const int64_t r = row_order ? (int64_t)row_order[pos] : pos;
         const int64_t i = row0 + r;
         const int64_t b = xrowptr[i], e = xrowptr[i + 1];
         // four entries per lane and step: the coalesced loads, then the four gathers, are issued together
@@ -260,13 +268,22 @@ __global__ __launch_bounds__(ATB) void k_apply_top2(const int64_t *__restrict__ 
         const uint64_t nx = xnormsq[i];
         const double sx = nx ? sqrt((double)nx) : 1.0;
         top2 t = {-INFINITY, -INFINITY, 0, 0, NONE, NONE};
-        for (int z = 0; z < AHS / 64; ++z) {  // the table's entries (and the table cleared for the next row)
-            const int slot = z * 64 + lane;
-            const uint32_t fam = keys[slot];
-            if (fam != NONE) {
+        // the table's entries (and the table cleared for the next row): all keys first, then all norm gathers together
+        uint32_t fk[AHS / 64];
+        double fn[AHS / 64];
+#pragma unroll
+        for (int z = 0; z < AHS / 64; ++z)
+            fk[z] = keys[z * 64 + lane];
+#pragma unroll
+        for (int z = 0; z < AHS / 64; ++z)
+            fn[z] = (fk[z] != NONE && distinct <= (uint32_t)AHCAP) ? ynorm[fk[z]] : 1.0;
+#pragma unroll
+        for (int z = 0; z < AHS / 64; ++z) {
+            if (fk[z] != NONE) {
+                const int slot = z * 64 + lane;
                 const long long d = (long long)vals[slot];
                 if (distinct <= (uint32_t)AHCAP)
-                    top2_push(t, (double)d / (sx * ynorm[fam]), fam, d);
+                    top2_push(t, (double)d / (sx * fn[z]), fk[z], d);
                 keys[slot] = NONE;
                 vals[slot] = 0ull;
             }
@@ -483,7 +500,7 @@ extern "C" int skm_matrix_row_stats(skm_ctx *ctx, int64_t n, int64_t m, const fl
 extern "C" int skm_apply_top2(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const uint32_t *d_xcolidx,
                               const uint32_t *d_xcounts, const uint64_t *d_xnormsq, int64_t m, int64_t ncols,
                               const uint32_t *d_ycolptr, const uint64_t *d_ypost, const uint64_t *d_ynormsq, int64_t row0,
-                              int64_t row1, uint32_t *d_idx, double *d_score, int64_t *d_dot)
+                              int64_t row1, const uint32_t *d_row_order, uint32_t *d_idx, double *d_score, int64_t *d_dot)
 {
     SKM_REQUIRE(ctx && n >= 0 && m >= 0 && ncols >= 0, SKM_E_BADARG, "skm_apply_top2: bad argument");
     SKM_REQUIRE(row0 >= 0 && row0 <= row1 && row1 <= n, SKM_E_BADARG, "skm_apply_top2: bad row range");
@@ -516,7 +533,7 @@ extern "C" int skm_apply_top2(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr,
         // (with no column or no family every entry is skipped: xcolidx may then only hold 0xFFFFFFFF)
         SKM_PROF(ctx, "k_apply_top2");
         k_apply_top2<<<skm_grid_cap(ctx, skm_ceil_div(nrows, ATB / 64), 16), ATB, 0, ctx->stream>>>(
-            d_xrowptr, d_xcolidx, d_xcounts, d_xnormsq, m, (ncols && m) ? desc : nullptr, d_ypost, ynorm, row0, nrows, over_list,
+            d_xrowptr, d_xcolidx, d_xcounts, d_xnormsq, m, (ncols && m) ? desc : nullptr, d_ypost, ynorm, row0, nrows, d_row_order, over_list,
             over_count, d_idx, d_score, (long long *)d_dot);
         SKM_TRY(skm_check_launch("k_apply_top2"));
     }

@@ -2688,12 +2688,19 @@ def test_apply_top2_wave_per_row_equals_numpy_and_the_dense_form(ctx):
     xs[xs == 0] = 1.0
     ts[ts == 0] = 1.0
     S = np.where(G != 0, G / (xs[:, None] * ts[None, :]), 0.0)
-    order = np.argsort(-S, axis=1, kind="stable")[:, :2]
+    order = order_ref = np.argsort(-S, axis=1, kind="stable")[:, :2]
     for tot in (totals, totals.columns):
         idx, score, dot = skm_apply.apply_top2(ctx, x, K, tot)
         assert (idx == order).all()
         assert (dot == np.take_along_axis(G, order, axis=1)).all()
         assert (score == np.take_along_axis(S, order, axis=1)).all()
+    # a processing order (rows of one family next to each other, or any permutation) changes nothing but the cache behaviour
+    for perm in (np.argsort(member, kind="stable"), rng.permutation(len(member))):
+        idx, score, dot = skm_apply.apply_top2(ctx, x, K, totals, order=perm)
+        assert (idx == order_ref).all() and (dot == np.take_along_axis(G, order_ref, axis=1)).all()
+        assert (score == np.take_along_axis(S, order_ref, axis=1)).all()
+    with pytest.raises(ValueError):
+        skm_apply.apply_top2(ctx, x, K, totals, order=np.zeros(len(member), dtype=np.uint32))
     plain = _dev_csr(ctx, sp.csr_matrix(T))  # no `columns`: transposed inside, as before
     idx, score, dot = skm_apply.apply_top2(ctx, x, K, plain)
     assert (idx == order).all() and (dot == np.take_along_axis(G, order, axis=1)).all()
