@@ -225,9 +225,10 @@ __global__ __launch_bounds__(ATB) void k_apply_top2(const int64_t *__restrict__ 
     // one contiguous eighth of the positions and its resident waves walk it side by side: with an order that puts
     // similar rows next to each other - the caller's labels, the records of one FASTA file - the rows in flight on an
     // XCD read the same columns' words and find them in that XCD's L2.
-    const int64_t xcd = blockIdx.x & 7, wg_in = blockIdx.x >> 3;
-    const int64_t wgs_here = ((int64_t)gridDim.x + 7 - xcd) >> 3;  // workgroups of this launch on this XCD
-    const int64_t share = (nrows + 7) >> 3, pos_end = min(nrows, (xcd + 1) * share);
+    const int64_t nx = gridDim.x >= 8 ? 8 : (int64_t)gridDim.x;  // (a launch of fewer than 8 workgroups: one share per workgroup)
+    const int64_t xcd = blockIdx.x % nx, wg_in = blockIdx.x / nx;
+    const int64_t wgs_here = ((int64_t)gridDim.x + nx - 1 - xcd) / nx;  // workgroups of this launch on this XCD
+    const int64_t share = (nrows + nx - 1) / nx, pos_end = min(nrows, (xcd + 1) * share);
     for (int64_t pos = xcd * share + wg_in * NW + wid; pos < pos_end; pos += wgs_here * NW) {
         const int64_t r = row_order ? (int64_t)row_order[pos] : pos;
         const int64_t i = row0 + r;
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(ATB) void k_apply_top2(const int64_t *__restrict__ 
         }
         __threadfence_block();
         const uint32_t distinct = __atomic_load_n(&s_distinct[wid], __ATOMIC_RELAXED);  // wave-uniform
-        const uint64_t nx = xnormsq[i];
-        const double sx = nx ? sqrt((double)nx) : 1.0;
+        const uint64_t nsq = xnormsq[i];
+        const double sx = nsq ? sqrt((double)nsq) : 1.0;
         top2 t = {-INFINITY, -INFINITY, 0, 0, NONE, NONE};
         // the table's entries (and the table cleared for the next row): all keys first, then all norm gathers together
         uint32_t fk[AHS / 64];

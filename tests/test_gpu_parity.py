@@ -2704,3 +2704,28 @@ def test_apply_top2_wave_per_row_equals_numpy_and_the_dense_form(ctx):
     plain = _dev_csr(ctx, sp.csr_matrix(T))  # no `columns`: transposed inside, as before
     idx, score, dot = skm_apply.apply_top2(ctx, x, K, plain)
     assert (idx == order).all() and (dot == np.take_along_axis(G, order, axis=1)).all()
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 13, 24, 33, 100])
+def test_apply_top2_every_row_of_a_small_batch_is_written(ctx, n):
+    """Launches of fewer workgroups than XCDs (a FASTA file of a few records, rules/apply.smk:188-206): every row gets its
+    two columns (the fuzz found rows left unwritten when the rows were first dealt to the eight XCDs)."""
+    import scipy.sparse as sp
+
+    from snekmer_amd import apply as skm_apply
+
+    rng = np.random.default_rng(n)
+    K, A_ = 50, 4
+    X = sp.random(n, K, density=0.3, random_state=n, data_rvs=lambda s: rng.integers(1, 5, size=s)).tocsr().astype(np.int64)
+    T = sp.random(A_, K, density=0.5, random_state=n + 1, data_rvs=lambda s: rng.integers(1, 50, size=s)).tocsr().astype(np.int64)
+    x, t = _dev_csr(ctx, X), _dev_csr(ctx, T)
+    idx, score, dot = skm_apply.apply_top2(ctx, x, K, t)
+    G = (X @ T.T).toarray().astype(np.int64)
+    xs = np.sqrt(np.asarray(X.multiply(X).sum(axis=1)).ravel().astype(np.float64))
+    ts = np.sqrt(np.asarray(T.multiply(T).sum(axis=1)).ravel().astype(np.float64))
+    xs[xs == 0] = 1.0
+    ts[ts == 0] = 1.0
+    S = np.where(G != 0, G / (xs[:, None] * ts[None, :]), 0.0)
+    order = np.argsort(-S, axis=1, kind="stable")[:, :2]
+    assert (idx == order).all() and (dot == np.take_along_axis(G, order, axis=1)).all()
+    assert (score == np.take_along_axis(S, order, axis=1)).all()
