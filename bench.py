@@ -1120,7 +1120,7 @@ def config4_one_rank_share(ctx, engine, alphabet, args):
     for names, nbytes, what in (
             (("k_gram_sparse", "k_gram_sparse_big", "k_gram_sparse_huge"), block_pairs * 8,
              "every (row, posting) pair of the 125 k-row block reads one 8-byte posting: 1/8 of the sum over shared columns of df^2"),
-            (("k_neighbors_topk", "k_neighbors_topk_lds"), int(entries) * 8 + block * 10 * 8,
+            (("k_neighbors_topk", "k_neighbors_topk_lds", "k_neighbors_topk_stream"), int(entries) * 8 + block * 10 * 8,
              "8 B per list entry read + 10 x 8 B (index, score) written per row"),
             (("k_basis_scatter", "k_basis_scatter_fused"), nnz * (code_b + 4) + shared * 20 + b.ncols * (code_b + 4),
              "1 M rows: sorted keys / indices read; per shared entry: posting word gathered, colidx + posting written; per column: code + start")):

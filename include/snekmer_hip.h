@@ -417,9 +417,11 @@ int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const 
 
 /* k best cosine neighbours per row from the lists of skm_gram_neighbors: score = dot * xrnorm[row0+r]
  * * yrnorm[j], descending, ties towards the lower j; exclude_self drops j == row0 + r.
- * d_idx / d_val are [nrows x k]; missing slots hold 0xFFFFFFFF / 0. */
+ * d_idx / d_val are [nrows x k]; missing slots hold 0xFFFFFFFF / 0.  m = number of rows of Y (entries of d_yrnorm;
+ * non-negative values): lets the k <= 16 kernel bound an entry's score by dot * xrnorm * max_j yrnorm and skip the gather of
+ * its neighbour's norm when the bound is below what 64 entries already reach; m <= 0: every norm is gathered. */
 int skm_neighbors_topk(skm_ctx *ctx, int64_t nrows, int64_t row0, const uint64_t *d_start, const uint32_t *d_len,
-                       const uint64_t *d_ent, const float *d_xrnorm, const float *d_yrnorm, int k, int exclude_self,
+                       const uint64_t *d_ent, const float *d_xrnorm, const float *d_yrnorm, int64_t m, int k, int exclude_self,
                        uint32_t *d_idx, float *d_val);
 
 /* Exact sum over columns of df*(df) pairs the sparse kernel will visit (cost model input). */

@@ -130,7 +130,7 @@ _SIGNATURES = {
     "skm_group_postings": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, C.POINTER(_i64)]),
     "skm_postings_to_csr": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _p, _p, _p]),
     "skm_gram_neighbors": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _p, _p, C.c_int, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)]),
-    "skm_neighbors_topk": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p, _p]),
+    "skm_neighbors_topk": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _i64, C.c_int, C.c_int, _p, _p]),
     "skm_jaccard_distance_from_gram": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64]),
     "skm_pair_work": (C.c_int, [_p, _i64, _p, C.POINTER(C.c_uint64)]),
     "skm_count_dense": (C.c_int, [_p, _p, C.c_int, C.c_int, _p, _p, _i64, C.c_int, _p, _i64]),

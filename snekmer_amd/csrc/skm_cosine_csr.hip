@@ -1022,7 +1022,146 @@ __global__ __launch_bounds__(256) void k_neighbors_topk(int64_t nrows, int64_t r
     }
 }
 
-// Rows whose list fits LDS (at most TOPK_CAP entries: nearly all): workgroup per row.  Scores are
+// k <= TOPK_KREG (the top-10 of BASELINE configs[3]): WAVE per row, ONE pass over the list whatever its length.  Every lane
+// keeps the TOPK_KREG best of the entries it has seen, sorted, in registers (the list is read once, coalesced, four loads
+// and four norm gathers in flight); the k results are then k rounds of a wave-wide arg-max over the lanes' current heads,
+// the winner popping its own.  No LDS, no barrier, eight rows per SIMD in flight.  (Until round 6 every row went through
+// the workgroup-per-row kernel below - 64 KiB of LDS, two rows per CU, two barriers and a full scan of the cached list per
+// result: 14 ms for the 125 k rows x 3264 neighbours of one rank's share of BASELINE configs[3].)  Order and arithmetic are
+// the other kernels': (score desc, j asc), score = (float)dot * xr[i] * yr[j].
+constexpr int TOPK_KREG = 16;
+
+// max_j yr[j] (non-negative floats: their bit patterns order like unsigned integers)
+__global__ __launch_bounds__(256) void k_max_f32(int64_t m, const float *__restrict__ yr, uint32_t *__restrict__ out)
+{
+    float mx = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += stride)
+        mx = fmaxf(mx, yr[j]);
+    for (int o = 32; o > 0; o >>= 1)
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(out, __float_as_uint(mx));
+}
+
+template <int KR>
+__global__ __launch_bounds__(256) void k_neighbors_topk_stream(int64_t nrows, int64_t row0, const uint64_t *__restrict__ g_start,
+                                                               const uint32_t *__restrict__ g_len,
+                                                               const uint64_t *__restrict__ g_ent,
+                                                               const float *__restrict__ xr, const float *__restrict__ yr,
+                                                               const float *__restrict__ yr_max, int k, int exclude_self,
+                                                               uint32_t *__restrict__ idx, float *__restrict__ val)
+{
+    constexpr int UNR = 4;
+    const float rmax = *yr_max;  // max_j yr[j]: dot * xr[i] * rmax bounds an entry's score before its norm is gathered
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < nrows; r += nwaves) {
+        const uint32_t raw = g_len[r];
+        const uint32_t len = raw == G_OVERFLOW ? 0u : raw;  // (a row the list kernels could not hold: no neighbours reported)
+        const uint64_t st = g_start[r];
+        const float ri = xr[row0 + r];
+        const uint32_t self = (uint32_t)(row0 + r);
+        float tv[KR];
+        uint32_t tj[KR];
+#pragma unroll
+        for (int q = 0; q < KR; ++q) {
+            tv[q] = -INFINITY;
+            tj[q] = 0xFFFFFFFFu;
+        }
+        // thr: the smallest of the 64 lanes' best scores so far.  64 >= k entries are at least that good, so an entry whose
+        // UPPER BOUND dot * xr[i] * max_j yr[j] is below it is in nobody's top k and its neighbour's norm is not even
+        // gathered: the kernel is bound by those random 4-byte gathers (one per entry: 4.5 ms for 4.1e8 entries), and
+        // behind the first few hundred entries of a row nearly every chance neighbour is dropped by this compare
+        float thr = -INFINITY;
+        for (uint32_t e0 = 0; e0 < len; e0 += 64 * UNR) {  // wave-uniform trip count
+            uint64_t w[UNR];
+            float rj[UNR];
+            bool need[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const uint32_t e = e0 + (uint32_t)(u * 64 + lane);
+                w[u] = __builtin_nontemporal_load(&g_ent[st + (e < len ? e : 0u)]);  // (streamed once)
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const uint32_t e = e0 + (uint32_t)(u * 64 + lane);
+                const uint32_t j = (uint32_t)(w[u] >> 32);
+                need[u] = e < len && !(exclude_self && j == self) && (float)(int)(uint32_t)w[u] * ri * rmax >= thr;
+                rj[u] = yr[need[u] ? j : 0u];  // (no branch around the load: the four gathers stay in flight together; a
+                                               // dropped entry reads norm 0, a line every lane shares)
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (!need[u])
+                    continue;
+                const uint32_t j = (uint32_t)(w[u] >> 32);
+                const float v = (float)(int)(uint32_t)w[u] * ri * rj[u];
+                if (v < thr || !(v > tv[KR - 1] || (v == tv[KR - 1] && j < tj[KR - 1])))
+                    continue;
+                // sorted insertion: every slot takes the better of (its left neighbour, the newcomer) once the newcomer
+                // beats the slot itself
+                float cv = v;
+                uint32_t cj = j;
+#pragma unroll
+                for (int q = 0; q < KR; ++q) {
+                    const bool ahead = cv > tv[q] || (cv == tv[q] && cj < tj[q]);
+                    if (ahead) {
+                        const float ov = tv[q];
+                        const uint32_t oj = tj[q];
+                        tv[q] = cv;
+                        tj[q] = cj;
+                        cv = ov;
+                        cj = oj;
+                    }
+                }
+            }
+            thr = tv[0];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                thr = fminf(thr, __shfl_xor(thr, o));
+        }
+        for (int t = 0; t < k; ++t) {
+            float rv = tv[0];
+            uint32_t rj2 = tj[0];
+            int rl = lane;
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(rv, o);
+                const uint32_t oj = __shfl_xor(rj2, o);
+                const int ol = __shfl_xor(rl, o);
+                if (ov > rv || (ov == rv && oj < rj2)) {
+                    rv = ov;
+                    rj2 = oj;
+                    rl = ol;
+                }
+            }
+            const bool none = rj2 == 0xFFFFFFFFu;  // fewer than k neighbours: the rest stays empty
+            if (lane == 0) {
+                idx[r * k + t] = rj2;
+                val[r * k + t] = none ? 0.0f : rv;
+            }
+            if (none) {
+                for (int u = t + 1 + lane; u < k; u += 64) {
+                    idx[r * k + u] = 0xFFFFFFFFu;
+                    val[r * k + u] = 0.0f;
+                }
+                break;
+            }
+            if (lane == rl) {  // the winner pops its head
+#pragma unroll
+                for (int q = 0; q + 1 < KR; ++q) {
+                    tv[q] = tv[q + 1];
+                    tj[q] = tj[q + 1];
+                }
+                tv[KR - 1] = -INFINITY;
+                tj[KR - 1] = 0xFFFFFFFFu;
+            }
+        }
+    }
+}
+
+// k > TOPK_KREG.  Rows whose list fits LDS (fewer than TOPK_CAP entries): workgroup per row.  Scores are
 // computed once (one gather of the neighbour's norm per entry) and cached with their row numbers;
 // each of the k rounds is then an arg-max over LDS in (score desc, j asc) order that retires its
 // pick.  The wave-per-row kernel above re-reads the list and the norms in every round.
@@ -1032,8 +1171,8 @@ __global__ __launch_bounds__(256) void k_neighbors_topk_lds(int64_t nrows, int64
                                                             const uint32_t *__restrict__ g_len,
                                                             const uint64_t *__restrict__ g_ent,
                                                             const float *__restrict__ xr, const float *__restrict__ yr,
-                                                            int k, int exclude_self, uint32_t *__restrict__ idx,
-                                                            float *__restrict__ val)
+                                                            int k, int exclude_self, uint32_t min_len,
+                                                            uint32_t *__restrict__ idx, float *__restrict__ val)
 {
     __shared__ float s_v[TOPK_CAP];
     __shared__ uint32_t s_j[TOPK_CAP];
@@ -1042,7 +1181,7 @@ __global__ __launch_bounds__(256) void k_neighbors_topk_lds(int64_t nrows, int64
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
         const uint32_t len = g_len[r];
-        if (len == G_OVERFLOW || len == 0u || len >= (uint32_t)TOPK_CAP)
+        if (len == G_OVERFLOW || len < min_len || len >= (uint32_t)TOPK_CAP)
             continue;  // uniform for the workgroup
         const uint64_t st = g_start[r];
         const float ri = xr[row0 + r];
@@ -1334,7 +1473,7 @@ extern "C" int skm_gram_neighbors(skm_ctx *ctx, int64_t n, const int64_t *d_xrow
 }
 
 extern "C" int skm_neighbors_topk(skm_ctx *ctx, int64_t nrows, int64_t row0, const uint64_t *d_start, const uint32_t *d_len,
-                                  const uint64_t *d_ent, const float *d_xrnorm, const float *d_yrnorm, int k,
+                                  const uint64_t *d_ent, const float *d_xrnorm, const float *d_yrnorm, int64_t m, int k,
                                   int exclude_self, uint32_t *d_idx, float *d_val)
 {
     SKM_REQUIRE(ctx && nrows >= 0 && row0 >= 0 && k >= 1 && k <= 1024, SKM_E_BADARG, "skm_neighbors_topk: bad argument");
@@ -1342,11 +1481,42 @@ extern "C" int skm_neighbors_topk(skm_ctx *ctx, int64_t nrows, int64_t row0, con
         return SKM_OK;
     SKM_REQUIRE(d_start && d_len && d_xrnorm && d_yrnorm && d_idx && d_val, SKM_E_BADARG, "skm_neighbors_topk: null array");
     SKM_HIP(hipSetDevice(ctx->device));
+    if (k <= TOPK_KREG) {  // one pass per row, the lanes' best in registers
+        // max_j yrnorm[j] for the bound that spares the gather of hopeless entries' norms (m <= 0: the caller did not say
+        // how many norms there are: +infinity, every norm is gathered)
+        void *p;
+        SKM_TRY(skm_ws(ctx, WS_SMALL, 4096, &p));
+        uint32_t *rmax = (uint32_t *)((uint8_t *)p + 3072);
+        if (m > 0) {
+            SKM_HIP(hipMemsetAsync(rmax, 0, 4, ctx->stream));
+            k_max_f32<<<skm_grid_cap(ctx, skm_ceil_div(m, 256 * 8), 4), 256, 0, ctx->stream>>>(m, d_yrnorm, rmax);
+            SKM_TRY(skm_check_launch("k_max_f32"));
+        } else {
+            const uint32_t inf_bits = 0x7F800000u;
+            SKM_HIP(hipMemcpyAsync(rmax, &inf_bits, 4, hipMemcpyHostToDevice, ctx->stream));
+            SKM_HIP(hipStreamSynchronize(ctx->stream));  // (the source is on this function's stack)
+        }
+        SKM_PROF(ctx, "k_neighbors_topk_stream");
+        const int grid = skm_grid_cap(ctx, skm_ceil_div(nrows, 4), 32);
+#define SKM_TOPK_STREAM(KR)                                                                                                   \
+    k_neighbors_topk_stream<KR><<<grid, 256, 0, ctx->stream>>>(nrows, row0, d_start, d_len, d_ent, d_xrnorm, d_yrnorm,        \
+                                                               (const float *)rmax, k, exclude_self, d_idx, d_val)
+        if (k <= 4)  // (the lanes keep KR >= k candidates each: fewer registers and a shorter insertion for a small k)
+            SKM_TOPK_STREAM(4);
+        else if (k <= 8)
+            SKM_TOPK_STREAM(8);
+        else if (k <= 12)
+            SKM_TOPK_STREAM(12);
+        else
+            SKM_TOPK_STREAM(16);
+#undef SKM_TOPK_STREAM
+        return skm_check_launch("k_neighbors_topk_stream");
+    }
     {
         // lists that fit LDS: scores cached once
         SKM_PROF(ctx, "k_neighbors_topk_lds");
         k_neighbors_topk_lds<<<skm_grid_cap(ctx, nrows, 8), 256, 0, ctx->stream>>>(nrows, row0, d_start, d_len, d_ent, d_xrnorm,
-                                                                                  d_yrnorm, k, exclude_self, d_idx, d_val);
+                                                                                  d_yrnorm, k, exclude_self, 1u, d_idx, d_val);
     }
     SKM_TRY(skm_check_launch("k_neighbors_topk_lds"));
     SKM_PROF(ctx, "k_neighbors_topk");  // longer lists, empty and flagged rows

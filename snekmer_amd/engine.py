@@ -587,8 +587,8 @@ def cosine_dense_i8(ctx, n: int, m: int, kdim: int, x_i8, y_i8, x_rnorm, y_rnorm
 class NeighborLists:
     """Exact sparse Gram rows of a row block: per row the rows j sharing a k-mer and the int32 dot."""
 
-    def __init__(self, ctx, row0, row1, start, length, ent, total, overflow_rows):
-        self.ctx, self.row0, self.row1 = ctx, row0, row1
+    def __init__(self, ctx, row0, row1, start, length, ent, total, overflow_rows, m=0):
+        self.ctx, self.row0, self.row1, self.m = ctx, row0, row1, m  # m: rows of Y (the neighbours' numbering)
         self.start, self.length, self.ent = start, length, ent
         self.total, self.overflow_rows = total, overflow_rows
 
@@ -617,7 +617,7 @@ def gram_neighbors(ctx, x: CountsCSR, x_rnorm, m: int, ncols: int, colptr, post,
     ctx.call("skm_gram_neighbors", _i64(x.n), _ptr(x.rowptr), _ptr(x.colidx), _ptr(x.counts), _i64(m), _i64(ncols),
              _ptr(colptr), _ptr(post), post_bits, _ptr(postcnt), _ptr(x_rnorm), _ptr(y_rnorm), _i64(row0), _i64(row1), _i64(cap),
              _ptr(start), _ptr(length), _ptr(ent), C.byref(total), C.byref(ovf))
-    return NeighborLists(ctx, row0, row1, start, length, ent, int(total.value), int(ovf.value))
+    return NeighborLists(ctx, row0, row1, start, length, ent, int(total.value), int(ovf.value), m=m)
 
 
 def neighbors_topk(ctx, nb: NeighborLists, x_rnorm, y_rnorm, k: int, exclude_self: bool = True):
@@ -626,7 +626,7 @@ def neighbors_topk(ctx, nb: NeighborLists, x_rnorm, y_rnorm, k: int, exclude_sel
     idx = ctx.empty(max(nrows * k, 1), np.uint32)
     val = ctx.empty(max(nrows * k, 1), np.float32)
     ctx.call("skm_neighbors_topk", _i64(nrows), _i64(nb.row0), _ptr(nb.start), _ptr(nb.length), _ptr(nb.ent),
-             _ptr(x_rnorm), _ptr(y_rnorm), k, 1 if exclude_self else 0, _ptr(idx), _ptr(val))
+             _ptr(x_rnorm), _ptr(y_rnorm), _i64(getattr(nb, "m", 0)), k, 1 if exclude_self else 0, _ptr(idx), _ptr(val))
     return idx.download(nrows * k).reshape(nrows, k), val.download(nrows * k).reshape(nrows, k)
 
 

@@ -1995,6 +1995,14 @@ def test_gram_neighbors_and_topk_vs_oracle(ctx):
         gram = ref[r, js] * norms[lo + r] * norms[js]
         assert np.abs(ds - np.rint(gram)).max() == 0
     assert nb.overflow_rows == 0 and held == hi - lo  # incl. the 9k/20k-window sequences (global-table pass)
+    # k <= 16 takes the one-pass wave kernel (the lanes' best in registers), larger k the LDS / re-scanning kernels: the same
+    # order and the same float expression, so the first 16 of a top-40 ARE the top-16, bit for bit, with and without self
+    for excl in (True, False):
+        i16, v16 = engine.neighbors_topk(ctx, nb, pipe.rnorm, pipe.rnorm, 16, exclude_self=excl)
+        i40, v40 = engine.neighbors_topk(ctx, nb, pipe.rnorm, pipe.rnorm, 40, exclude_self=excl)
+        assert (i16 == i40[:, :16]).all() and (v16 == v40[:, :16]).all()
+        i1, v1 = engine.neighbors_topk(ctx, nb, pipe.rnorm, pipe.rnorm, 1, exclude_self=excl)
+        assert (i1[:, 0] == i40[:, 0]).all() and (v1[:, 0] == v40[:, 0]).all()
     kk = 7
     idx, val = engine.neighbors_topk(ctx, nb, pipe.rnorm, pipe.rnorm, kk, exclude_self=True)
     for r in range(0, hi - lo, 13):
