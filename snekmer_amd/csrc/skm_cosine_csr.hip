@@ -1409,19 +1409,12 @@ int gram_neighbors_impl(skm_ctx *ctx, int64_t n, const int64_t *d_xrowptr, const
     const unsigned long long cap = (unsigned long long)cap_ent;
     {
         // rows whose dot products may not fit the 32-bit entries (skm_row_is_wide) are marked G_OVERFLOW at once.
-        // Against half a million rows or more (BASELINE configs[3]: 1 M) a row's CHANCE neighbours - k-mers shared with
-        // unrelated sequences - outnumber its family (3264 neighbours per row at 1 M x 300 aa, red6 k=12): the 2048-slot
-        // tables (1536 neighbours) then fail for nearly every row after half of its walk, so the first pass takes
-        // 4096-slot tables there (3072 neighbours, three workgroups per CU instead of six).
+        // (Round 6 measured 4096-slot tables for this pass against >= 2^19 rows - BASELINE configs[3], 3264 neighbours per
+        // row -: first pass 10.8 -> 16.0 ms, second 25.5 -> 19.2, i.e. 38.7 -> 37.3 ms for a rank's 125 k rows: not kept.)
         SKM_PROF(ctx, "k_gram_sparse");
-        if (m >= ((int64_t)1 << 19))
-            k_gram_sparse<0, 1, 4096, 256, 2, 32, 2, PW><<<(unsigned)nrows, 256, 0, st>>>(
-                d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0, row1, 0ull, 0, d_ent, cap, g_counter, d_start,
-                d_len, list1, cnt1, d_xrnorm, &state->min_yrnorm, G_OVERFLOW);
-        else
-            k_gram_sparse<0, 1, 2048, 256, 2, 32, 2, PW><<<(unsigned)nrows, 256, 0, st>>>(
-                d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0, row1, 0ull, 0, d_ent, cap, g_counter, d_start,
-                d_len, list1, cnt1, d_xrnorm, &state->min_yrnorm, G_OVERFLOW);
+        k_gram_sparse<0, 1, 2048, 256, 2, 32, 2, PW><<<(unsigned)nrows, 256, 0, st>>>(
+            d_xrowptr, d_xcolidx, d_xcounts, d_ycolptr, d_ypost, d_ypostcnt, row0, row1, 0ull, 0, d_ent, cap, g_counter, d_start,
+            d_len, list1, cnt1, d_xrnorm, &state->min_yrnorm, G_OVERFLOW);
     }
     SKM_TRY(skm_check_launch("k_gram_sparse"));
     {
