@@ -1052,7 +1052,8 @@ int skm_basis_stage_async(skm_ctx *ctx, int code_bits, int key_bits, int64_t cap
     }
     {
         SKM_PROF(ctx, "k_head_count");
-        if (nblocks <= 4096) {  // small inputs: the scan over the blocks rides on the last workgroup of the count (one launch less)
+        if (nblocks <= 256) {  // small inputs (<= 0.5 M entries): the scan over the blocks rides on the last workgroup of the count:
+                               // one launch less; above, the blocks' same-address ticket atomics (~5 ns each) cost more than the launch
             SKM_TRY(skm_ws(ctx, WS_ZERO, 256, &p));
             uint32_t *ticket = (uint32_t *)p + 32;  // (words 0-6: the count stage's size-class counters; zero between launches)
             if (code_bits == 32)
