@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512) void k_cosine_dense_i8_v4(int64_t n, int64_t m
 
 // ------------------------------------------------------------------------------- i8 MFMA cosine, v5
 // v4 stages both operands through LDS, and its LDS-DMA issue (60-185 cycles per instruction, four per wave and stage)
-// and fragment reads leave the matrix pipe idle 45 % of the time (section 5.2 of DESIGN.md).  Here only A goes
+// and fragment reads leave the matrix pipe idle 45 % of the time (section 5.2 of profiles/HISTORY.md).  Here only A goes
 // through LDS.  The eight waves sit side by side (1 x 8): wave w owns all 256 rows x columns [32 w, 32 w + 32) of the
 // tile, so
 //   A (256 rows x 64 B per stage) goes through LDS (two LDS-DMA instructions per wave per stage, a ring of eight

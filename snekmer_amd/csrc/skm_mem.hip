@@ -1,7 +1,7 @@
 // Device memory, streams, events and pinned words of libsnekmer_hip.so: everything the HIP runtime hands out is taken
 // ONCE and recycled here.
 //
-// Why ("the intermittent stop"): until round 5 every skm_malloc was a hipMalloc and every skm_free a hipFree, a
+// Why ("The stop"): until round 5 every skm_malloc was a hipMalloc and every skm_free a hipFree, a
 // scratch slot that grew was hipFree'd, and every side context of engine.OverlappedPipeline created and destroyed a
 // CU-masked stream (a hardware queue of its own), a pinned page and a handful of events.  hipFree waits, implicitly, for
 // every stream of the device; callers (score._set_measure) let arrays go while the kernels reading them were still
