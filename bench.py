@@ -471,7 +471,7 @@ def main():
     barrier()
     # the side contexts time the vectorize stages of the next batch, the Gram of its last rows and (their scratch holds those
     # lists) the writer launches for those rows
-    prof_ctxs = [ctx] + (list(dict.fromkeys(op.sides)) if op is not None else [])
+    prof_ctxs = [ctx] + (op.contexts() if op is not None else [])
     for c in prof_ctxs:
         c.profile_enable(True)
         c.profile_reset()
@@ -531,10 +531,8 @@ def main():
             lat.append((time.perf_counter() - t1) * 1e3)
         stream_info["host_to_result_ms"] = min(lat)
         op.out = None
-        sides = list(dict.fromkeys(op.sides))
+        op.close()  # (the side contexts' streams go back to the library's cache: skm_mem.hip)
         op = prof_ctxs = None
-        for side in sides:
-            side.close()  # (their streams go back to the library's cache: skm_mem.hip)
         uploader.close()
         batch = engine.SeqBatch(ctx, res, off)  # the extras below run on the first batch, resident
 

@@ -983,6 +983,7 @@ class OverlappedPipeline:
             self.sides = [first] + [_hip.Context(ctx.device, cu_groups=first.cu_groups) if first.cu_groups else _hip.Context(ctx.device)
                                     for _ in range(nsets - 1)]
         self.side = first
+        self._owned = [c for c in dict.fromkeys(self.sides) if c is not side_ctx]
         self.sets = [[None, None, None] for _ in range(nsets)]  # (csr, basis, rnorm) per buffer set
         self.queue = []     # sets holding a vectorized batch that has not been consumed yet, oldest first
         self.nxt = 0
@@ -1047,6 +1048,9 @@ class OverlappedPipeline:
             self.out = None
             self.out = self.ctx.empty((max(n, 1), max(ld, 1)), np.float32)
         r = self._split_row(n)
+        # (Round 6 measured the lists of rows [0, r) on a THIRD context, so that the main stream carries the two writer
+        # launches only: 10.6 / 11.4 / 12.0 ms per step with that context on CU groups 4-7 / 0-3 / 4-5 against 9.45 without
+        # it - a third latency-bound stream slows the writer and the side stream more than it hides: not kept.)
         if r > 0 or n == 0:
             self._block(self.ctx, s, 0, r, 0, self.out.ptr, ld)
         if r < n:
@@ -1056,7 +1060,19 @@ class OverlappedPipeline:
             self.prefetch(next_batch)
         return self.out
 
+    def contexts(self):
+        """Every context besides the main one that carries work of this pipeline (for per-kernel timing, waiting, closing)."""
+        return list(dict.fromkeys(self.sides))
+
     def sync(self):
-        for c in dict.fromkeys(self.sides):
+        for c in self.contexts():
             c.sync()
         self.ctx.sync()
+
+    def close(self):
+        """Wait for everything queued, then close the contexts this pipeline created (their streams go back to the
+        library's cache)."""
+        self.sync()
+        for c in self._owned:
+            c.close()
+        self._owned = []

@@ -149,8 +149,7 @@ def one_round(ctx, seed, verbose=False):
                 got = op.step(nxt)
                 op.sync()
                 same(got.download().reshape(got.shape)[:n, :n], S["three"], "OverlappedPipeline with split lists")
-            for c in dict.fromkeys(op.sides):
-                c.close()
+            op.close()
         # neighbour lists of a random row block: the same neighbour set and the exact integer dot products
         lo = int(rng.integers(0, n))
         hi = int(rng.integers(lo + 1, n + 1))

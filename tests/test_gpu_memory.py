@@ -166,6 +166,5 @@ def test_batch_uploader_stream_equals_resident_batches(ctx):
         assert (got == want[i]).all(), i
     pipe.sync()
     assert up.host_waits <= len(packed)
-    for c in dict.fromkeys(pipe.sides):
-        c.close()
+    pipe.close()
     up.close()
