@@ -83,7 +83,9 @@ class BatchUploader:
     asynchronous copies - no allocation, no fill, no host wait per batch - and returns a SeqBatch whose `ready` event a
     consumer on another context waits for ON THE DEVICE (engine.OverlappedPipeline.prefetch does).  A slot is refilled
     only behind the event the consumer recorded after queuing the slot's last reader (`on_consumed`), and its staging
-    buffer only once the copy out of it has run.
+    buffer only once the copy out of it has run.  The caller hands every batch to a pipeline before `slots` further
+    uploads come round to its slot (bench.py keeps two uploads ahead of the vectorize with three slots): a batch that no
+    pipeline has taken has no reader to wait for and would be overwritten.
 
         up = BatchUploader(ctx, max_residues, max_sequences, slots=3)
         pipe.prefetch(up.upload(res0, off0))
